@@ -1,0 +1,306 @@
+/* jpeg_gpu_amd — MI355X-native JPEG block-decode path: C-ABI boundary.
+ *
+ * This header is the drop-in boundary.  It has three parts:
+ *
+ *  1. The data model the reference harness already speaks (struct image,
+ *     image_plane, jpeg_header, jpeg_component, jpeg_quant, jpeg_info, the
+ *     jpeg_decode_out stage enum and the jpeg_decode_ctx_vtbl plugin table).
+ *     These are restated field-for-field because they ARE the interface:
+ *       image / image_plane ......... reference src/image.h:25-51
+ *       jpeg_quant .. jpeg_info ..... reference src/jpeg_info.h:37-71
+ *       jpeg_decode_out, vtbl ....... reference src/jpeg_wrap.h:22-51
+ *     If the reference's own headers were included first (their include
+ *     guards _image_H / _jpeg_info_H / _jpeg_wrap_H are defined) the
+ *     restatement is skipped, so a maintainer can include both.
+ *
+ *  2. HIPJPEG_DECODE_CTX_VTBL — the plugin instance that sits where
+ *     XJPEG_DECODE_CTX_VTBL / LIBJPEG_DECODE_CTX_VTBL sit
+ *     (reference src/jpeg_wrap.h:53-54, selected at src/jpeg_gpu.c:545-557).
+ *
+ *  3. jga_* entry points: the pieces of the hot path as plain C calls (layout,
+ *     host entropy decode, device launches on resident coefficient planes,
+ *     the pipelined batch decoder).  No torch / HIP types appear: device
+ *     pointers are void*, streams are void* (a hipStream_t).
+ *
+ * All functions returning int use the reference's convention
+ * (src/jpeg_wrap.c:269-283, 329-339): 0 = EXIT_SUCCESS, 1 = EXIT_FAILURE, with
+ * a one-line message on stderr (also retrievable via jga_last_error()).
+ */
+#ifndef JPEG_GPU_AMD_H
+#define JPEG_GPU_AMD_H (1)
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* 1. Data model (ABI-identical to the reference; sizes asserted in abi.c)   */
+/* ------------------------------------------------------------------------ */
+
+#if !defined(_jpeg_info_H)
+# define NCOMPS_MAX (3)
+# define NQUANT_MAX (4)
+
+typedef enum jpeg_subsamp {
+  JPEG_SUBSAMP_UNKNOWN,
+  JPEG_SUBSAMP_444,
+  JPEG_SUBSAMP_422,
+  JPEG_SUBSAMP_420,
+  JPEG_SUBSAMP_440,
+  JPEG_SUBSAMP_411,
+  JPEG_SUBSAMP_MONO,
+  JPEG_SUBSAMP_MAX
+} jpeg_subsamp;
+
+typedef struct jpeg_quant {
+  int valid;
+  unsigned char bits;          /* 8 or 16 */
+  unsigned short tbl[64];      /* NATURAL (de-zigzagged) order, xjpeg.c:240,245 */
+} jpeg_quant;
+
+typedef struct jpeg_component {
+  int hblocks;                 /* nhmb*hsamp: MCU-padded width in blocks  */
+  int vblocks;                 /* nvmb*vsamp: MCU-padded height in blocks */
+  int hsamp;
+  int vsamp;
+  jpeg_quant *quant;           /* points INTO the owning jpeg_header */
+} jpeg_component;
+
+typedef struct jpeg_header {
+  int bits;
+  int width;
+  int height;
+  int ncomps;
+  jpeg_subsamp subsamp;
+  int restart_interval;
+  jpeg_component comp[NCOMPS_MAX];
+  jpeg_quant quant[NQUANT_MAX];
+} jpeg_header;
+
+typedef struct jpeg_info {
+  int size;
+  unsigned char *buf;          /* caller-owned JPEG file bytes */
+} jpeg_info;
+#endif /* _jpeg_info_H */
+
+#if !defined(_image_H)
+# define NPLANES_MAX (3)
+
+typedef struct image_plane {
+  int bitdepth;
+  unsigned char xdec;
+  unsigned char ydec;
+  int xstride;
+  int ystride;
+  unsigned short width;        /* MCU-padded, = hblocks*8 */
+  unsigned short height;       /* MCU-padded, = vblocks*8 */
+  unsigned char *data;         /* ystride*height u8 samples */
+  short *coef;                 /* this plane's slice of image.coef */
+  int cstride;                 /* rows of luma-width block rows it occupies */
+  int packed;
+  int *index;
+} image_plane;
+
+typedef struct image {
+  unsigned short width;        /* true size */
+  unsigned short height;
+  int nplanes;
+  image_plane plane[NPLANES_MAX];
+  short *coef;                 /* packed coefficient planes ("quant"/"dct") */
+  int packed;
+  int *index;
+  unsigned char *pixels;       /* width*height*3 interleaved RGB (1 B/px grey) */
+} image;
+#endif /* _image_H */
+
+#if !defined(_jpeg_wrap_H)
+typedef struct jpeg_decode_ctx jpeg_decode_ctx;   /* opaque */
+
+typedef enum jpeg_decode_out {
+  JPEG_DECODE_PACK,
+  JPEG_DECODE_QUANT,
+  JPEG_DECODE_DCT,
+  JPEG_DECODE_YUV,
+  JPEG_DECODE_RGB,
+  JPEG_DECODE_OUT_MAX
+} jpeg_decode_out;
+
+typedef jpeg_decode_ctx *(*jpeg_decode_alloc_func)(jpeg_info *info);
+typedef int (*jpeg_decode_header_func)(jpeg_decode_ctx *dec,
+ jpeg_header *header);
+typedef int (*jpeg_decode_image_func)(jpeg_decode_ctx *dec, image *img,
+ jpeg_decode_out out);
+typedef void (*jpeg_decode_reset_func)(jpeg_decode_ctx *dec, jpeg_info *info);
+typedef void (*jpeg_decode_free_func)(jpeg_decode_ctx *dec);
+
+typedef struct jpeg_decode_ctx_vtbl {
+  jpeg_decode_alloc_func decode_alloc;
+  jpeg_decode_header_func decode_header;
+  jpeg_decode_image_func decode_image;
+  jpeg_decode_reset_func decode_reset;
+  jpeg_decode_free_func decode_free;
+} jpeg_decode_ctx_vtbl;
+#endif /* _jpeg_wrap_H */
+
+/* ------------------------------------------------------------------------ */
+/* 2. The plugin instance                                                    */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces XJPEG_DECODE_CTX_VTBL (reference src/jpeg_wrap.c:352-358).
+ * Call order is the reference's (src/jpeg_gpu.c:612-613, 1215, 1231-1237):
+ * alloc -> header -> [image_init] -> image, then per frame reset -> header ->
+ * image, free at exit.  Stages: QUANT and DCT fill img->coef on the host (same
+ * bytes as the reference, src/xjpeg.c:550-563); YUV fills every
+ * img->plane[i].data and RGB fills img->pixels, both computed on the GPU.
+ * PACK is rejected with "Unsupported output 'pack' for hipjpeg wrapper.". */
+extern const jpeg_decode_ctx_vtbl HIPJPEG_DECODE_CTX_VTBL;
+
+/* ------------------------------------------------------------------------ */
+/* 3. jga_* C entry points                                                   */
+/* ------------------------------------------------------------------------ */
+
+const char *jga_version(void);
+/* Last error message of the calling thread ("" if none). */
+const char *jga_last_error(void);
+
+/* --- layout: replaces image_init / image_zero / image_clear
+ *     (reference src/image.c:24-97, 99-112, 114-124).  Same fields, same
+ *     sizes, 16-byte aligned buffers; buffers come from the library's own
+ *     allocator so only jga_image_clear may free them. ------------------- */
+int  jga_image_init(image *img, jpeg_header *header);
+void jga_image_zero(image *img);
+void jga_image_clear(image *img);
+
+/* Geometry of the packed coefficient buffer and of the outputs for one frame,
+ * derived from a jpeg_header exactly as image_init + xjpeg.c:556-561 imply
+ * (SURVEY.md Appendix B).  All offsets in shorts. */
+typedef struct jga_plane_geom {
+  int hblocks;                 /* plane width  in blocks (MCU padded) */
+  int vblocks;                 /* plane height in blocks (MCU padded) */
+  int xdec;
+  int ydec;
+  int cstride;                 /* packed rows of RS shorts */
+  int qidx;                    /* which of qtab[0..2] this plane uses (= plane#) */
+  long long coef_off;          /* offset of plane base in the coef buffer */
+  long long data_off;          /* offset of plane in a concatenated YUV buffer */
+} jga_plane_geom;
+
+typedef struct jga_geom {
+  int width;                   /* true size */
+  int height;
+  int nplanes;                 /* 1 or 3 */
+  int subsamp;                 /* jpeg_subsamp */
+  int w0;                      /* luma padded width in pixels; RS = w0*8 */
+  int nhmb;                    /* MCUs per row */
+  int nvmb;                    /* MCU rows */
+  int restart_interval;
+  long long coef_shorts;       /* size of the packed coefficient buffer */
+  long long coef_blocks;       /* real coded blocks (sum hblocks*vblocks) */
+  long long yuv_bytes;         /* sum of padded plane sizes */
+  long long rgb_bytes;         /* width*height*nplanes (3 B/px colour, 1 grey) */
+  jga_plane_geom plane[NPLANES_MAX];
+} jga_geom;
+
+int jga_geom_from_header(jga_geom *g, const jpeg_header *header);
+/* Offset (in shorts) of block (bx,by) of plane p: xjpeg.c:556-561. */
+long long jga_block_offset(const jga_geom *g, int p, int bx, int by);
+
+/* --- host entropy stage: replaces xjpeg_init/xjpeg_decode_header/
+ *     xjpeg_decode_image(QUANT|DCT) (reference src/xjpeg.c:449-632, 704-780).
+ *     Bounds-checked, restart-aware; writes de-zigzagged int16 blocks in the
+ *     Appendix-B layout.  `dequant` = 0 gives the QUANT stage (raw levels),
+ *     1 gives the DCT stage (level*q truncated to int16). ---------------- */
+int jga_parse_header(const unsigned char *buf, int size, jpeg_header *header);
+int jga_entropy_decode(const unsigned char *buf, int size,
+ const jga_geom *g, short *coef, int dequant);
+/* PACK wire format (xjpeg.c:484-496, 513-519, 531-535): RLE words + per-block
+ * start index.  Returns number of words via *nwords. */
+int jga_entropy_decode_pack(const unsigned char *buf, int size,
+ const jga_geom *g, short *pack, long long pack_cap, int *index,
+ long long *nwords);
+
+/* --- device stage: dequantise + row IDCT + column IDCT + level shift/clamp
+ *     (+ chroma upsample + YCbCr->RGB) on coefficient planes RESIDENT IN HBM.
+ *     Replaces the three GLSL passes res/horz_quant_yuv.fs.glsl:81-99,
+ *     res/vert.fs.glsl:79-101, res/unyuv.fs.glsl:17-50 (and ungrey) and their
+ *     driver src/jpeg_gpu.c:1312-1365; arithmetic is the CPU path's
+ *     (src/dct.c:100-121, src/xjpeg.c:501-503,524-527,565-584).
+ *
+ *     d_coef : nimages coefficient buffers, image i at d_coef + i*coef_stride
+ *              (shorts), each in the Appendix-B layout of `g`.
+ *     d_qtab : nimages * 3 * 64 uint16, natural order, table of plane p of
+ *              image i at d_qtab[(i*3+p)*64].  (`dequant_on_device`=0 means
+ *              the coefficients are already dequantised = DCT stage input and
+ *              d_qtab may be NULL.)
+ *     d_rgb  : image i at d_rgb + i*rgb_stride, row pitch width*nplanes.
+ *     d_yuv  : image i at d_yuv + i*yuv_stride, planes concatenated at
+ *              g->plane[p].data_off, each padded, ystride = plane width.
+ *     stream : hipStream_t (NULL = default stream).  Asynchronous. -------- */
+int jga_device_count(void);
+int jga_idct_rgb_batch(const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
+ int dequant_on_device, unsigned char *d_rgb, long long rgb_stride,
+ void *stream);
+int jga_idct_yuv_batch(const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
+ int dequant_on_device, unsigned char *d_yuv, long long yuv_stride,
+ void *stream);
+/* Name of the kernel the two calls above launch for `g` (for profiles). */
+const char *jga_kernel_name(const jga_geom *g, int rgb);
+
+/* Thin device-memory helpers so C/ctypes callers need no HIP binding. */
+void *jga_device_malloc(size_t bytes);
+void  jga_device_free(void *p);
+void *jga_host_malloc_pinned(size_t bytes);
+void  jga_host_free_pinned(void *p);
+int   jga_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+int   jga_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+int   jga_device_memset(void *dst, int value, size_t bytes, void *stream);
+int   jga_stream_sync(void *stream);
+int   jga_set_device(int dev);
+void *jga_stream_create(void);
+void  jga_stream_destroy(void *stream);
+/* Time `reps` back-to-back launches of the rgb (or yuv) batch kernel with HIP
+ * events on `stream`; returns average milliseconds per launch in *ms. */
+int jga_time_idct_batch(const jga_geom *g, int nimages, const short *d_coef,
+ long long coef_stride, const unsigned short *d_qtab, int dequant_on_device,
+ unsigned char *d_out, long long out_stride, int rgb, int reps, void *stream,
+ float *ms);
+
+/* --- pipelined batch decoder (build addition; SURVEY.md §8b "batch/async
+ *     entry"): N host entropy threads -> pinned ring -> H2D on a copy stream
+ *     -> fused kernel on a compute stream (-> optional D2H).  One pipeline
+ *     per GPU; images are independent, no collectives. ------------------- */
+typedef struct jga_pipeline jga_pipeline;
+
+typedef struct jga_pipeline_config {
+  int device;                  /* HIP device ordinal */
+  int nthreads;                /* host entropy threads (0 = hardware default) */
+  int depth;                   /* pinned slots in flight (0 = 2*nthreads) */
+  int out;                     /* JPEG_DECODE_YUV or JPEG_DECODE_RGB */
+  int copy_back;               /* 1: D2H into caller's host buffers */
+  long long max_coef_shorts;   /* slot capacity (0 = sized on first submit) */
+  long long max_out_bytes;
+} jga_pipeline_config;
+
+typedef struct jga_job {
+  const unsigned char *jpeg;   /* in : file bytes (caller keeps alive) */
+  int size;
+  unsigned char *host_out;     /* in : destination if copy_back (may be NULL) */
+  unsigned char *dev_out;      /* in : device destination, or NULL = internal */
+  int status;                  /* out: 0 ok, 1 failed */
+  int width, height, nplanes;  /* out */
+} jga_job;
+
+jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);
+/* Decode jobs[0..n) ; returns when all are complete (outputs valid). */
+int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);
+void jga_pipeline_destroy(jga_pipeline *pl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEG_GPU_AMD_H */
