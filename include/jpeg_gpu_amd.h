@@ -35,9 +35,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* everything declared here is exported from libjpeg_gpu_amd.so (which is built
+ * with -fvisibility=hidden) */
+#pragma GCC visibility push(default)
 
 /* ------------------------------------------------------------------------ */
-/* 1. Data model (ABI-identical to the reference; sizes asserted in abi.c)   */
+/* 1. Data model (ABI-identical to the reference; sizes asserted in csrc/layout.c)   */
 /* ------------------------------------------------------------------------ */
 
 #if !defined(_jpeg_info_H)
@@ -217,10 +220,12 @@ int jga_parse_header(const unsigned char *buf, int size, jpeg_header *header);
 int jga_entropy_decode(const unsigned char *buf, int size,
  const jga_geom *g, short *coef, int dequant);
 /* PACK wire format (xjpeg.c:484-496, 513-519, 531-535): RLE words + per-block
- * start index.  Returns number of words via *nwords. */
+ * start index (index laid out per plane as image_init does, src/image.c:93-94).
+ * Returns the number of words via *nwords and, if plane_words != NULL, the
+ * words each plane contributed (the reference's image_plane.packed). */
 int jga_entropy_decode_pack(const unsigned char *buf, int size,
  const jga_geom *g, short *pack, long long pack_cap, int *index,
- long long *nwords);
+ long long *nwords, long long *plane_words);
 
 /* --- device stage: dequantise + row IDCT + column IDCT + level shift/clamp
  *     (+ chroma upsample + YCbCr->RGB) on coefficient planes RESIDENT IN HBM.
@@ -300,6 +305,7 @@ jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);
 int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);
 void jga_pipeline_destroy(jga_pipeline *pl);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

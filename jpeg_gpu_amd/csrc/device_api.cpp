@@ -1,0 +1,219 @@
+// device_api.cpp — C-ABI wrappers around the HIP kernels: launch descriptors,
+// device memory helpers, event timing.  This is the code that replaces the
+// reference's GL driver for the three passes (src/jpeg_gpu.c:902-1119 setup,
+// 1312-1399 per-frame upload + draws): one descriptor + one launch per batch.
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jga_internal.h"
+#include "kernel_params.h"
+
+#define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return jga_fail("HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #call); } while (0)
+
+static jga_divisor make_divisor(uint32_t d) {
+  jga_divisor r;
+  uint32_t s = 0;
+  if (d == 0) d = 1;
+  while ((1ull << s) < d) s++;
+  r.mul = (uint32_t)((1ull << (31 + s))/d + 1);
+  r.shift = 31 + s;
+  return r;
+}
+
+// 0 = strided per-lane loads, 1 = coalesced through VGPR + LDS, 2 = LDS-DMA
+static int default_loadmode(void) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("JGA_LOADMODE");
+    mode = e ? atoi(e) : 2;
+    if (mode < 0 || mode > 2) mode = 2;
+  }
+  return mode;
+}
+
+static int fill_params(jga_kparams *P, const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
+ int dequant, unsigned char *d_out, long long out_stride, int rgb) {
+  int p;
+  memset(P, 0, sizeof(*P));
+  if (nimages < 1) return jga_fail("Invalid batch size %d", nimages);
+  if (g->nplanes != 1 && g->nplanes != 3) {
+    return jga_fail("Unsupported number of components %i", g->nplanes);
+  }
+  if (dequant && !d_qtab) return jga_fail("Missing quantisation tables");
+  if (g->nplanes == 3 && (g->plane[0].xdec || g->plane[0].ydec
+   || g->plane[1].xdec != g->plane[2].xdec
+   || g->plane[1].ydec != g->plane[2].ydec)) {
+    return jga_fail("Unsupported sampling for the device stage");
+  }
+  if (coef_stride < g->coef_shorts) return jga_fail("coef_stride too small");
+  P->coef = (const int16_t *)d_coef;
+  P->qtab = (const uint16_t *)d_qtab;
+  P->out = d_out;
+  P->coef_stride = coef_stride;
+  P->out_stride = out_stride;
+  P->nimages = nimages;
+  P->nplanes = g->nplanes;
+  P->dequant = dequant ? 1 : 0;
+  P->width = g->width;
+  P->height = g->height;
+  P->w0_blocks = g->w0/8;
+  P->slots_per_image = (int)(g->coef_shorts/64);
+  P->tiles_per_row = (g->nhmb + 63)/64;
+  P->nvmb = g->nvmb;
+  P->div_w0 = make_divisor((uint32_t)P->w0_blocks);
+  for (p = 0; p < g->nplanes; p++) {
+    P->plane_hblocks[p] = g->plane[p].hblocks;
+    P->plane_vblocks[p] = g->plane[p].vblocks;
+    P->plane_xdec[p] = g->plane[p].xdec;
+    P->plane_slot0[p] = (int)(g->plane[p].coef_off/64);
+    P->plane_coef_off[p] = g->plane[p].coef_off;
+    P->plane_data_off[p] = g->plane[p].data_off;
+    P->div_hb[p] = make_divisor((uint32_t)(P->w0_blocks >> g->plane[p].xdec));
+  }
+  if (rgb) {
+    const long long pitch = (long long)g->width*g->nplanes;
+    if (out_stride < g->rgb_bytes) return jga_fail("rgb_stride too small");
+    P->out_aligned = (pitch % 4 == 0) && (out_stride % 4 == 0)
+     && (((uintptr_t)d_out) % 4 == 0);
+  }
+  else {
+    if (out_stride < g->yuv_bytes) return jga_fail("yuv_stride too small");
+    if (out_stride % 8 || ((uintptr_t)d_out) % 8) {
+      return jga_fail("YUV output must be 8-byte aligned");
+    }
+    P->out_aligned = 1;
+  }
+  if (((uintptr_t)d_coef) % 16 || coef_stride % 8) {
+    return jga_fail("Coefficient buffers must be 16-byte aligned");
+  }
+  return EXIT_SUCCESS;
+}
+
+extern "C" {
+
+JGA_EXPORT int jga_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+JGA_EXPORT int jga_idct_rgb_batch(const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
+ int dequant_on_device, unsigned char *d_rgb, long long rgb_stride,
+ void *stream) {
+  jga_kparams P;
+  int rc;
+  if (fill_params(&P, g, nimages, d_coef, coef_stride, d_qtab,
+   dequant_on_device, d_rgb, rgb_stride, 1) != EXIT_SUCCESS) {
+    return EXIT_FAILURE;
+  }
+  rc = jga_launch_rgb(&P, g->plane[1].xdec, g->plane[1].ydec, default_loadmode(),
+   stream);
+  if (rc) return jga_fail("RGB kernel launch failed (HIP error %d)", rc);
+  return EXIT_SUCCESS;
+}
+
+JGA_EXPORT int jga_idct_yuv_batch(const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
+ int dequant_on_device, unsigned char *d_yuv, long long yuv_stride,
+ void *stream) {
+  jga_kparams P;
+  int rc;
+  if (fill_params(&P, g, nimages, d_coef, coef_stride, d_qtab,
+   dequant_on_device, d_yuv, yuv_stride, 0) != EXIT_SUCCESS) {
+    return EXIT_FAILURE;
+  }
+  rc = jga_launch_yuv(&P, default_loadmode(), stream);
+  if (rc) return jga_fail("YUV kernel launch failed (HIP error %d)", rc);
+  return EXIT_SUCCESS;
+}
+
+JGA_EXPORT const char *jga_kernel_name(const jga_geom *g, int rgb) {
+  if (!rgb) return "jga_idct_yuv_kernel";
+  return g->nplanes == 1 ? "jga_idct_grey_kernel" : "jga_idct_rgb_kernel";
+}
+
+JGA_EXPORT int jga_time_idct_batch(const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
+ int dequant_on_device, unsigned char *d_out, long long out_stride, int rgb,
+ int reps, void *stream, float *ms) {
+  hipEvent_t e0, e1;
+  int i, rc = EXIT_SUCCESS;
+  float t = 0.0f;
+  if (reps < 1) reps = 1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
+  for (i = 0; i < reps && rc == EXIT_SUCCESS; i++) {
+    rc = rgb ? jga_idct_rgb_batch(g, nimages, d_coef, coef_stride, d_qtab,
+     dequant_on_device, d_out, out_stride, stream)
+     : jga_idct_yuv_batch(g, nimages, d_coef, coef_stride, d_qtab,
+     dequant_on_device, d_out, out_stride, stream);
+  }
+  HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (ms) *ms = t/(float)reps;
+  return rc;
+}
+
+// ---- thin device-memory helpers -------------------------------------------
+
+JGA_EXPORT void *jga_device_malloc(size_t bytes) {
+  void *p = NULL;
+  if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    jga_fail("hipMalloc(%zu) failed", bytes);
+    return NULL;
+  }
+  return p;
+}
+JGA_EXPORT void jga_device_free(void *p) { if (p) (void)hipFree(p); }
+
+JGA_EXPORT void *jga_host_malloc_pinned(size_t bytes) {
+  void *p = NULL;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    jga_fail("hipHostMalloc(%zu) failed", bytes);
+    return NULL;
+  }
+  return p;
+}
+JGA_EXPORT void jga_host_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
+
+JGA_EXPORT int jga_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_device_memset(void *dst, int value, size_t bytes, void *stream) {
+  HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_stream_sync(void *stream) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_set_device(int dev) {
+  HIP_TRY(hipSetDevice(dev));
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT void *jga_stream_create(void) {
+  hipStream_t s = NULL;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    jga_fail("hipStreamCreate failed");
+    return NULL;
+  }
+  return (void *)s;
+}
+JGA_EXPORT void jga_stream_destroy(void *stream) {
+  if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+}
+
+}  // extern "C"

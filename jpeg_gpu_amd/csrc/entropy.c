@@ -1,0 +1,619 @@
+/* entropy.c — host entropy stage: baseline JPEG bytes -> packed coefficient
+ * planes.  north_star keeps this stage on the host ("the branchy Huffman
+ * entropy decode ... stays on the host in C"); it feeds the HIP kernels.
+ *
+ * Replaces, with the same outputs on every conforming baseline stream:
+ *   marker loop ............ reference src/xjpeg.c:704-763
+ *   DQT / DHT / SOF0 / DRI .. src/xjpeg.c:219-256, 258-345, 350-410, 412-420
+ *   SOS + scan loop ........ src/xjpeg.c:634-695, 449-632
+ *   header copy-out ........ src/jpeg_wrap.c:263-319
+ * Output contract: 64 de-zigzagged int16 per block
+ * at jga_block_offset(); QUANT stage = raw levels with the DC predictor
+ * accumulated in int16 (xjpeg.c:480, 498-499); DCT stage = level*q truncated
+ * to int16 (xjpeg.c:501-503, 524-527); PACK = RLE words (xjpeg.c:484-496,
+ * 513-519, 531-535).
+ *
+ * This is NOT the reference's decoder restated (that lives in oracle/): it is
+ * a bounds-checked decoder with a 64-bit bit window refilled 8 bytes at a
+ * time, a 10-bit Huffman lookup and a combined code+magnitude AC lookup.
+ * Unlike the reference's default build (no validation) it never
+ * reads or writes out of bounds on malformed input.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jga_internal.h"
+
+#define FAST_BITS 10
+
+typedef struct htab {
+  int valid;
+  uint16_t fast[1 << FAST_BITS];     /* (len << 8) | symbol, 0 = longer code */
+  int32_t fast_ac[1 << FAST_BITS];   /* (value << 8) | (run << 4) | total bits */
+  uint32_t maxcode[18];              /* left-aligned 16-bit exclusive bounds */
+  int32_t delta[17];                 /* symbol index = code + delta[len] */
+  uint8_t sym[256];
+  int nsym;
+} htab;
+
+typedef struct comp_info {
+  int id, hs, vs, tq, td, ta;
+} comp_info;
+
+typedef struct parser {
+  const uint8_t *buf;
+  long size, pos;
+  int width, height, bits, ncomps;
+  int restart_interval;
+  int frame_valid, scan_valid;
+  comp_info comp[3];
+  jpeg_quant quant[NQUANT_MAX];
+  htab dc[4], ac[4];
+} parser;
+
+static int DEZZ[64];   /* zig-zag position -> natural index (T.81 Fig. A.6) */
+static void init_dezz(void) {
+  int k = 0, s, i;
+  if (DEZZ[63] == 63) return;
+  for (s = 0; s < 15; s++) {
+    for (i = 0; i <= s; i++) {
+      int r = (s & 1) ? i : s - i, c = s - r;
+      if (r < 8 && c < 8) DEZZ[k++] = r*8 + c;
+    }
+  }
+}
+
+/* ---- segment parsing ---------------------------------------------------- */
+
+static int need(parser *ps, long n) { return ps->pos + n <= ps->size; }
+static int rd8(parser *ps) { return ps->buf[ps->pos++]; }
+static int rd16(parser *ps) {
+  int v = (ps->buf[ps->pos] << 8) | ps->buf[ps->pos + 1];
+  ps->pos += 2;
+  return v;
+}
+
+static int parse_dqt(parser *ps, long end) {
+  init_dezz();
+  while (ps->pos < end) {
+    int b, pq, tq, k;
+    b = rd8(ps);
+    pq = b >> 4;
+    tq = b & 15;
+    if (pq > 1 || tq > 3) return jga_fail("Error DQT expected Pq 0..1, Tq 0..3.");
+    if (ps->pos + 64*(pq + 1) > end) return jga_fail("Error decoding DQT, truncated.");
+    ps->quant[tq].valid = 1;
+    ps->quant[tq].bits = pq ? 16 : 8;
+    for (k = 0; k < 64; k++) {
+      ps->quant[tq].tbl[DEZZ[k]] = (unsigned short)(pq ? rd16(ps) : rd8(ps));
+    }
+  }
+  return EXIT_SUCCESS;
+}
+
+static int build_htab(htab *h, const uint8_t counts[16], const uint8_t *syms,
+ int is_ac) {
+  unsigned code = 0;
+  int k = 0, len, i;
+  uint8_t size[257];
+  uint16_t codes[256];
+  memset(h, 0, sizeof(*h));
+  for (len = 1; len <= 16; len++) {
+    for (i = 0; i < counts[len - 1]; i++) {
+      if (k >= 256) return 1;
+      size[k] = (uint8_t)len;
+      codes[k] = (uint16_t)code;
+      h->sym[k] = syms[k];
+      k++;
+      code++;
+    }
+    if (code > (1u << len)) return 1;         /* over-subscribed */
+    h->delta[len] = k - (int)code;            /* index of code c = c + delta */
+    h->maxcode[len] = code << (16 - len);
+    code <<= 1;
+  }
+  h->maxcode[17] = 0xFFFFFFFFu;
+  h->nsym = k;
+  for (i = 0; i < k; i++) {
+    int s = size[i];
+    if (s <= FAST_BITS) {
+      unsigned c = (unsigned)codes[i] << (FAST_BITS - s);
+      unsigned m = 1u << (FAST_BITS - s), j;
+      for (j = 0; j < m; j++) h->fast[c + j] = (uint16_t)((s << 8) | h->sym[i]);
+    }
+  }
+  if (is_ac) {
+    for (i = 0; i < (1 << FAST_BITS); i++) {
+      int e = h->fast[i];
+      if (e) {
+        int rs = e & 255, len0 = e >> 8;
+        int run = rs >> 4, mag = rs & 15;
+        if (mag && len0 + mag <= FAST_BITS) {
+          int v = (i >> (FAST_BITS - len0 - mag)) & ((1 << mag) - 1);
+          if (v < (1 << (mag - 1))) v -= (1 << mag) - 1;
+          h->fast_ac[i] = (int32_t)((uint32_t)v << 8) | (run << 4) | (len0 + mag);
+        }
+      }
+    }
+  }
+  h->valid = 1;
+  return 0;
+}
+
+static int parse_dht(parser *ps, long end) {
+  while (ps->pos < end) {
+    int b, tc, th, n = 0, i;
+    const uint8_t *counts;
+    if (ps->pos + 17 > end) return jga_fail("Error decoding DHT, truncated.");
+    b = rd8(ps);
+    tc = b >> 4;
+    th = b & 15;
+    if (tc > 1 || th > 3) return jga_fail("Error DHT expected Tc 0..1, Th 0..3.");
+    counts = ps->buf + ps->pos;
+    ps->pos += 16;
+    for (i = 0; i < 16; i++) n += counts[i];
+    if (n > 256 || ps->pos + n > end) {
+      return jga_fail("Error DHT needs more bytes than available.");
+    }
+    if (build_htab(tc ? &ps->ac[th] : &ps->dc[th], counts, ps->buf + ps->pos, tc)) {
+      return jga_fail("Error invalid DHT.");
+    }
+    if (!tc) {
+      for (i = 0; i < n; i++) {
+        if (ps->buf[ps->pos + i] > 15) return jga_fail("Error invalid DC symbol.");
+      }
+    }
+    ps->pos += n;
+  }
+  return EXIT_SUCCESS;
+}
+
+static int parse_sof0(parser *ps, long end) {
+  int i;
+  if (ps->frame_valid) return jga_fail("Error multiple SOF not supported.");
+  if (end - ps->pos < 6) return jga_fail("Error SOF needs at least 9 bytes");
+  ps->bits = rd8(ps);
+  ps->height = rd16(ps);
+  ps->width = rd16(ps);
+  ps->ncomps = rd8(ps);
+  if (ps->bits != 8) return jga_fail("Unsupported sample precision %i", ps->bits);
+  if (!ps->height) return jga_fail("Error SOF has invalid height.");
+  if (!ps->width) return jga_fail("Error SOF has invalid width.");
+  if (ps->ncomps != 1 && ps->ncomps != 3) {
+    return jga_fail("Unsupported number of components %i", ps->ncomps);
+  }
+  if (end - ps->pos != 3*ps->ncomps) {
+    return jga_fail("Error decoding SOF, wrong length.");
+  }
+  for (i = 0; i < ps->ncomps; i++) {
+    comp_info *c = &ps->comp[i];
+    int b;
+    c->id = rd8(ps);
+    b = rd8(ps);
+    c->hs = b >> 4;
+    c->vs = b & 15;
+    c->tq = rd8(ps);
+    if (c->hs != 1 && c->hs != 2 && c->hs != 4) {
+      return jga_fail("Unsupported horizontal sampling.");
+    }
+    if (c->vs != 1 && c->vs != 2 && c->vs != 4) {
+      return jga_fail("Unsupported vertical sampling.");
+    }
+    if (c->tq > 3) return jga_fail("Error SOF expected Tq value 0 to 3.");
+  }
+  ps->frame_valid = 1;
+  return EXIT_SUCCESS;
+}
+
+static int parse_sos(parser *ps, long end) {
+  int n, i, j;
+  if (!ps->frame_valid) return jga_fail("Error SOS before SOF.");
+  if (ps->scan_valid) return jga_fail("Error multiple SOS not supported.");
+  if (end - ps->pos < 1) return jga_fail("Error SOS needs at least 6 bytes");
+  n = rd8(ps);
+  if (n != ps->ncomps) {
+    return jga_fail("Error only single-scan files with all components supported");
+  }
+  if (end - ps->pos != 2*n + 3) return jga_fail("Error decoding SOS, wrong length.");
+  for (i = 0; i < n; i++) {
+    int id = rd8(ps), b = rd8(ps);
+    j = i;
+    /* scan order must equal frame order (the reference assumes it,
+       src/xjpeg.c:437-443; interleaving order is defined by the frame) */
+    if (ps->comp[j].id != id) {
+      return jga_fail("Error SOS component order differs from SOF.");
+    }
+    ps->comp[j].td = b >> 4;
+    ps->comp[j].ta = b & 15;
+    if (ps->comp[j].td > 3 || !ps->dc[ps->comp[j].td].valid) {
+      return jga_fail("Error SOS component references invalid DC entropy table.");
+    }
+    if (ps->comp[j].ta > 3 || !ps->ac[ps->comp[j].ta].valid) {
+      return jga_fail("Error SOS component references invalid AC entropy table.");
+    }
+  }
+  if (rd8(ps) != 0) return jga_fail("Error SOS expected Ss value 0.");
+  if (rd8(ps) != 63) return jga_fail("Error SOS expected Se value 63.");
+  if (rd8(ps) != 0) return jga_fail("Error SOS expected Ah/Al value 0.");
+  for (i = 0; i < n; i++) {
+    if (!ps->quant[ps->comp[i].tq].valid) {
+      return jga_fail("Invalid quantization table for components %i", i);
+    }
+  }
+  ps->scan_valid = 1;
+  return EXIT_SUCCESS;
+}
+
+/* Walk the marker segments up to and including SOS.  On success ps->pos is the
+ * first byte of entropy-coded data. */
+static int parse_to_scan(parser *ps, const uint8_t *buf, long size) {
+  memset(ps, 0, sizeof(*ps));
+  ps->buf = buf;
+  ps->size = size;
+  if (size < 4 || buf[0] != 0xFF || buf[1] != 0xD8) {
+    return jga_fail("Error, not a JPEG (invalid SOI marker).");
+  }
+  ps->pos = 2;
+  for (;;) {
+    int marker, rc = EXIT_SUCCESS;
+    long len, end;
+    if (!need(ps, 2)) return jga_fail("Error underflow reading marker.");
+    if (ps->buf[ps->pos] != 0xFF) return jga_fail("Error, invalid JPEG syntax.");
+    while (ps->pos < ps->size && ps->buf[ps->pos] == 0xFF) ps->pos++;  /* fill */
+    if (!need(ps, 1)) return jga_fail("Error underflow reading marker.");
+    marker = rd8(ps);
+    if (marker == 0xD8 || (marker >= 0xD0 && marker <= 0xD7) || marker == 0x01) {
+      continue;                                   /* standalone markers */
+    }
+    if (marker == 0xD9) return jga_fail("Error, EOI before any scan.");
+    if (!need(ps, 2)) return jga_fail("Error reading past the end of file.");
+    len = rd16(ps);
+    end = ps->pos + len - 2;
+    if (len < 2 || end > ps->size) return jga_fail("Error skipping past the end of file.");
+    switch (marker) {
+      case 0xDB : rc = parse_dqt(ps, end); break;
+      case 0xC4 : rc = parse_dht(ps, end); break;
+      case 0xC0 : rc = parse_sof0(ps, end); break;
+      case 0xDD : {
+        if (len != 4) return jga_fail("Error decoding DRI, unprocessed bytes.");
+        ps->restart_interval = rd16(ps);
+        break;
+      }
+      case 0xDA : {
+        rc = parse_sos(ps, end);
+        if (rc == EXIT_SUCCESS) ps->pos = end;
+        return rc;
+      }
+      case 0xC1 : case 0xC2 : case 0xC3 : case 0xC5 : case 0xC6 : case 0xC7 :
+      case 0xC9 : case 0xCA : case 0xCB : case 0xCD : case 0xCE : case 0xCF : {
+        return jga_fail("Unsupported JPEG process (SOF%i); baseline only.", marker & 15);
+      }
+      default : break;                            /* APPn, COM, ... skipped */
+    }
+    if (rc != EXIT_SUCCESS) return rc;
+    ps->pos = end;
+  }
+}
+
+static void fill_header(const parser *ps, jpeg_header *h) {
+  int i, hmax = 0, vmax = 0, nhmb, nvmb;
+  memset(h, 0, sizeof(*h));
+  h->bits = ps->bits;
+  h->width = ps->width;
+  h->height = ps->height;
+  h->ncomps = ps->ncomps;
+  h->restart_interval = ps->restart_interval;
+  for (i = 0; i < NQUANT_MAX; i++) h->quant[i] = ps->quant[i];
+  for (i = 0; i < ps->ncomps; i++) {
+    if (ps->comp[i].hs > hmax) hmax = ps->comp[i].hs;
+    if (ps->comp[i].vs > vmax) vmax = ps->comp[i].vs;
+  }
+  nhmb = (ps->width + 8*hmax - 1)/(8*hmax);
+  nvmb = (ps->height + 8*vmax - 1)/(8*vmax);
+  for (i = 0; i < ps->ncomps; i++) {
+    h->comp[i].hsamp = ps->comp[i].hs;
+    h->comp[i].vsamp = ps->comp[i].vs;
+    h->comp[i].hblocks = nhmb*ps->comp[i].hs;
+    h->comp[i].vblocks = nvmb*ps->comp[i].vs;
+    h->comp[i].quant = &h->quant[ps->comp[i].tq];
+  }
+  if (ps->ncomps == 1) h->subsamp = JPEG_SUBSAMP_MONO;
+  else {
+    h->subsamp = (jpeg_subsamp)jga_subsamp_of(
+     jga_ilog(ps->comp[0].hs) - jga_ilog(ps->comp[1].hs),
+     jga_ilog(ps->comp[0].vs) - jga_ilog(ps->comp[1].vs), 3);
+  }
+}
+
+JGA_EXPORT int jga_parse_header(const unsigned char *buf, int size,
+ jpeg_header *header) {
+  parser *ps = (parser *)malloc(sizeof(parser));
+  int rc;
+  if (!ps) return jga_fail("Out of memory");
+  rc = parse_to_scan(ps, buf, size);
+  if (rc == EXIT_SUCCESS) fill_header(ps, header);
+  free(ps);
+  return rc;
+}
+
+/* ---- bit reader --------------------------------------------------------- */
+
+typedef struct bitreader {
+  uint64_t bits;       /* MSB-aligned window; only the top nbits are promised */
+  int nbits;
+  const uint8_t *p, *end;
+  int marker;          /* marker byte that stopped the refill, 0 = none */
+  long zeros;          /* pad bytes fed after the data ran out */
+} bitreader;
+
+static inline uint64_t load_be64(const uint8_t *p) {
+  uint64_t w;
+  memcpy(&w, p, 8);
+  return __builtin_bswap64(w);
+}
+
+static void refill_slow(bitreader *br) {
+  br->bits &= br->nbits ? ~(uint64_t)0 << (64 - br->nbits) : 0;
+  while (br->nbits <= 56) {
+    unsigned b;
+    if (br->marker || br->p >= br->end) {
+      if (!br->marker) br->marker = 0xD9;          /* ran off the buffer */
+      br->nbits += 8;
+      br->zeros++;
+      continue;
+    }
+    b = *br->p;
+    if (b == 0xFF) {
+      unsigned b2 = br->p + 1 < br->end ? br->p[1] : 0xD9;
+      if (b2 == 0x00) br->p += 2;                  /* stuffed zero */
+      else if (b2 == 0xFF) { br->p++; continue; }  /* fill byte */
+      else { br->marker = (int)b2; continue; }     /* stay on the FF */
+    }
+    else br->p++;
+    br->bits |= (uint64_t)b << (56 - br->nbits);
+    br->nbits += 8;
+  }
+}
+
+/* After this at least 57 bits are available (real or padding). */
+static inline void refill(bitreader *br) {
+  if (br->p + 8 <= br->end && !br->marker) {
+    uint64_t w = load_be64(br->p);
+    uint64_t x = ~w;
+    if (!((x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL)) {
+      br->bits |= w >> br->nbits;
+      br->p += (63 - br->nbits) >> 3;
+      br->nbits |= 56;
+      return;
+    }
+  }
+  refill_slow(br);
+}
+
+#define PEEK(br, n) ((unsigned)((br)->bits >> (64 - (n))))
+#define SKIP(br, n) ((br)->bits <<= (n), (br)->nbits -= (n))
+
+/* Decode one Huffman symbol; needs >= 16 bits in the window. */
+static inline int huff_symbol(bitreader *br, const htab *h) {
+  unsigned e = h->fast[PEEK(br, FAST_BITS)];
+  unsigned code;
+  int len;
+  if (e) {
+    SKIP(br, e >> 8);
+    return (int)(e & 255);
+  }
+  code = PEEK(br, 16);
+  len = FAST_BITS + 1;
+  while (code >= h->maxcode[len]) len++;
+  if (len > 16) return -1;
+  SKIP(br, len);
+  return h->sym[((int)(code >> (16 - len)) + h->delta[len]) & 255];
+}
+
+static inline int receive_extend(bitreader *br, int s) {
+  int v = (int)PEEK(br, s);
+  SKIP(br, s);
+  if (v < (1 << (s - 1))) v -= (1 << s) - 1;
+  return v;
+}
+
+/* ---- scan --------------------------------------------------------------- */
+
+typedef struct scan_out {
+  int stage;
+  short *coef;
+  short *pack;
+  long long pack_cap, nwords;
+  long long plane_words[3];
+  int *index;
+} scan_out;
+
+/* One block.  `blk` receives 64 natural-order shorts (QUANT/DCT stages). */
+static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
+ const unsigned short *q, short *pred, short *blk, scan_out *so, int stage) {
+  int s, k;
+  refill(br);
+  s = huff_symbol(br, dc);
+  if (s < 0 || s > 15) return jga_fail("Error invalid DC code.");
+  if (s) *pred = (short)(*pred + receive_extend(br, s));
+  if (stage == JGA_STAGE_PACK) {
+    if (so->nwords + 66 > so->pack_cap) return jga_fail("Error PACK buffer too small.");
+    so->pack[so->nwords++] = (short)(*pred & 0xfff);
+  }
+  else {
+    memset(blk, 0, 64*sizeof(short));
+    blk[0] = stage == JGA_STAGE_DCT ? (short)(*pred*q[0]) : *pred;
+  }
+  for (k = 1; k < 64;) {
+    int e, rs, r, v;
+    refill(br);
+    e = ac->fast_ac[PEEK(br, FAST_BITS)];
+    if (e) {
+      r = (e >> 4) & 15;
+      s = 1;
+      v = e >> 8;
+      SKIP(br, e & 15);
+    }
+    else {
+      rs = huff_symbol(br, ac);
+      if (rs < 0) return jga_fail("Error invalid AC code.");
+      if (rs == 0) {                               /* EOB */
+        if (stage == JGA_STAGE_PACK) so->pack[so->nwords++] = 0;
+        break;
+      }
+      r = rs >> 4;
+      s = rs & 15;
+      v = s ? receive_extend(br, s) : 0;
+    }
+    k += r;
+    if (k > 63) return jga_fail("Error indexing outside block.");
+    if (stage == JGA_STAGE_PACK) {
+      so->pack[so->nwords++] = (short)((r << 12) | (v & 0xfff));
+    }
+    else if (s) {
+      int n = DEZZ[k];
+      blk[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v;
+    }
+    k++;
+  }
+  return EXIT_SUCCESS;
+}
+
+static int next_restart(bitreader *br, int expect) {
+  if (br->zeros*8 > br->nbits) return jga_fail("Error, entropy data ended early.");
+  if (!br->marker) {
+    /* tolerate stray bytes before the marker */
+    while (br->p + 1 < br->end
+     && !(br->p[0] == 0xFF && br->p[1] != 0x00 && br->p[1] != 0xFF)) {
+      br->p++;
+    }
+    if (br->p + 1 >= br->end) return jga_fail("Error, expected to find marker.");
+    br->marker = br->p[1];
+  }
+  if (br->marker != 0xD0 + (expect & 7)) {
+    if (br->marker >= 0xD0 && br->marker <= 0xD7) {
+      return jga_fail("Error invalid RST counter in marker.");
+    }
+    return jga_fail("Error, unknown marker found in scan.");
+  }
+  br->p += 2;
+  br->bits = 0;
+  br->nbits = 0;
+  br->marker = 0;
+  br->zeros = 0;
+  return EXIT_SUCCESS;
+}
+
+static int check_geom(const parser *ps, const jga_geom *g) {
+  jpeg_header h;
+  jga_geom mine;
+  fill_header(ps, &h);
+  if (jga_geom_from_header(&mine, &h) != EXIT_SUCCESS) return EXIT_FAILURE;
+  if (mine.width != g->width || mine.height != g->height
+   || mine.nplanes != g->nplanes || mine.coef_shorts != g->coef_shorts
+   || mine.w0 != g->w0 || mine.nhmb != g->nhmb || mine.nvmb != g->nvmb) {
+    return jga_fail("Error, image geometry does not match the JPEG headers.");
+  }
+  return EXIT_SUCCESS;
+}
+
+static int decode_scan(parser *ps, const jga_geom *g, scan_out *so,
+ const int stage) {
+  bitreader br;
+  short pred[3] = {0, 0, 0};
+  short scratch[64];
+  int mbx, mby, i, sbx, sby;
+  long mcus = 0, total = (long)g->nhmb*g->nvmb;
+  int rst = 0;
+  long long index_base[3];
+  init_dezz();
+  memset(&br, 0, sizeof(br));
+  br.p = ps->buf + ps->pos;
+  br.end = ps->buf + ps->size;
+  index_base[0] = 0;
+  for (i = 1; i < 3; i++) {
+    index_base[i] = index_base[i - 1]
+     + (long long)(g->plane[i - 1].hblocks << g->plane[i - 1].xdec)
+     *g->plane[i - 1].cstride;
+  }
+  for (mby = 0; mby < g->nvmb; mby++) {
+    for (mbx = 0; mbx < g->nhmb; mbx++) {
+      for (i = 0; i < ps->ncomps; i++) {
+        const comp_info *c = &ps->comp[i];
+        const htab *dc = &ps->dc[c->td], *ac = &ps->ac[c->ta];
+        const unsigned short *q = ps->quant[c->tq].tbl;
+        for (sby = 0; sby < c->vs; sby++) {
+          for (sbx = 0; sbx < c->hs; sbx++) {
+            int bx = mbx*c->hs + sbx, by = mby*c->vs + sby;
+            short *blk = scratch;
+            if (stage == JGA_STAGE_PACK) {
+              so->index[index_base[i] + (long long)by*g->plane[i].hblocks + bx] =
+               (int)so->nwords;
+            }
+            else blk = so->coef + jga_block_offset(g, i, bx, by);
+            {
+              const long long w0 = so->nwords;
+              if (decode_block(&br, dc, ac, q, &pred[i], blk, so, stage)
+               != EXIT_SUCCESS) {
+                return EXIT_FAILURE;
+              }
+              so->plane_words[i] += so->nwords - w0;
+            }
+          }
+        }
+      }
+      mcus++;
+      if (ps->restart_interval && mcus % ps->restart_interval == 0
+       && mcus < total) {
+        if (next_restart(&br, rst++) != EXIT_SUCCESS) return EXIT_FAILURE;
+        pred[0] = pred[1] = pred[2] = 0;
+      }
+    }
+  }
+  if (br.zeros*8 > br.nbits) return jga_fail("Error, entropy data ended early.");
+  return EXIT_SUCCESS;
+}
+
+static int run_decode(const unsigned char *buf, int size, const jga_geom *g,
+ scan_out *so) {
+  parser *ps = (parser *)malloc(sizeof(parser));
+  int rc;
+  if (!ps) return jga_fail("Out of memory");
+  rc = parse_to_scan(ps, buf, size);
+  if (rc == EXIT_SUCCESS) rc = check_geom(ps, g);
+  if (rc == EXIT_SUCCESS) {
+    /* literal stage arguments so each loop is specialised */
+    switch (so->stage) {
+      case JGA_STAGE_PACK : rc = decode_scan(ps, g, so, JGA_STAGE_PACK); break;
+      case JGA_STAGE_QUANT : rc = decode_scan(ps, g, so, JGA_STAGE_QUANT); break;
+      default : rc = decode_scan(ps, g, so, JGA_STAGE_DCT); break;
+    }
+  }
+  free(ps);
+  return rc;
+}
+
+JGA_EXPORT int jga_entropy_decode(const unsigned char *buf, int size,
+ const jga_geom *g, short *coef, int dequant) {
+  scan_out so;
+  memset(&so, 0, sizeof(so));
+  so.stage = dequant ? JGA_STAGE_DCT : JGA_STAGE_QUANT;
+  so.coef = coef;
+  return run_decode(buf, size, g, &so);
+}
+
+JGA_EXPORT int jga_entropy_decode_pack(const unsigned char *buf, int size,
+ const jga_geom *g, short *pack, long long pack_cap, int *index,
+ long long *nwords, long long *plane_words) {
+  scan_out so;
+  int rc;
+  memset(&so, 0, sizeof(so));
+  so.stage = JGA_STAGE_PACK;
+  so.pack = pack;
+  so.pack_cap = pack_cap;
+  so.index = index;
+  rc = run_decode(buf, size, g, &so);
+  if (nwords) *nwords = so.nwords;
+  if (plane_words) memcpy(plane_words, so.plane_words, sizeof(so.plane_words));
+  return rc;
+}

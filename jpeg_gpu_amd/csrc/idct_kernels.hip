@@ -1,0 +1,581 @@
+// idct_kernels.hip — the JPEG block-decode hot path as CDNA4 (gfx950) kernels.
+//
+// Replaces the reference's three fragment-shader passes and the CPU loop that
+// defines their arithmetic:
+//   dequantise ........ src/xjpeg.c:501-503, 524-527   (res/horz_quant_yuv.fs.glsl:81-99)
+//   row + column IDCT .. src/dct.c:21-87, 100-121       (res/horz.fs.glsl, res/vert.fs.glsl)
+//   +128, clamp, store . src/xjpeg.c:565-584
+//   upsample + RGB ..... res/unyuv.fs.glsl:17-50, res/ungrey.fs.glsl
+// in ONE launch with no intermediate HBM traffic (the reference writes 256 B +
+// 128 B per block between its passes).
+//
+// Bit-exactness rules: binary32, every operation
+// in the reference's association, two-step scaling, floor not trunc, NO fused
+// multiply-add — this file must be compiled with -ffp-contract=off (the build
+// also greps the ISA for v_fma/v_mad/v_fmac, see build.py).
+//
+// Mapping (MI355X-first, not a shader translation): ONE LANE OWNS ONE 8x8
+// BLOCK.  Its 64 coefficients live in 64 VGPRs, both 1-D passes run in
+// registers with compile-time indices, so there is no transpose, no cross-lane
+// traffic and no per-lane scale table.  A wave is 64 horizontally adjacent
+// blocks: its coefficient reads cover 8 KB contiguous and its pixel stores are
+// 512 B (planes) / 1536 B (RGB) contiguous runs per image row.
+//   * RGB kernel: a workgroup is a tile of 64 MCUs of one MCU row: (1<<xdec)*
+//     (1<<ydec) luma waves + one Cb wave + one Cr wave.  Chroma waves publish
+//     their 8x8 (Cb-128),(Cr-128) samples through LDS (padded, conflict-free),
+//     luma waves replicate them (s>>xdec, t>>ydec), convert and store
+//     interleaved RGB straight from registers.
+//   * YUV kernel: flat — every wave takes 64 consecutive 128-byte blocks of the
+//     packed coefficient buffer and stores 8x8 u8 tiles into the padded planes.
+// No MFMA: there is no dense contraction here; the kernel is HBM-bound
+// (6 B/px in+out) with ~37 VALU lane-ops/px next to it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernel_params.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+
+#define DEV static __device__ __forceinline__
+
+// n / d for n < 2^31 with a host-precomputed reciprocal (kernel_params.h):
+// keeps integer division (which hipcc expands through float rcp + fma) out of
+// the kernels, so the "no fma in the ISA" build check can be strict.
+DEV uint32_t fastdiv(uint32_t n, jga_divisor d) {
+  return (uint32_t)(((uint64_t)n*d.mul) >> d.shift);
+}
+
+// ---- constants (closed forms) ------------------
+#define S0 0.35355339059327373f   // 1/(2*sqrt(2))      3eb504f3
+#define S1 0.49039264020161522f   // cos(1*pi/16)/2     3efb14be
+#define S2 0.46193976625564337f   // cos(2*pi/16)/2     3eec835e
+#define S3 0.41573480615127262f   // cos(3*pi/16)/2     3ed4db31
+#define S4 0.35355339059327373f   // cos(4*pi/16)/2     3eb504f3
+#define S5 0.27778511650980114f   // cos(5*pi/16)/2     3e8e39da
+#define S6 0.19134171618254492f   // cos(6*pi/16)/2     3e43ef15
+#define S7 0.097545161008064166f  // cos(7*pi/16)/2     3dc7c5c2
+#define C1 1.4142135623730951f    // sqrt(2)
+#define C2 1.8477590650225735f    // 2cos(pi/8)
+#define C3 1.0823922002923938f    // 2(cos(pi/8)-sin(pi/8))
+#define C4 2.6131259297527532f    // 2(cos(pi/8)+sin(pi/8))
+
+// 1-D 8-point scaled IDCT, operation for operation src/dct.c:39-86.
+DEV void idct8(float y0, float y1, float y2, float y3, float y4, float y5,
+ float y6, float y7, float &x0, float &x1, float &x2, float &x3, float &x4,
+ float &x5, float &x6, float &x7) {
+  // embedded 4-point DCT-II on the even inputs (dct.c:47-55)
+  float e0 = y0 + y4;
+  float e1 = y0 - y4;
+  float e3 = y2 + y6;
+  float e2 = (y2 - y6)*C1 - e3;
+  float a0 = e0 + e3;
+  float a3 = e0 - e3;
+  float a1 = e1 + e2;
+  float a2 = e1 - e2;
+  // embedded 4-point DST-IV on the odd inputs (dct.c:57-69)
+  float p5 = y5 + y3;
+  float p6 = y5 - y3;
+  float p7 = y1 + y7;
+  float p4 = y1 - y7;
+  float b7 = p7 + p5;
+  float o5 = (p7 - p5)*C1;
+  float o8 = (p4 + p6)*C2;
+  float o4 = o8 - p4*C3;
+  float o6 = o8 - p6*C4;
+  float b6 = b7 - o6;
+  float b5 = b6 + o5;
+  float b4 = b5 - o4;
+  // butterflies (dct.c:71-86)
+  x0 = a0 + b7;
+  x7 = a0 - b7;
+  x6 = a1 + b6;
+  x1 = a1 - b6;
+  x2 = a2 + b5;
+  x5 = a2 - b5;
+  x4 = a3 + b4;
+  x3 = a3 - b4;
+}
+
+// Dequantise + scale one coefficient row (8 int16 in 4 dwords) into floats:
+//   c = (int16)(level*q)            xjpeg.c:501-503, 524-527 (wraps mod 2^16)
+//   t = ((float)c * S[j]) * S[i]    dct.c:107-108 (two roundings)
+template <bool DEQUANT>
+DEV void load_row(const uint4 raw, const uint32_t *__restrict__ q /*4 dwords*/,
+ const float sj, float *t) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  const float si[8] = {S0, S1, S2, S3, S4, S5, S6, S7};
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    uint32_t c = w[d];
+    if (DEQUANT) {
+      v2us lv = __builtin_bit_cast(v2us, w[d]);
+      v2us qv = __builtin_bit_cast(v2us, q[d]);
+      c = __builtin_bit_cast(uint32_t, (v2us)(lv*qv));   // v_pk_mul_lo_u16
+    }
+    float lo = (float)(short)(c & 0xffffu);
+    float hi = (float)(short)(c >> 16);
+    t[2*d] = (lo*sj)*si[2*d];
+    t[2*d + 1] = (hi*sj)*si[2*d + 1];
+  }
+}
+
+// Full 2-D transform of one block held by this lane.  rows[r] = 16 bytes of
+// coefficient row r; q = 32 dwords (64 u16, natural order).  On return
+// t[k*8+i] = floor(idct)(row k, col i) as an integer-valued float, already
+// passed through the (short) wrap of dct.c:118 when it can matter.
+template <bool DEQUANT>
+DEV void idct_block(const uint4 (&rows)[8], const uint32_t *__restrict__ q,
+ float (&t)[64]) {
+  const float sj[8] = {S0, S1, S2, S3, S4, S5, S6, S7};
+  float z[64];
+  // scale + row pass (dct.c:105-111)
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    float y[8];
+    load_row<DEQUANT>(rows[r], q + 4*r, sj[r], y);
+    idct8(y[0], y[1], y[2], y[3], y[4], y[5], y[6], y[7], z[r*8 + 0],
+     z[r*8 + 1], z[r*8 + 2], z[r*8 + 3], z[r*8 + 4], z[r*8 + 5], z[r*8 + 6],
+     z[r*8 + 7]);
+  }
+  // column pass: vector i = row-pass outputs at column i over rows 0..7,
+  // +0.5 on its first entry (dct.c:112-115)
+  float m = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float o[8];
+    idct8(z[0*8 + i] + 0.5f, z[1*8 + i], z[2*8 + i], z[3*8 + i], z[4*8 + i],
+     z[5*8 + i], z[6*8 + i], z[7*8 + i], o[0], o[1], o[2], o[3], o[4], o[5],
+     o[6], o[7]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      float f = __builtin_floorf(o[k]);          // dct.c:118 floor
+      t[k*8 + i] = f;
+    }
+    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[0*8 + i]),
+     __builtin_fabsf(t[1*8 + i])));
+    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[2*8 + i]),
+     __builtin_fabsf(t[3*8 + i])));
+    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[4*8 + i]),
+     __builtin_fabsf(t[5*8 + i])));
+    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[6*8 + i]),
+     __builtin_fabsf(t[7*8 + i])));
+  }
+  // (short) cast of dct.c:118: x86-64 converts through int32 and keeps the
+  // low 16 bits.  Only reachable with |coefficients| far outside what a JPEG
+  // encoder emits, so it is a rarely taken exact path, not the main one.
+  if (__builtin_expect(!(m < 32000.0f), 0)) {
+#pragma unroll
+    for (int n = 0; n < 64; n++) t[n] = (float)(short)(int)t[n];
+  }
+}
+
+DEV uint32_t pack_u8x4(float a, float b, float c, float d) {
+  // v_cvt_pk_u8_f32 converts with saturation to [0,255]; inputs here are
+  // already integer-valued so its rounding mode is irrelevant.
+  uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(a, 0, 0);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(b, 1, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(c, 2, r);
+  r = __builtin_amdgcn_cvt_pk_u8_f32(d, 3, r);
+  return r;
+}
+
+// u8 = (int)(clamp(c,0,255) + 0.5f)   == sat_u8(floor(c+0.5f))
+DEV float unorm8(float c) { return __builtin_floorf(c + 0.5f); }
+
+// Fetch the 8 coefficient rows of the block at `src` (128 contiguous bytes).
+DEV void load_block_direct(const int16_t *__restrict__ src, uint4 (&rows)[8]) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+  for (int r = 0; r < 8; r++) rows[r] = p[r];
+}
+
+// Coalesced fetch of a wave's 64 consecutive blocks (8 KB) through LDS: each
+// instruction moves 1 KB contiguous (8 blocks); the LDS image of region k is
+// [row ^ ((k>>1)&1)][block&7] in 16-byte slots so that the per-lane
+// ds_read_b128 of "my block, row r" is bank-conflict free.
+DEV void load_block_staged(const int16_t *__restrict__ wave_src, int lane,
+ uint4 *__restrict__ lds /* 512 slots of this wave */, uint4 (&rows)[8]) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(wave_src);
+  const int j = lane & 7, rr = lane >> 3;
+  uint4 tmp[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int r = rr ^ ((k >> 1) & 1);
+    tmp[k] = p[k*64 + j*8 + r];                 // block 8k+j, row r
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) lds[k*64 + lane] = tmp[k];
+  // the slots are private to this wave: order its own LDS writes before its
+  // own LDS reads (other lanes' data), no workgroup barrier needed
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int k = lane >> 3;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    rows[r] = lds[k*64 + ((r ^ ((k >> 1) & 1))*8 + j)];
+  }
+}
+
+// Same LDS image, filled by the LDS-DMA path (global_load_lds_dwordx4): each
+// instruction lands 1 KB at wave-uniform base + lane*16, so the swizzle goes on
+// the per-lane SOURCE address; no VGPR round trip.
+DEV void load_block_dma(const int16_t *__restrict__ wave_src, int lane,
+ uint4 *__restrict__ lds /* 512 slots of this wave */, uint4 (&rows)[8]) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  const uint4 *p = reinterpret_cast<const uint4 *>(wave_src);
+  const int j = lane & 7, rr = lane >> 3;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int r = rr ^ ((k >> 1) & 1);
+    __builtin_amdgcn_global_load_lds((gptr_t *)(p + k*64 + j*8 + r),
+     (lptr_t *)(lds + k*64), 16, 0, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0): DMA landed
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int k = lane >> 3;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    rows[r] = lds[k*64 + ((r ^ ((k >> 1) & 1))*8 + j)];
+  }
+}
+
+template <int LOADMODE>
+DEV void load_block_wave(const int16_t *__restrict__ wave_src, int lane,
+ uint4 *__restrict__ lds, uint4 (&rows)[8]) {
+  if (LOADMODE == 2) load_block_dma(wave_src, lane, lds, rows);
+  else load_block_staged(wave_src, lane, lds, rows);
+}
+
+// ---------------------------------------------------------------------------
+// YUV stage: coefficient planes -> padded u8 planes (JPEG_DECODE_YUV).
+// ---------------------------------------------------------------------------
+template <bool DEQUANT, int LOADMODE>
+__global__ __launch_bounds__(256) void jga_idct_yuv_kernel(const jga_kparams P) {
+  __shared__ uint4 stage[LOADMODE ? 4*512 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int img = blockIdx.y;
+  const int wslot = (blockIdx.x*4 + wave)*64;      // first slot of this wave
+  if (wslot >= P.slots_per_image) return;
+  const bool in_range = wslot + lane < P.slots_per_image;
+  const int s = in_range ? wslot + lane : P.slots_per_image - 1;
+  // slot -> (plane, bx, by): inverse of xjpeg.c:556-561
+  int pl = 0;
+  if (P.nplanes == 3) pl = s >= P.plane_slot0[2] ? 2 : s >= P.plane_slot0[1] ? 1 : 0;
+  const int ls = s - P.plane_slot0[pl];
+  const int row = (int)fastdiv(ls, P.div_w0), col = ls - row*P.w0_blocks;
+  const int xdec = P.plane_xdec[pl];
+  const int hb = P.w0_blocks >> xdec;
+  const int sub = (int)fastdiv(col, P.div_hb[pl]);
+  const int bx = col - sub*hb;
+  const int by = (row << xdec) + sub;
+  const bool valid = in_range && by < P.plane_vblocks[pl];
+
+  const int16_t *cbase = P.coef + (long long)img*P.coef_stride;
+  uint4 rows[8];
+  if (LOADMODE != 0 && wslot + 64 <= P.slots_per_image) {
+    load_block_wave<LOADMODE>(cbase + (long long)wslot*64, lane, stage + wave*512,
+     rows);
+  }
+  else load_block_direct(cbase + (long long)s*64, rows);
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(P.qtab)
+   + ((long long)img*3 + pl)*32;
+  uint32_t qv[32];
+  if (DEQUANT) {
+#pragma unroll
+    for (int n = 0; n < 32; n++) qv[n] = q[n];
+  }
+  float t[64];
+  idct_block<DEQUANT>(rows, qv, t);
+  if (!valid) return;
+  uint8_t *dst = P.out + (long long)img*P.out_stride + P.plane_data_off[pl]
+   + ((long long)by*8*P.plane_hblocks[pl] + bx)*8;
+  const long long pitch = (long long)P.plane_hblocks[pl]*8;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint2 v;
+    v.x = pack_u8x4(t[k*8 + 0] + 128.0f, t[k*8 + 1] + 128.0f,
+     t[k*8 + 2] + 128.0f, t[k*8 + 3] + 128.0f);
+    v.y = pack_u8x4(t[k*8 + 4] + 128.0f, t[k*8 + 5] + 128.0f,
+     t[k*8 + 6] + 128.0f, t[k*8 + 7] + 128.0f);
+    *reinterpret_cast<uint2 *>(dst + k*pitch) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// RGB stage: coefficient planes -> interleaved RGB8 (JPEG_DECODE_RGB).
+// Tile = 64 MCUs of one MCU row.  Waves [0, NLW) are luma, NLW = Cb, NLW+1 = Cr.
+// ---------------------------------------------------------------------------
+template <int XDEC, int YDEC>
+struct rgb_cfg {
+  static constexpr int LW = 1 << XDEC, LH = 1 << YDEC;
+  static constexpr int NLW = LW*LH;           // luma waves per tile
+  static constexpr int THREADS = (NLW + 2)*64;
+  static constexpr int CW = 8 >> XDEC, CH = 8 >> YDEC;   // chroma patch per luma block
+  // LDS (uint4 slots): coefficient staging (8 KB per wave) and, after a
+  // barrier, the chroma hand-off [comp][row][chroma block][8 floats] = 32 KB
+  static constexpr int CHROMA_SLOTS = 2*8*64*2;
+};
+
+template <int XDEC, int YDEC, bool DEQUANT, int LOADMODE>
+__global__ __launch_bounds__((rgb_cfg<XDEC, YDEC>::THREADS))
+void jga_idct_rgb_kernel(const jga_kparams P) {
+  typedef rgb_cfg<XDEC, YDEC> cfg;
+  constexpr int STAGE_SLOTS = LOADMODE ? (cfg::NLW + 2)*512 : 0;
+  __shared__ uint4 lds[STAGE_SLOTS > cfg::CHROMA_SLOTS ? STAGE_SLOTS : cfg::CHROMA_SLOTS];
+  uint4 *stage = lds;
+  float *chroma = reinterpret_cast<float *>(lds);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tx = blockIdx.x, mrow = blockIdx.y, img = blockIdx.z;
+  const int cbx0 = tx*64;                      // first chroma block / MCU of tile
+  const int16_t *cbase = P.coef + (long long)img*P.coef_stride;
+  const long long rs = (long long)P.w0_blocks*64;
+
+  const bool is_luma = wave < cfg::NLW;
+  int pl, bx, by, cb = 0, subx = 0, suby = 0;
+  if (is_luma) {
+    const int lxw = wave & (cfg::LW - 1);
+    suby = wave >> XDEC;
+    const int lx = lxw*64 + lane;
+    pl = 0;
+    bx = cbx0*cfg::LW + lx;
+    by = mrow*cfg::LH + suby;
+    cb = lx >> XDEC;
+    subx = lx & (cfg::LW - 1);
+  }
+  else {
+    pl = 1 + (wave - cfg::NLW);
+    bx = cbx0 + lane;
+    by = mrow;
+  }
+  const int hblocks = P.plane_hblocks[pl];
+  const bool valid = bx < hblocks;
+  const int cbxl = valid ? bx : hblocks - 1;   // clamp: tail lanes reload a real block
+  const int xdec = is_luma ? 0 : XDEC;
+  const long long boff = P.plane_coef_off[pl] + rs*(by >> xdec)
+   + (rs >> xdec)*(by & ((1 << xdec) - 1));
+
+  uint4 rows[8];
+  // staged (coalesced) load needs the wave's 64 blocks to exist contiguously
+  const int wbx0 = is_luma ? cbx0*cfg::LW + (wave & (cfg::LW - 1))*64 : cbx0;
+  if (LOADMODE != 0 && wbx0 + 64 <= hblocks) {
+    load_block_wave<LOADMODE>(cbase + boff + (long long)wbx0*64, lane,
+     stage + wave*512, rows);
+  }
+  else load_block_direct(cbase + boff + (long long)cbxl*64, rows);
+
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(P.qtab)
+   + ((long long)img*3 + pl)*32;
+  uint32_t qv[32];
+  if (DEQUANT) {
+#pragma unroll
+    for (int n = 0; n < 32; n++) qv[n] = q[n];
+  }
+  float t[64];
+  idct_block<DEQUANT>(rows, qv, t);
+
+  // the hand-off area aliases the staging slots: every wave must have pulled
+  // its coefficients into registers first
+  if (LOADMODE) __syncthreads();
+  if (!is_luma) {
+    // publish (sample-128) clamped to [-128,127] == clamp255(s+128)-128
+    float *dst = chroma + (((wave - cfg::NLW)*8)*64 + lane)*8;
+#pragma unroll
+    for (int n = 0; n < 64; n += 4) {
+      v4f v;
+      v.x = __builtin_amdgcn_fmed3f(t[n + 0], -128.0f, 127.0f);
+      v.y = __builtin_amdgcn_fmed3f(t[n + 1], -128.0f, 127.0f);
+      v.z = __builtin_amdgcn_fmed3f(t[n + 2], -128.0f, 127.0f);
+      v.w = __builtin_amdgcn_fmed3f(t[n + 3], -128.0f, 127.0f);
+      *reinterpret_cast<v4f *>(dst + (n >> 3)*512 + (n & 4)) = v;
+    }
+  }
+  __syncthreads();
+  if (!is_luma || !valid) return;
+
+  // chroma patch of this luma block: rows suby*CH.., cols subx*CW..
+  float u[cfg::CH*cfg::CW], v[cfg::CH*cfg::CW];
+  {
+    const float *ub = chroma + ((suby*cfg::CH)*64 + cb)*8 + subx*cfg::CW;
+    const float *vb = ub + 8*64*8;
+#pragma unroll
+    for (int r = 0; r < cfg::CH; r++) {
+#pragma unroll
+      for (int c = 0; c < cfg::CW; c++) {
+        u[r*cfg::CW + c] = ub[r*512 + c];
+        v[r*cfg::CW + c] = vb[r*512 + c];
+      }
+    }
+  }
+  const int x0 = bx*8, y0 = by*8;
+  const long long pitch = (long long)P.width*3;
+  uint8_t *obase = P.out + (long long)img*P.out_stride + (long long)y0*pitch
+   + (long long)x0*3;
+  const bool fast = P.out_aligned && x0 + 8 <= P.width;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    float rgb[24];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float Y = __builtin_amdgcn_fmed3f(t[k*8 + i], -128.0f, 127.0f) + 128.0f;
+      const float uu = u[(k >> YDEC)*cfg::CW + (i >> XDEC)];
+      const float vv = v[(k >> YDEC)*cfg::CW + (i >> XDEC)];
+      // unyuv.fs.glsl:12-16,48 in mat3*vec3 column order
+      rgb[3*i + 0] = unorm8(Y + 1.402f*vv);
+      rgb[3*i + 1] = unorm8((Y + (-0.34414f)*uu) + (-0.71414f)*vv);
+      rgb[3*i + 2] = unorm8(Y + 1.772f*uu);
+    }
+    if (y0 + k >= P.height) continue;
+    uint8_t *o = obase + k*pitch;
+    if (fast) {
+      uint4 a;
+      uint2 b;
+      a.x = pack_u8x4(rgb[0], rgb[1], rgb[2], rgb[3]);
+      a.y = pack_u8x4(rgb[4], rgb[5], rgb[6], rgb[7]);
+      a.z = pack_u8x4(rgb[8], rgb[9], rgb[10], rgb[11]);
+      a.w = pack_u8x4(rgb[12], rgb[13], rgb[14], rgb[15]);
+      b.x = pack_u8x4(rgb[16], rgb[17], rgb[18], rgb[19]);
+      b.y = pack_u8x4(rgb[20], rgb[21], rgb[22], rgb[23]);
+      *reinterpret_cast<uint4 *>(o) = a;
+      *reinterpret_cast<uint2 *>(o + 16) = b;
+    }
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (x0 + i < P.width) {
+          o[3*i + 0] = (uint8_t)(pack_u8x4(rgb[3*i + 0], 0, 0, 0) & 255u);
+          o[3*i + 1] = (uint8_t)(pack_u8x4(rgb[3*i + 1], 0, 0, 0) & 255u);
+          o[3*i + 2] = (uint8_t)(pack_u8x4(rgb[3*i + 2], 0, 0, 0) & 255u);
+        }
+      }
+    }
+  }
+}
+
+// Grey: one plane, img->pixels is 1 B/px at the true size (ungrey.fs.glsl:18;
+// pixel layout src/jpeg_wrap.c:215-219).  Flat over the luma raster.
+template <bool DEQUANT, int LOADMODE>
+__global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P) {
+  __shared__ uint4 stage[LOADMODE ? 4*512 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int img = blockIdx.y;
+  const int wslot = (blockIdx.x*4 + wave)*64;
+  if (wslot >= P.slots_per_image) return;
+  const bool in_range = wslot + lane < P.slots_per_image;
+  const int s = in_range ? wslot + lane : P.slots_per_image - 1;
+  const int by = (int)fastdiv(s, P.div_w0), bx = s - by*P.w0_blocks;
+  const int16_t *cbase = P.coef + (long long)img*P.coef_stride;
+  uint4 rows[8];
+  if (LOADMODE != 0 && wslot + 64 <= P.slots_per_image) {
+    load_block_wave<LOADMODE>(cbase + (long long)wslot*64, lane, stage + wave*512,
+     rows);
+  }
+  else load_block_direct(cbase + (long long)s*64, rows);
+  const uint32_t *q = reinterpret_cast<const uint32_t *>(P.qtab) + (long long)img*3*32;
+  uint32_t qv[32];
+  if (DEQUANT) {
+#pragma unroll
+    for (int n = 0; n < 32; n++) qv[n] = q[n];
+  }
+  float t[64];
+  idct_block<DEQUANT>(rows, qv, t);
+  if (!in_range) return;
+  const int x0 = bx*8, y0 = by*8;
+  uint8_t *obase = P.out + (long long)img*P.out_stride + (long long)y0*P.width + x0;
+  const bool fast = P.out_aligned && x0 + 8 <= P.width;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (y0 + k >= P.height) continue;
+    uint8_t *o = obase + (long long)k*P.width;
+    uint2 v;
+    v.x = pack_u8x4(t[k*8 + 0] + 128.0f, t[k*8 + 1] + 128.0f,
+     t[k*8 + 2] + 128.0f, t[k*8 + 3] + 128.0f);
+    v.y = pack_u8x4(t[k*8 + 4] + 128.0f, t[k*8 + 5] + 128.0f,
+     t[k*8 + 6] + 128.0f, t[k*8 + 7] + 128.0f);
+    if (fast) *reinterpret_cast<uint2 *>(o) = v;
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (x0 + i < P.width) o[i] = (uint8_t)(((i < 4 ? v.x : v.y) >> (8*(i & 3))) & 255u);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Host-side launch table (C++ linkage inside the library; the C-ABI wrappers
+// live in device_api.cpp).
+// ---------------------------------------------------------------------------
+template <int XDEC, int YDEC>
+static hipError_t launch_rgb_t(const jga_kparams &P, int loadmode,
+ hipStream_t st) {
+  typedef rgb_cfg<XDEC, YDEC> cfg;
+  dim3 grid(P.tiles_per_row, P.nvmb, P.nimages), block(cfg::THREADS);
+#define JGA_RGB_LAUNCH(DQ, LM) hipLaunchKernelGGL((jga_idct_rgb_kernel<XDEC, YDEC, DQ, LM>), grid, block, 0, st, P)
+  if (P.dequant) {
+    if (loadmode == 2) JGA_RGB_LAUNCH(true, 2);
+    else if (loadmode == 1) JGA_RGB_LAUNCH(true, 1);
+    else JGA_RGB_LAUNCH(true, 0);
+  }
+  else {
+    if (loadmode == 2) JGA_RGB_LAUNCH(false, 2);
+    else if (loadmode == 1) JGA_RGB_LAUNCH(false, 1);
+    else JGA_RGB_LAUNCH(false, 0);
+  }
+#undef JGA_RGB_LAUNCH
+  return hipGetLastError();
+}
+
+extern "C" int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec,
+ int loadmode, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipErrorInvalidValue;
+  if (P->nplanes == 1) {
+    dim3 grid((P->slots_per_image + 255)/256, P->nimages), block(256);
+#define JGA_GREY_LAUNCH(DQ, LM) hipLaunchKernelGGL((jga_idct_grey_kernel<DQ, LM>), grid, block, 0, st, *P)
+    if (P->dequant) {
+      if (loadmode == 2) JGA_GREY_LAUNCH(true, 2);
+      else if (loadmode == 1) JGA_GREY_LAUNCH(true, 1);
+      else JGA_GREY_LAUNCH(true, 0);
+    }
+    else {
+      if (loadmode == 2) JGA_GREY_LAUNCH(false, 2);
+      else if (loadmode == 1) JGA_GREY_LAUNCH(false, 1);
+      else JGA_GREY_LAUNCH(false, 0);
+    }
+#undef JGA_GREY_LAUNCH
+    e = hipGetLastError();
+  }
+  else {
+    if (xdec == 0 && ydec == 0) e = launch_rgb_t<0, 0>(*P, loadmode, st);
+    else if (xdec == 1 && ydec == 0) e = launch_rgb_t<1, 0>(*P, loadmode, st);
+    else if (xdec == 1 && ydec == 1) e = launch_rgb_t<1, 1>(*P, loadmode, st);
+    else if (xdec == 0 && ydec == 1) e = launch_rgb_t<0, 1>(*P, loadmode, st);
+    else if (xdec == 2 && ydec == 0) e = launch_rgb_t<2, 0>(*P, loadmode, st);
+  }
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int jga_launch_yuv(const jga_kparams *P, int loadmode, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((P->slots_per_image + 255)/256, P->nimages), block(256);
+#define JGA_YUV_LAUNCH(DQ, LM) hipLaunchKernelGGL((jga_idct_yuv_kernel<DQ, LM>), grid, block, 0, st, *P)
+  if (P->dequant) {
+    if (loadmode == 2) JGA_YUV_LAUNCH(true, 2);
+    else if (loadmode == 1) JGA_YUV_LAUNCH(true, 1);
+    else JGA_YUV_LAUNCH(true, 0);
+  }
+  else {
+    if (loadmode == 2) JGA_YUV_LAUNCH(false, 2);
+    else if (loadmode == 1) JGA_YUV_LAUNCH(false, 1);
+    else JGA_YUV_LAUNCH(false, 0);
+  }
+#undef JGA_YUV_LAUNCH
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -1,0 +1,25 @@
+/* jga_internal.h — declarations shared by the host-side C/C++ sources. */
+#ifndef JGA_INTERNAL_H
+#define JGA_INTERNAL_H (1)
+
+#include "../../include/jpeg_gpu_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JGA_EXPORT __attribute__((visibility("default")))
+
+/* Record an error (thread-local), print it to stderr unless JGA_QUIET is set,
+ * return EXIT_FAILURE. */
+int jga_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int jga_ilog(unsigned v);
+int jga_subsamp_of(int xdec, int ydec, int ncomps);
+
+/* Entropy decode with an explicit stage (entropy.c). */
+enum { JGA_STAGE_PACK = 0, JGA_STAGE_QUANT = 1, JGA_STAGE_DCT = 2 };
+
+#ifdef __cplusplus
+}
+#endif
+#endif

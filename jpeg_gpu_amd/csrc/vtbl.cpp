@@ -1,0 +1,217 @@
+// vtbl.cpp — HIPJPEG_DECODE_CTX_VTBL: the decoder plugin that drops in where
+// the reference's XJPEG_DECODE_CTX_VTBL sits (src/jpeg_wrap.c:246-358).
+//
+//   decode_alloc  <-> xjpeg_decode_alloc    jpeg_wrap.c:254-261
+//   decode_header <-> xjpeg_decode_header_  jpeg_wrap.c:263-319
+//   decode_image  <-> xjpeg_decode_image_   jpeg_wrap.c:321-342
+//   decode_reset  <-> xjpeg_decode_reset    jpeg_wrap.c:344-346
+//   decode_free   <-> xjpeg_decode_free     jpeg_wrap.c:348-350
+//
+// Same call order, ownership (caller owns jpeg_info.buf and the image) and
+// error convention (EXIT_FAILURE + one line on stderr).  Differences, all
+// additive: the YUV and RGB stages are computed on the GPU (the reference
+// computes YUV on the CPU and rejects RGB, jpeg_wrap.c:335-339), and malformed
+// input is rejected instead of read out of bounds.  There is NO CPU fallback
+// for the GPU stages: without a HIP device they fail loudly.
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "jga_internal.h"
+
+namespace {
+
+const char *const OUT_NAMES[JPEG_DECODE_OUT_MAX] =
+ {"pack", "quant", "dct", "yuv", "rgb"};
+
+struct hipjpeg_ctx {
+  const unsigned char *buf;
+  int size;
+  int have_header;
+  jpeg_header header;
+  jga_geom geom;
+  // device side, created on the first GPU-stage decode and reused per frame
+  hipStream_t stream;
+  short *h_coef;              // pinned
+  unsigned char *h_out;       // pinned
+  short *d_coef;
+  unsigned short *d_qtab;
+  unsigned char *d_out;
+  long long cap_coef, cap_out;
+};
+
+void release_device(hipjpeg_ctx *c) {
+  if (c->h_coef) (void)hipHostFree(c->h_coef);
+  if (c->h_out) (void)hipHostFree(c->h_out);
+  if (c->d_coef) (void)hipFree(c->d_coef);
+  if (c->d_qtab) (void)hipFree(c->d_qtab);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  c->h_coef = NULL; c->h_out = NULL; c->d_coef = NULL; c->d_qtab = NULL;
+  c->d_out = NULL; c->stream = NULL; c->cap_coef = c->cap_out = 0;
+}
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return jga_fail("hipjpeg: HIP error %d (%s) at %s", (int)e_, \
+  hipGetErrorString(e_), #call); } while (0)
+
+int ensure_device(hipjpeg_ctx *c, long long coef_shorts, long long out_bytes) {
+  if (!c->stream) HIP_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (!c->d_qtab) HIP_OK(hipMalloc((void **)&c->d_qtab, 3*64*sizeof(unsigned short)));
+  if (coef_shorts > c->cap_coef) {
+    if (c->h_coef) (void)hipHostFree(c->h_coef);
+    if (c->d_coef) (void)hipFree(c->d_coef);
+    c->h_coef = NULL; c->d_coef = NULL; c->cap_coef = 0;
+    HIP_OK(hipHostMalloc((void **)&c->h_coef, coef_shorts*sizeof(short), hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&c->d_coef, coef_shorts*sizeof(short)));
+    c->cap_coef = coef_shorts;
+  }
+  if (out_bytes > c->cap_out) {
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->d_out) (void)hipFree(c->d_out);
+    c->h_out = NULL; c->d_out = NULL; c->cap_out = 0;
+    HIP_OK(hipHostMalloc((void **)&c->h_out, out_bytes, hipHostMallocDefault));
+    HIP_OK(hipMalloc((void **)&c->d_out, out_bytes));
+    c->cap_out = out_bytes;
+  }
+  return EXIT_SUCCESS;
+}
+
+jpeg_decode_ctx *hipjpeg_alloc(jpeg_info *info) {
+  hipjpeg_ctx *c = (hipjpeg_ctx *)calloc(1, sizeof(hipjpeg_ctx));
+  if (c != NULL) {
+    c->buf = info->buf;
+    c->size = info->size;
+  }
+  return (jpeg_decode_ctx *)c;
+}
+
+int hipjpeg_header(jpeg_decode_ctx *dec, jpeg_header *headers) {
+  hipjpeg_ctx *c = (hipjpeg_ctx *)dec;
+  int i;
+  if (jga_parse_header(c->buf, c->size, &c->header) != EXIT_SUCCESS) {
+    return EXIT_FAILURE;
+  }
+  if (jga_geom_from_header(&c->geom, &c->header) != EXIT_SUCCESS) {
+    return EXIT_FAILURE;
+  }
+  c->have_header = 1;
+  *headers = c->header;
+  for (i = 0; i < headers->ncomps; i++) {
+    // comp[i].quant points INTO its own header (jpeg_wrap.c:313)
+    headers->comp[i].quant =
+     &headers->quant[c->header.comp[i].quant - c->header.quant];
+  }
+  return EXIT_SUCCESS;
+}
+
+int check_image(const hipjpeg_ctx *c, const image *img) {
+  int i;
+  if (img->nplanes != c->geom.nplanes || img->width != c->geom.width
+   || img->height != c->geom.height) {
+    return jga_fail("hipjpeg: image does not match the JPEG headers");
+  }
+  for (i = 0; i < img->nplanes; i++) {
+    if (img->plane[i].width != c->geom.plane[i].hblocks*8
+     || img->plane[i].height != c->geom.plane[i].vblocks*8
+     || img->plane[i].ystride != img->plane[i].width
+     || img->plane[i].xstride != 1) {
+      return jga_fail("hipjpeg: image plane %d does not match the JPEG headers", i);
+    }
+  }
+  return EXIT_SUCCESS;
+}
+
+int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
+  hipjpeg_ctx *c = (hipjpeg_ctx *)dec;
+  const jga_geom *g = &c->geom;
+  unsigned short qtab[3*64];
+  int i;
+  if (!c->have_header) {
+    // the reference's header pass parks on SOS (xjpeg.c:716-719): same rule
+    return jga_fail("hipjpeg: decode_header must precede decode_image");
+  }
+  if (check_image(c, img) != EXIT_SUCCESS) return EXIT_FAILURE;
+  switch (out) {
+    case JPEG_DECODE_PACK : {
+      long long words = 0, per_plane[3] = {0, 0, 0};
+      if (jga_entropy_decode_pack(c->buf, c->size, g, img->coef,
+       g->coef_shorts, img->index, &words, per_plane) != EXIT_SUCCESS) {
+        return EXIT_FAILURE;
+      }
+      for (i = 0; i < img->nplanes; i++) img->plane[i].packed = (int)per_plane[i];
+      img->packed = (int)words;
+      return EXIT_SUCCESS;
+    }
+    case JPEG_DECODE_QUANT :
+    case JPEG_DECODE_DCT : {
+      return jga_entropy_decode(c->buf, c->size, g, img->coef,
+       out == JPEG_DECODE_DCT);
+    }
+    case JPEG_DECODE_YUV :
+    case JPEG_DECODE_RGB : break;
+    default : {
+      return jga_fail("Unsupported output '%s' for hipjpeg wrapper.",
+       (unsigned)out < JPEG_DECODE_OUT_MAX ? OUT_NAMES[out] : "?");
+    }
+  }
+  // GPU stages: host entropy decode -> pinned -> H2D -> fused kernel -> D2H
+  {
+    const int rgb = out == JPEG_DECODE_RGB;
+    const long long out_bytes = rgb ? g->rgb_bytes : g->yuv_bytes;
+    if (ensure_device(c, g->coef_shorts, (out_bytes + 15) & ~15ll) != EXIT_SUCCESS) {
+      return EXIT_FAILURE;
+    }
+    if (jga_entropy_decode(c->buf, c->size, g, c->h_coef, 0) != EXIT_SUCCESS) {
+      return EXIT_FAILURE;
+    }
+    memset(qtab, 0, sizeof(qtab));
+    for (i = 0; i < g->nplanes; i++) {
+      memcpy(qtab + 64*i, c->header.comp[i].quant->tbl, 64*sizeof(unsigned short));
+    }
+    HIP_OK(hipMemcpyAsync(c->d_qtab, qtab, sizeof(qtab), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpyAsync(c->d_coef, c->h_coef, g->coef_shorts*sizeof(short),
+     hipMemcpyHostToDevice, c->stream));
+    if ((rgb ? jga_idct_rgb_batch(g, 1, c->d_coef, g->coef_shorts, c->d_qtab, 1,
+     c->d_out, c->cap_out, c->stream)
+     : jga_idct_yuv_batch(g, 1, c->d_coef, g->coef_shorts, c->d_qtab, 1,
+     c->d_out, c->cap_out, c->stream)) != EXIT_SUCCESS) {
+      return EXIT_FAILURE;
+    }
+    HIP_OK(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    if (rgb) memcpy(img->pixels, c->h_out, out_bytes);
+    else {
+      for (i = 0; i < img->nplanes; i++) {
+        memcpy(img->plane[i].data, c->h_out + g->plane[i].data_off,
+         (size_t)img->plane[i].ystride*img->plane[i].height);
+      }
+    }
+  }
+  return EXIT_SUCCESS;
+}
+
+void hipjpeg_reset(jpeg_decode_ctx *dec, jpeg_info *info) {
+  hipjpeg_ctx *c = (hipjpeg_ctx *)dec;
+  c->buf = info->buf;
+  c->size = info->size;
+  c->have_header = 0;
+}
+
+void hipjpeg_free(jpeg_decode_ctx *dec) {
+  hipjpeg_ctx *c = (hipjpeg_ctx *)dec;
+  if (c) {
+    release_device(c);
+    free(c);
+  }
+}
+
+}  // namespace
+
+extern "C" JGA_EXPORT const jpeg_decode_ctx_vtbl HIPJPEG_DECODE_CTX_VTBL = {
+  hipjpeg_alloc,
+  hipjpeg_header,
+  hipjpeg_image,
+  hipjpeg_reset,
+  hipjpeg_free
+};

@@ -1,0 +1,342 @@
+"""ctypes binding of libjpeg_gpu_amd.so — every call goes through the C-ABI."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpeg_gpu_amd.so")
+
+# Symbols include/jpeg_gpu_amd.h declares (checked by tests/test_abi.py).
+EXPORTED = [
+    "HIPJPEG_DECODE_CTX_VTBL", "jga_version", "jga_last_error", "jga_image_init",
+    "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",
+    "jga_parse_header", "jga_entropy_decode", "jga_entropy_decode_pack",
+    "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_kernel_name",
+    "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
+    "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
+    "jga_stream_sync", "jga_set_device", "jga_stream_create", "jga_stream_destroy",
+    "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
+    "jga_pipeline_destroy",
+]
+
+
+class JgaError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: the HIP extension has not been built "
+            "(run `python -m jpeg_gpu_amd.build`). There is no CPU fallback." % LIB_PATH)
+    # If torch is (going to be) in this process its bundled HIP runtime must be
+    # the one we bind to; it shares our DT_NEEDED soname (libamdhip64.so.7).
+    if "torch" in sys.modules:
+        pass
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+L = _load()
+os.environ.setdefault("JGA_QUIET", "1")   # errors are raised, not printed
+
+_vp, _i, _ll = C.c_void_p, C.c_int, C.c_longlong
+_G = C.POINTER(abi.jga_geom)
+L.jga_version.restype = C.c_char_p
+L.jga_last_error.restype = C.c_char_p
+L.jga_kernel_name.restype = C.c_char_p
+L.jga_kernel_name.argtypes = [_G, _i]
+L.jga_image_init.argtypes = [C.POINTER(abi.image), C.POINTER(abi.jpeg_header)]
+L.jga_image_zero.argtypes = [C.POINTER(abi.image)]
+L.jga_image_zero.restype = None
+L.jga_image_clear.argtypes = [C.POINTER(abi.image)]
+L.jga_image_clear.restype = None
+L.jga_geom_from_header.argtypes = [_G, C.POINTER(abi.jpeg_header)]
+L.jga_block_offset.argtypes = [_G, _i, _i, _i]
+L.jga_block_offset.restype = _ll
+L.jga_parse_header.argtypes = [C.c_char_p, _i, C.POINTER(abi.jpeg_header)]
+L.jga_entropy_decode.argtypes = [C.c_char_p, _i, _G, _vp, _i]
+L.jga_entropy_decode_pack.argtypes = [C.c_char_p, _i, _G, _vp, _ll, _vp,
+                                      C.POINTER(_ll), C.POINTER(_ll)]
+L.jga_idct_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+L.jga_idct_yuv_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+L.jga_time_idct_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _i, _i, _vp,
+                                  C.POINTER(C.c_float)]
+L.jga_device_malloc.argtypes = [C.c_size_t]
+L.jga_device_malloc.restype = _vp
+L.jga_device_free.argtypes = [_vp]
+L.jga_device_free.restype = None
+L.jga_host_malloc_pinned.argtypes = [C.c_size_t]
+L.jga_host_malloc_pinned.restype = _vp
+L.jga_host_free_pinned.argtypes = [_vp]
+L.jga_host_free_pinned.restype = None
+L.jga_memcpy_h2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
+L.jga_memcpy_d2h.argtypes = [_vp, _vp, C.c_size_t, _vp]
+L.jga_device_memset.argtypes = [_vp, _i, C.c_size_t, _vp]
+L.jga_stream_sync.argtypes = [_vp]
+L.jga_set_device.argtypes = [_i]
+L.jga_stream_create.restype = _vp
+L.jga_stream_destroy.argtypes = [_vp]
+L.jga_stream_destroy.restype = None
+L.jga_pipeline_create.argtypes = [C.POINTER(abi.jga_pipeline_config)]
+L.jga_pipeline_create.restype = _vp
+L.jga_pipeline_run.argtypes = [_vp, C.POINTER(abi.jga_job), _i]
+L.jga_pipeline_destroy.argtypes = [_vp]
+L.jga_pipeline_destroy.restype = None
+
+VTBL = abi.jpeg_decode_ctx_vtbl.in_dll(L, "HIPJPEG_DECODE_CTX_VTBL")
+
+
+def check(rc):
+    if rc != 0:
+        raise JgaError((L.jga_last_error() or b"?").decode())
+
+
+def version():
+    return L.jga_version().decode()
+
+
+def device_count():
+    return L.jga_device_count()
+
+
+# ---- host stage ---------------------------------------------------------------
+
+def parse_header(data):
+    h = abi.jpeg_header()
+    check(L.jga_parse_header(bytes(data), len(data), C.byref(h)))
+    return h
+
+
+def geom_from_header(h):
+    g = abi.jga_geom()
+    check(L.jga_geom_from_header(C.byref(g), C.byref(h)))
+    return g
+
+
+def geom_of(data):
+    h = parse_header(data)
+    return h, geom_from_header(h)
+
+
+def qtab_of(h):
+    """(3,64) uint16: quantisation table of each PLANE, natural order."""
+    q = np.zeros((3, 64), np.uint16)
+    for p in range(h.ncomps):
+        q[p] = np.ctypeslib.as_array(h.comp[p].quant.contents.tbl)
+    return q
+
+
+def entropy_decode(data, g=None, dequant=False, out=None):
+    if g is None:
+        _, g = geom_of(data)
+    if out is None:
+        out = np.zeros(g.coef_shorts, np.int16)
+    check(L.jga_entropy_decode(bytes(data), len(data), C.byref(g), out.ctypes.data,
+                               int(dequant)))
+    return out
+
+
+def entropy_decode_pack(data, g=None):
+    if g is None:
+        _, g = geom_of(data)
+    pack = np.zeros(g.coef_shorts, np.int16)
+    nblk = sum((g.plane[i].hblocks << g.plane[i].xdec) * g.plane[i].cstride
+               for i in range(g.nplanes))
+    index = np.zeros(nblk, np.int32)
+    n = C.c_longlong()
+    per = (C.c_longlong * 3)()
+    check(L.jga_entropy_decode_pack(bytes(data), len(data), C.byref(g), pack.ctypes.data,
+                                    pack.size, index.ctypes.data, C.byref(n), per))
+    return pack[:n.value].copy(), index, list(per)
+
+
+# ---- device stage ---------------------------------------------------------------
+
+class DeviceBuffer:
+    """hipMalloc'd bytes owned through the C-ABI helpers."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = L.jga_device_malloc(self.nbytes)
+        if not self.ptr:
+            raise JgaError((L.jga_last_error() or b"hipMalloc failed").decode())
+
+    def upload(self, arr, offset=0, stream=None):
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes
+        check(L.jga_memcpy_h2d(self.ptr + offset, arr.ctypes.data, arr.nbytes, stream))
+        check(L.jga_stream_sync(stream))
+
+    def download(self, nbytes=None, offset=0, dtype=np.uint8, stream=None):
+        nbytes = self.nbytes - offset if nbytes is None else int(nbytes)
+        out = np.empty(nbytes, np.uint8)
+        check(L.jga_memcpy_d2h(out.ctypes.data, self.ptr + offset, nbytes, stream))
+        check(L.jga_stream_sync(stream))
+        return out.view(dtype)
+
+    def fill(self, value, stream=None):
+        check(L.jga_device_memset(self.ptr, value, self.nbytes, stream))
+        check(L.jga_stream_sync(stream))
+
+    def free(self):
+        if self.ptr:
+            L.jga_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _align(n, a=256):
+    return (int(n) + a - 1) // a * a
+
+
+def idct_batch(g, coefs, qtabs, rgb=True, dequant=True):
+    """Run the device stage on host arrays (upload -> kernel -> download).
+
+    coefs: (n, coef_shorts) int16; qtabs: (n, 3, 64) uint16.
+    Returns (n, rgb_bytes) or (n, yuv_bytes) uint8.
+    """
+    coefs = np.ascontiguousarray(coefs, np.int16).reshape(-1, g.coef_shorts)
+    n = coefs.shape[0]
+    qtabs = np.ascontiguousarray(qtabs, np.uint16).reshape(n, 3, 64)
+    out_bytes = g.rgb_bytes if rgb else g.yuv_bytes
+    cstride = _align(g.coef_shorts * 2) // 2
+    ostride = _align(out_bytes)
+    d_coef = DeviceBuffer(cstride * 2 * n)
+    d_q = DeviceBuffer(qtabs.nbytes)
+    d_out = DeviceBuffer(ostride * n)
+    try:
+        d_out.fill(0xA5)
+        for i in range(n):
+            d_coef.upload(coefs[i], offset=i * cstride * 2)
+        d_q.upload(qtabs)
+        fn = L.jga_idct_rgb_batch if rgb else L.jga_idct_yuv_batch
+        check(fn(C.byref(g), n, d_coef.ptr, cstride, d_q.ptr, int(dequant), d_out.ptr,
+                 ostride, None))
+        check(L.jga_stream_sync(None))
+        raw = d_out.download().reshape(n, ostride)
+        return raw[:, :out_bytes].copy()
+    finally:
+        d_coef.free()
+        d_q.free()
+        d_out.free()
+
+
+def split_planes(g, yuv):
+    """Views of the padded planes inside one concatenated YUV buffer."""
+    out = []
+    for p in range(g.nplanes):
+        pl = g.plane[p]
+        n = pl.hblocks * pl.vblocks * 64
+        out.append(yuv[pl.data_off:pl.data_off + n].reshape(pl.vblocks * 8, pl.hblocks * 8))
+    return out
+
+
+# ---- plugin (vtable) ------------------------------------------------------------
+
+class Decoder:
+    """Drives HIPJPEG_DECODE_CTX_VTBL exactly as the reference's main() drives a
+    decoder (src/jpeg_gpu.c:612-613, 637, 701-704, 1215, 1231-1237)."""
+
+    def __init__(self, data):
+        self._data = np.frombuffer(bytes(data), np.uint8).copy()
+        self._info = abi.jpeg_info(len(self._data), self._data.ctypes.data)
+        self.ctx = VTBL.decode_alloc(C.byref(self._info))
+        if not self.ctx:
+            raise MemoryError("decode_alloc failed")
+        self.header = abi.jpeg_header()
+        self.img = None
+
+    def read_header(self):
+        check(VTBL.decode_header(self.ctx, C.byref(self.header)))
+        return self.header
+
+    def init_image(self):
+        self.img = abi.image()
+        check(L.jga_image_init(C.byref(self.img), C.byref(self.header)))
+        L.jga_image_zero(C.byref(self.img))
+        return self.img
+
+    def decode(self, out):
+        check(VTBL.decode_image(self.ctx, C.byref(self.img), out))
+
+    def reset(self, data=None):
+        if data is not None:
+            self._data = np.frombuffer(bytes(data), np.uint8).copy()
+            self._info = abi.jpeg_info(len(self._data), self._data.ctypes.data)
+        VTBL.decode_reset(self.ctx, C.byref(self._info))
+
+    # views into the image buffers
+    def planes(self):
+        out = []
+        for i in range(self.img.nplanes):
+            p = self.img.plane[i]
+            a = np.ctypeslib.as_array(C.cast(p.data, C.POINTER(C.c_ubyte)),
+                                      (p.height, p.width))
+            out.append(a.copy())
+        return out
+
+    def pixels(self):
+        n = self.img.nplanes
+        shape = (self.img.height, self.img.width, 3) if n == 3 else \
+            (self.img.height, self.img.width)
+        a = np.ctypeslib.as_array(C.cast(self.img.pixels, C.POINTER(C.c_ubyte)), shape)
+        return a.copy()
+
+    def coef(self):
+        g = geom_from_header(self.header)
+        a = np.ctypeslib.as_array(C.cast(self.img.coef, C.POINTER(C.c_short)),
+                                  (g.coef_shorts,))
+        return a.copy()
+
+    def close(self):
+        if self.img is not None:
+            L.jga_image_clear(C.byref(self.img))
+            self.img = None
+        if self.ctx:
+            VTBL.decode_free(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+# ---- pipeline -------------------------------------------------------------------
+
+class Pipeline:
+    def __init__(self, device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
+                 max_coef_shorts=0, max_out_bytes=0):
+        cfg = abi.jga_pipeline_config(device, nthreads, 0, out, int(copy_back),
+                                      max_coef_shorts, max_out_bytes)
+        self.ptr = L.jga_pipeline_create(C.byref(cfg))
+        if not self.ptr:
+            raise JgaError((L.jga_last_error() or b"pipeline_create failed").decode())
+        self.copy_back = copy_back
+
+    def run(self, jpegs, host_outs=None, dev_outs=None):
+        n = len(jpegs)
+        keep = [np.frombuffer(bytes(j), np.uint8) for j in jpegs]
+        jobs = (abi.jga_job * n)()
+        for i in range(n):
+            jobs[i].jpeg = keep[i].ctypes.data
+            jobs[i].size = keep[i].size
+            jobs[i].host_out = host_outs[i].ctypes.data if host_outs is not None else None
+            jobs[i].dev_out = dev_outs[i] if dev_outs is not None else None
+        rc = L.jga_pipeline_run(self.ptr, jobs, n)
+        return rc, jobs
+
+    def close(self):
+        if self.ptr:
+            L.jga_pipeline_destroy(self.ptr)
+            self.ptr = None

@@ -1,0 +1,101 @@
+"""Synthetic baseline-JPEG inputs (ctypes binding of libjga_synth.so).
+
+The reference ships no fixtures; tests and bench.py make their
+inputs with csrc/synth_encode.c.  Input generator only: not on the decode path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libjga_synth.so")
+if not os.path.exists(_PATH):
+    raise ImportError("%s missing: run `python -m jpeg_gpu_amd.build`" % _PATH)
+S = C.CDLL(_PATH)
+
+DQT16, NO_JFIF, SPLIT_DHT = 1, 2, 4
+# luma sampling factors (hs, vs) by name
+SAMPLING = {"444": (1, 1), "422": (2, 1), "420": (2, 2), "440": (1, 2), "411": (4, 1),
+            "grey": (1, 1)}
+
+S.jgs_encode_synthetic.restype = C.c_long
+S.jgs_encode_synthetic.argtypes = [C.c_int] * 7 + [C.c_uint, C.c_int, C.c_void_p, C.c_long]
+S.jgs_encode_pixels.restype = C.c_long
+S.jgs_encode_pixels.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.c_void_p, C.c_long]
+S.jgs_encode_levels.restype = C.c_long
+S.jgs_encode_levels.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_int,
+                                                               C.c_void_p, C.c_long]
+S.jgs_coef_shorts.restype = C.c_longlong
+S.jgs_coef_shorts.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]
+S.jgs_quality_tables.argtypes = [C.c_int, C.c_void_p]
+S.jgs_synthetic_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint]
+
+
+def _samp(sampling, ncomps):
+    if ncomps == 1:
+        return 1, 1
+    return SAMPLING[sampling] if isinstance(sampling, str) else tuple(sampling)
+
+
+def synthetic_jpeg(width, height, sampling="420", quality=90, restart_interval=0, seed=1234,
+                   flags=0):
+    """SURVEY.md §8(d) recipe.  restart_interval: MCUs, 0 = none, -1 = one MCU row."""
+    ncomps = 1 if sampling == "grey" else 3
+    hs, vs = _samp(sampling, ncomps)
+    buf = np.empty(width * height * ncomps + (1 << 16), np.uint8)
+    n = S.jgs_encode_synthetic(width, height, ncomps, hs, vs, quality, restart_interval,
+                               seed, flags, buf.ctypes.data, buf.size)
+    if n <= 0:
+        raise ValueError("jgs_encode_synthetic failed: %d" % n)
+    return buf[:n].tobytes()
+
+
+def synthetic_pixels(width, height, ncomps=3, seed=1234):
+    px = np.empty((height, width, ncomps) if ncomps == 3 else (height, width), np.uint8)
+    S.jgs_synthetic_pixels(px.ctypes.data, width, height, ncomps, seed)
+    return px
+
+
+def encode_pixels(pixels, sampling="420", quality=90, restart_interval=0, flags=0):
+    pixels = np.ascontiguousarray(pixels, np.uint8)
+    ncomps = 3 if pixels.ndim == 3 else 1
+    h, w = pixels.shape[:2]
+    hs, vs = _samp(sampling, ncomps)
+    buf = np.empty(w * h * ncomps * 2 + (1 << 16), np.uint8)
+    n = S.jgs_encode_pixels(pixels.ctypes.data, w, h, ncomps, hs, vs, quality,
+                            restart_interval, flags, buf.ctypes.data, buf.size)
+    if n <= 0:
+        raise ValueError("jgs_encode_pixels failed: %d" % n)
+    return buf[:n].tobytes()
+
+
+def coef_shorts(width, height, sampling="420"):
+    ncomps = 1 if sampling == "grey" else 3
+    hs, vs = _samp(sampling, ncomps)
+    return int(S.jgs_coef_shorts(width, height, ncomps, hs, vs, None, None, None))
+
+
+def quality_tables(quality):
+    q = np.zeros((3, 64), np.uint16)
+    S.jgs_quality_tables(quality, q.ctypes.data)
+    return q
+
+
+def encode_levels(levels, width, height, sampling="420", qtab=None, restart_interval=0,
+                  flags=0):
+    """Entropy-code quantised levels given in the packed coefficient layout."""
+    ncomps = 1 if sampling == "grey" else 3
+    hs, vs = _samp(sampling, ncomps)
+    levels = np.ascontiguousarray(levels, np.int16)
+    assert levels.size == coef_shorts(width, height, sampling)
+    if qtab is None:
+        qtab = quality_tables(90)
+    qtab = np.ascontiguousarray(qtab, np.uint16).reshape(3, 64)
+    buf = np.empty(levels.size * 4 + (1 << 16), np.uint8)
+    n = S.jgs_encode_levels(levels.ctypes.data, width, height, ncomps, hs, vs,
+                            qtab.ctypes.data, restart_interval, flags, buf.ctypes.data,
+                            buf.size)
+    if n <= 0:
+        raise ValueError("jgs_encode_levels failed: %d" % n)
+    return buf[:n].tobytes()

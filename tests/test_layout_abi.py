@@ -1,0 +1,121 @@
+"""Layout + C-ABI surface: image_init semantics (reference test/image.c:21-55 and
+SURVEY.md Appendix B), struct sizes, exported symbols."""
+import ctypes as C
+import re
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def make_header(abi, width, height, samp):
+    h = abi.jpeg_header()
+    h.bits, h.width, h.height, h.ncomps = 8, width, height, len(samp)
+    hmax = max(s[0] for s in samp)
+    vmax = max(s[1] for s in samp)
+    nhmb = (width + 8 * hmax - 1) // (8 * hmax)
+    nvmb = (height + 8 * vmax - 1) // (8 * vmax)
+    for i, (hs, vs) in enumerate(samp):
+        h.comp[i].hsamp, h.comp[i].vsamp = hs, vs
+        h.comp[i].hblocks, h.comp[i].vblocks = nhmb * hs, nvmb * vs
+    return h
+
+
+def test_image_init_8bit_420(lib):
+    """The reference's own layout test, check for check (test/image.c:21-55)."""
+    from jpeg_gpu_amd import abi
+    h = make_header(abi, 32, 24, [(2, 2), (1, 1), (1, 1)])
+    img = abi.image()
+    assert lib.L.jga_image_init(C.byref(img), C.byref(h)) == 0
+    p = img.plane
+    assert (p[0].xdec, p[0].ydec, p[0].xstride, p[0].ystride) == (0, 0, 1, 32)
+    assert (p[1].xdec, p[1].ydec, p[1].xstride, p[1].ystride) == (1, 1, 1, 16)
+    assert (p[2].xdec, p[2].ydec, p[2].xstride, p[2].ystride) == (1, 1, 1, 16)
+    lib.L.jga_image_clear(C.byref(img))
+    assert img.nplanes == 0 and not img.pixels
+
+
+def test_layout_matches_reference_image_init(lib, golden_layout):
+    """cstride / coef offsets / sizes for the BASELINE geometries (Appendix B),
+    golden values captured from the compiled reference image_init."""
+    from jpeg_gpu_amd import abi
+    for name, want in golden_layout.items():
+        samp = [tuple(s) for s in want["samp"]]
+        h = make_header(abi, want["width"], want["height"], samp)
+        g = lib.geom_from_header(h)
+        n = want["ncomps"]
+        assert g.coef_shorts == want["coef_shorts"], name
+        assert [g.plane[i].coef_off for i in range(n)] == want["coef_off"], name
+        assert [g.plane[i].cstride for i in range(n)] == want["cstride"], name
+        assert [g.plane[i].xdec for i in range(n)] == want["xdec"], name
+        assert [g.plane[i].ydec for i in range(n)] == want["ydec"], name
+        assert (g.nhmb, g.nvmb) == (want["nhmb"], want["nvmb"]), name
+        img = abi.image()
+        assert lib.L.jga_image_init(C.byref(img), C.byref(h)) == 0
+        for i in range(n):
+            assert img.plane[i].cstride == want["cstride"][i]
+            assert (img.plane[i].coef - img.coef) // 2 == want["coef_off"][i]
+            assert img.plane[i].data % 16 == 0
+        assert img.coef % 16 == 0 and img.pixels % 16 == 0 and img.index % 16 == 0
+        lib.L.jga_image_clear(C.byref(img))
+
+
+def test_appendix_b_sizes(lib):
+    from jpeg_gpu_amd import abi
+    cases = {(512, 512, ((1, 1),)): 524288, (1920, 1080, ((2, 2), (1, 1), (1, 1))): 6266880,
+             (3840, 2160, ((1, 1),) * 3): 49766400,
+             (3840, 2160, ((2, 2), (1, 1), (1, 1))): 24944640,
+             (7680, 4320, ((2, 2), (1, 1), (1, 1))): 99532800}
+    for (w, h, samp), nbytes in cases.items():
+        g = lib.geom_from_header(make_header(abi, w, h, list(samp)))
+        assert g.coef_shorts * 2 == nbytes
+        assert g.rgb_bytes == w * h * len(samp)
+
+
+def test_block_offset_formula(lib):
+    from jpeg_gpu_amd import abi
+    g = lib.geom_from_header(make_header(abi, 100, 75, [(2, 2), (1, 1), (1, 1)]))
+    rs = g.w0 * 8
+    assert lib.L.jga_block_offset(C.byref(g), 0, 3, 2) == rs * 2 + 3 * 64
+    assert lib.L.jga_block_offset(C.byref(g), 1, 2, 3) == g.plane[1].coef_off + rs * 1 + rs // 2 + 128
+
+
+def test_unsupported_headers_fail(lib):
+    from jpeg_gpu_amd import abi
+    h = make_header(abi, 16, 16, [(1, 1), (2, 2), (1, 1)])   # chroma wider than luma
+    with pytest.raises(lib.JgaError):
+        lib.geom_from_header(h)
+    h = make_header(abi, 16, 16, [(1, 1)])
+    h.ncomps = 2
+    with pytest.raises(lib.JgaError):
+        lib.geom_from_header(h)
+
+
+def test_exports_every_declared_symbol(lib):
+    """Every function/variable include/jpeg_gpu_amd.h declares is exported."""
+    hdr = open(os.path.join(ROOT, "include", "jpeg_gpu_amd.h")).read()
+    declared = set(re.findall(r"\b(jga_[a-z0-9_]+)\s*\(", hdr))
+    declared |= {"HIPJPEG_DECODE_CTX_VTBL"}
+    declared -= {"jga_plane_geom", "jga_geom", "jga_pipeline_config", "jga_job"}
+    assert declared == set(lib.EXPORTED)
+    for name in sorted(declared):
+        assert hasattr(lib.L, name), name
+    v = lib.VTBL
+    assert all(bool(f) for f in (v.decode_alloc, v.decode_header, v.decode_image,
+                                 v.decode_reset, v.decode_free))
+    assert lib.version().startswith("jpeg_gpu_amd")
+
+
+def test_product_never_touches_oracle():
+    """The product must not import/link/execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "jpeg_gpu_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".cpp", ".h", ".hip")):
+                text = open(os.path.join(base, f)).read()
+                code = "\n".join(l for l in text.splitlines()
+                                 if not l.strip().startswith(("#", "//", "*", "/*")))
+                assert "import oracle" not in code and "liboracle" not in code \
+                    and "libjpeggpu_ref" not in code, f
