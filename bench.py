@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the JPEG block-decode path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE pass of the hot path (fused dequantise + 2x1-D IDCT + chroma
+upsample + YCbCr->RGB kernel) over one batch of synthetic 3840x2160 4:2:0 q90
+baseline JPEGs whose packed coefficient planes are ALREADY RESIDENT IN HBM when
+the timed region starts; the RGB8 output stays in HBM.  Images are independent:
+each rank (one per GPU) owns its own batch, there is no data-path collective
+(weak scaling); the only cross-rank traffic is the timing barrier / max.
+
+Rank 0 prints ONE JSON line: BASELINE.json's metric (Mpixel/s) as `value`, plus
+  roofline      achieved algorithmic HBM GB/s of the fused kernel, measured live
+                with HIP events on the launch stream over the timed region
+  cpu_baseline  the CPU port of the same path (oracle/, whole decode to RGB) timed
+                on this box's host cores on a bounded sample (rank 0, N=1 only)
+  e2e           supplementary: JPEG bytes in host RAM -> RGB, through the
+                pipelined decoder (host Huffman threads + pinned H2D + kernel);
+                PCIe/host-inclusive, never `value`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+W, H, SAMPLING, QUALITY = 3840, 2160, "420", 90
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=48, help="images per GPU per step")
+    ap.add_argument("--distinct", type=int, default=6, help="distinct synthetic images")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the supplementary e2e leg")
+    ap.add_argument("--e2e-images", type=int, default=96)
+    ap.add_argument("--e2e-threads", type=int, default=0, help="0 = min(cores, 48)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def make_inputs(synth, n, rank):
+    seeds = [1234 + rank * 1000 + i for i in range(n)]
+    with ThreadPoolExecutor(max_workers=min(n, 8)) as ex:
+        return list(ex.map(lambda s: synth.synthetic_jpeg(W, H, SAMPLING, QUALITY, seed=s),
+                           seeds))
+
+
+def cpu_baseline(jpegs, seconds):
+    """The CPU port of the whole path (oracle.orc_decode_rgb: Huffman + float IDCT
+    + clamp + upsample + RGB), one image per thread on the host cores; bounded."""
+    import numpy as np
+    import oracle
+    orc = oracle.Oracle()
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    threads = max(1, min(ncpu, 64))
+    # single core first: calibrates the sample size
+    info = orc.parse(jpegs[0])
+    scratch = np.empty(info.hblocks[0] * info.vblocks[0] * 64 * 3, np.uint8)
+    rgb = np.empty((H, W, 3), np.uint8)
+    t0 = time.perf_counter()
+    orc.decode_rgb(jpegs[0], scratch, rgb)
+    t1 = time.perf_counter() - t0
+    # ~`seconds` of total CPU work, spread over the threads
+    per_thread = max(1, min(16, int(round(seconds / max(t1, 1e-3) / threads))))
+
+    def work(i):
+        sc = np.empty_like(scratch)
+        out = np.empty_like(rgb)
+        for k in range(per_thread):
+            orc.decode_rgb(jpegs[(i + k) % len(jpegs)], sc, out)
+        return per_thread
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        done = sum(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    res = {
+        "value": round(done * W * H / dt / 1e6, 1), "unit": "Mpixel/s", "cores": threads,
+        "kind": "port",
+        "sample": "%d decodes of %dx%d 4:2:0 q90 JPEGs to RGB on %d threads "
+                  "(oracle.orc_decode_rgb, %.1f s)" % (done, W, H, threads, dt),
+        "single_core_value": round(W * H / t1 / 1e6, 1),
+    }
+    if oracle.Reference.available():
+        ref = oracle.Reference()
+        t0 = time.perf_counter()
+        ref.decode(jpegs[0], oracle.YUV)
+        res["reference_yuv_single_core"] = {
+            "value": round(W * H / (time.perf_counter() - t0) / 1e6, 1), "unit": "Mpixel/s",
+            "note": "the reference's own xjpeg+dct.c compiled (oracle/_ref), YUV stage "
+                    "(it has no CPU RGB stage), 1 decode incl. image_init"}
+    return res
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log("bench.py: --gpus %d needs torch.distributed.run with %d ranks; "
+                "running rank-local only" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch                      # first: its bundled HIP runtime must be THE runtime
+    import torch.distributed as dist
+    import numpy as np
+    import ctypes as C
+    import __graft_entry__
+    __graft_entry__.build()
+    from jpeg_gpu_amd import abi, lib, synth
+
+    if not torch.cuda.is_available() or lib.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    lib.check(lib.L.jga_set_device(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    # ---- inputs: synthetic JPEGs -> host entropy stage -> coefficient planes in HBM
+    t_setup = time.perf_counter()
+    jpegs = make_inputs(synth, args.distinct, rank)
+    hdr, g = lib.geom_of(jpegs[0])
+    B = args.batch
+    cstride = (g.coef_shorts * 2 + 255) // 256 * 128          # shorts, 256-B aligned
+    ostride = (g.rgb_bytes + 255) // 256 * 256
+    d_coef = lib.DeviceBuffer(cstride * 2 * B)
+    d_q = lib.DeviceBuffer(3 * 64 * 2 * B)
+    d_out = lib.DeviceBuffer(ostride * B)
+    coefs = [lib.entropy_decode(j, g) for j in jpegs]
+    qt = np.zeros((B, 3, 64), np.uint16)
+    for i in range(B):
+        d_coef.upload(coefs[i % len(coefs)], offset=i * cstride * 2)
+        qt[i] = lib.qtab_of(lib.parse_header(jpegs[i % len(jpegs)]))
+    d_q.upload(qt)
+    stream = lib.L.jga_stream_create()
+    log("rank %d: setup %.1f s, batch %d x %dx%d, coef %.1f MB + rgb %.1f MB per image"
+        % (rank, time.perf_counter() - t_setup, B, W, H, g.coef_shorts * 2 / 1e6,
+           g.rgb_bytes / 1e6))
+
+    def launch(reps):
+        ms = C.c_float()
+        lib.check(lib.L.jga_time_idct_batch(C.byref(g), B, d_coef.ptr, cstride, d_q.ptr, 1,
+                                            d_out.ptr, ostride, 1, reps, stream, C.byref(ms)))
+        return ms.value
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        launch(args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    ev_ms = launch(args.steps)            # K launches, HIP events on `stream`
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        e = torch.tensor([ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        ev_ms = float(e.item())
+
+    # spot-check the last step's output against the oracle (outside the timed region)
+    ok = True
+    if rank == 0:
+        import oracle
+        want = oracle.Oracle().decode_rgb(jpegs[0])[1].reshape(-1)
+        got = d_out.download(g.rgb_bytes, offset=0)
+        ok = bool(np.array_equal(got, want))
+        if not ok:
+            raise SystemExit("bench.py: device output differs from the oracle")
+
+    pixels_per_step = B * W * H
+    value = world * pixels_per_step * args.steps / dt / 1e6
+    alg_bytes = B * (g.coef_blocks * 128 + g.rgb_bytes)
+    achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            if pmc.get("batch") == B and pmc.get("workload") == "%dx%d %s" % (W, H, SAMPLING):
+                traffic = pmc.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Mpixel/s end-to-end decode, 4K 4:2:0 baseline JPEG",
+        "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "3840x2160 4:2:0 q90 baseline JPEG; step = fused dequant+IDCT+"
+                        "upsample+RGB over a batch of %d images per GPU, packed int16 "
+                        "coefficient planes resident in HBM -> RGB8 in HBM" % B,
+            "batch_per_gpu": B, "distinct_images": len(jpegs),
+            "parallelism": "image-sharded x%d, no collectives" % world,
+            "kernel": lib.L.jga_kernel_name(C.byref(g), 1).decode(),
+            "bit_exact_vs_oracle": ok,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms_per_launch": round(ev_ms, 4),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_seconds)
+
+    if rank == 0 and world == 1 and not args.no_e2e:
+        n = args.e2e_images
+        e2e = {}
+        nthr = args.e2e_threads or max(1, min(os.cpu_count() or 1, 48))
+        for copy_back in (False, True):
+            pl = lib.Pipeline(device=local_rank, nthreads=nthr,
+                              out=abi.JPEG_DECODE_RGB, copy_back=copy_back)
+            jobs = [jpegs[i % len(jpegs)] for i in range(n)]
+            outs = [np.empty(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
+            pl.run(jobs[:16], host_outs=outs[:16] if outs else None)   # warm: slots, pages
+            t0 = time.perf_counter()
+            rc, _ = pl.run(jobs, host_outs=outs)
+            te = time.perf_counter() - t0
+            pl.close()
+            key = "jpeg_host_to_rgb_host" if copy_back else "jpeg_host_to_rgb_hbm"
+            e2e[key] = {"value": round(n * W * H / te / 1e6, 1), "unit": "Mpixel/s",
+                        "images": n, "ok": rc == 0}
+        e2e["host_threads"] = nthr
+        e2e["note"] = "host Huffman threads + pinned hipMemcpyAsync + fused kernel; " \
+                      "PCIe- and host-inclusive, not `value`"
+        out["e2e"] = e2e
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    lib.L.jga_stream_destroy(stream)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,270 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle
+on the same seeded inputs — bit-exact (integer/byte outputs)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SAMPLINGS = ["grey", "444", "422", "420", "440", "411"]
+
+
+def oracle_outputs(orc, info, quant):
+    planes = orc.coef_to_planes(info, quant, True)
+    return planes, orc.planes_to_rgb(info, planes)
+
+
+def run_device(gpu, g, quant, qtab, rgb, dequant=True):
+    out = gpu.idct_batch(g, quant[None], qtab[None], rgb=rgb, dequant=dequant)[0]
+    return out
+
+
+def check_image(gpu, orc, data, dequant=True):
+    import oracle
+    h, g = gpu.geom_of(data)
+    info = orc.parse(data)
+    quant = gpu.entropy_decode(data, g, dequant=not dequant)
+    q = gpu.qtab_of(h)
+    want_planes, want_rgb = oracle_outputs(orc, info, orc.decode(data, oracle.QUANT)[1])
+    yuv = run_device(gpu, g, quant, q, rgb=False, dequant=dequant)
+    for p, (a, b) in enumerate(zip(gpu.split_planes(g, yuv), want_planes)):
+        assert np.array_equal(a, b), "plane %d: %d samples differ" % (p, (a != b).sum())
+    rgb = run_device(gpu, g, quant, q, rgb=True, dequant=dequant)
+    assert np.array_equal(rgb, want_rgb.reshape(-1)), \
+        "rgb: %d bytes differ" % (rgb != want_rgb.reshape(-1)).sum()
+
+
+@pytest.mark.parametrize("sampling", SAMPLINGS)
+@pytest.mark.parametrize("size", [(8, 8), (17, 9), (100, 75), (640, 360), (1031, 517)])
+def test_kernel_matches_oracle(gpu, orc, synth, sampling, size):
+    """Every sampling x aligned/odd/sub-MCU sizes (tile tails, edge crops,
+    unaligned row pitch -> byte-store path)."""
+    data = synth.synthetic_jpeg(size[0], size[1], sampling, quality=90, seed=size[0])
+    check_image(gpu, orc, data)
+
+
+@pytest.mark.parametrize("sampling", ["420", "444", "grey"])
+def test_dct_stage_input(gpu, orc, synth, sampling):
+    """dequant_on_device=0: coefficients already multiplied on the host (DCT stage)."""
+    data = synth.synthetic_jpeg(200, 120, sampling, quality=75, seed=2)
+    check_image(gpu, orc, data, dequant=False)
+
+
+def test_golden_jpegs(gpu, golden_jpegs):
+    """Committed vectors from the compiled reference: Y/Cb/Cr planes bit-exact."""
+    for name in golden_jpegs.names:
+        data = golden_jpegs.jpeg(name)
+        h, g = gpu.geom_of(data)
+        quant = golden_jpegs[name + ".quant"]
+        yuv = run_device(gpu, g, quant, gpu.qtab_of(h), rgb=False)
+        for a, b in zip(gpu.split_planes(g, yuv), golden_jpegs.planes(name)):
+            assert np.array_equal(a, b), name
+
+
+def test_golden_blocks_through_kernel(gpu, golden_blocks, synth):
+    """4096+ reference in/out blocks pushed through the kernel as a grey image
+    with unit quantisers: plane = clamp255(idct + 128) (xjpeg.c:578)."""
+    from jpeg_gpu_amd import abi
+    from test_layout_abi import make_header
+    inp, out = golden_blocks
+    n = len(inp)
+    wb = 64
+    hb = (n + wb - 1) // wb
+    g = gpu.geom_from_header(make_header(abi, wb * 8, hb * 8, [(1, 1)]))
+    coef = np.zeros(g.coef_shorts, np.int16)
+    coef[:n * 64] = inp.reshape(-1)
+    q = np.ones((3, 64), np.uint16)
+    yuv = run_device(gpu, g, coef, q, rgb=False)
+    plane = gpu.split_planes(g, yuv)[0]
+    got = plane.reshape(hb, 8, wb, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:n]
+    want = np.clip(out.astype(np.int32) + 128, 0, 255).astype(np.uint8)
+    assert np.array_equal(got, want), "%d blocks differ" % (got != want).any(1).sum()
+
+
+def test_extreme_coefficients(gpu, orc, synth):
+    """Full int16 coefficient range with 16-bit quantisers: dequant wraps mod 2^16
+    (xjpeg.c:501-503) and the (short) cast after floor wraps (dct.c:118)."""
+    import oracle
+    from jpeg_gpu_amd import abi
+    from test_layout_abi import make_header
+    rng = np.random.default_rng(5)
+    for samp, name in (([(2, 2), (1, 1), (1, 1)], "420"), ([(1, 1)], "grey")):
+        h = make_header(abi, 256, 64, samp)
+        g = gpu.geom_from_header(h)
+        coef = rng.integers(-32768, 32768, g.coef_shorts).astype(np.int16)
+        coef.reshape(-1, 64)[::3, 1:] = 0            # some DC-only giants
+        q = rng.integers(1, 65536, (3, 64)).astype(np.uint16)
+        q[:, ::2] = rng.integers(1, 4, (3, 32))
+        info = orc.parse(synth.synthetic_jpeg(256, 64, name))
+        for p in range(info.ncomps):
+            for k in range(64):
+                info.quant[p][k] = int(q[p, k])
+        want_planes, want_rgb = oracle_outputs(orc, info, coef)
+        yuv = run_device(gpu, g, coef, q, rgb=False)
+        for a, b in zip(gpu.split_planes(g, yuv), want_planes):
+            assert np.array_equal(a, b)
+        rgb = run_device(gpu, g, coef, q, rgb=True)
+        assert np.array_equal(rgb, want_rgb.reshape(-1))
+
+
+def test_ieee1180_on_device(gpu):
+    """The reference's own IDCT accuracy test (test/dct.c:229-261) on the kernel:
+    run via unit quantisers, recover idct = plane - 128 where unclamped."""
+    from jpeg_gpu_amd import abi
+    from test_layout_abi import make_header
+    from test_oracle_pins import ieee1180_check, assert_ieee1180
+
+    def dev_idct(blocks):
+        n = len(blocks)
+        wb = 50
+        hb = (n + wb - 1) // wb
+        g = gpu.geom_from_header(make_header(abi, wb * 8, hb * 8, [(1, 1)]))
+        coef = np.zeros(g.coef_shorts, np.int16)
+        # bias DC by -? no: compare in the [-128,127] window, the spec range is
+        # [-256,255]; run twice with the level shift moved by +-128 via DC offset
+        # is not exact, so instead check only samples that are unclamped.
+        coef[:n * 64] = blocks.reshape(-1)
+        plane = gpu.split_planes(g, run_device(gpu, g, coef, np.ones((3, 64), np.uint16),
+                                               rgb=False))[0]
+        got = plane.reshape(hb, 8, wb, 8).transpose(0, 2, 1, 3).reshape(-1, 64)[:n]
+        return got.astype(np.int32) - 128
+
+    stats = ieee1180_check_clamped(dev_idct)
+    assert_ieee1180(stats)
+
+
+def ieee1180_check_clamped(idct_fn, n=1000):
+    """IEEE-1180 statistics restricted to the [-128,127] output window the u8 plane
+    can represent (both sides clamped identically)."""
+    from test_oracle_pins import ieee1180_blocks, dct_matrix
+    m = dct_matrix()
+    stats = []
+    for lo, hi in ((-256, 255), (-5, 5), (-300, 300)):
+        for sign in (1, -1):
+            px = ieee1180_blocks(n, lo, hi, sign).astype(np.float64)
+            coef = np.clip(np.rint(np.einsum("ij,njk,lk->nil", m, px, m)), -2048, 2047)
+            ref = np.clip(np.rint(np.einsum("ji,njk,kl->nil", m, coef, m)), -128, 127)
+            got = idct_fn(coef.astype(np.int16).reshape(-1, 64)).reshape(-1, 8, 8)
+            err = got - ref
+            stats.append(dict(peak=np.abs(err).max(), pmse=(err ** 2).mean(0).max(),
+                              omse=(err ** 2).mean(), pme=np.abs(err.mean(0)).max(),
+                              ome=abs(err.mean())))
+    return stats
+
+
+def test_batch_of_images(gpu, orc, synth):
+    """Batched launch: n images of one geometry, distinct content and tables."""
+    import oracle
+    datas = [synth.synthetic_jpeg(328, 200, "420", quality=60 + 5 * i, seed=i) for i in range(5)]
+    h0, g = gpu.geom_of(datas[0])
+    coefs = np.stack([gpu.entropy_decode(d, g) for d in datas])
+    qt = np.stack([gpu.qtab_of(gpu.parse_header(d)) for d in datas])
+    rgb = gpu.idct_batch(g, coefs, qt, rgb=True)
+    yuv = gpu.idct_batch(g, coefs, qt, rgb=False)
+    for i, d in enumerate(datas):
+        info, planes = orc.decode(d, oracle.YUV)
+        assert np.array_equal(rgb[i], orc.planes_to_rgb(info, planes).reshape(-1)), i
+        for a, b in zip(gpu.split_planes(g, yuv[i]), planes):
+            assert np.array_equal(a, b), i
+
+
+def test_full_size_configs_match_oracle(gpu, orc, synth):
+    """BASELINE configs at full size: 1080p 4:2:0 and 4K 4:4:4 against the oracle."""
+    for w, h, s in ((1920, 1080, "420"), (3840, 2160, "444")):
+        check_image(gpu, orc, synth.synthetic_jpeg(w, h, s, quality=90, seed=1234))
+
+
+def test_4k_420_properties(gpu, orc, synth):
+    """Headline config, size-independent properties: (i) the RGB image equals the
+    RGB stage applied to the device's own planes, (ii) decoding is idempotent /
+    deterministic across launches, (iii) a checksum of per-tile checksums matches
+    the oracle's."""
+    import oracle
+    data = synth.synthetic_jpeg(3840, 2160, "420", quality=90, seed=1234)
+    h, g = gpu.geom_of(data)
+    quant = gpu.entropy_decode(data, g)
+    q = gpu.qtab_of(h)
+    rgb1 = run_device(gpu, g, quant, q, rgb=True)
+    rgb2 = run_device(gpu, g, quant, q, rgb=True)
+    assert np.array_equal(rgb1, rgb2)
+    yuv = run_device(gpu, g, quant, q, rgb=False)
+    info = orc.parse(data)
+    assert np.array_equal(orc.planes_to_rgb(info, gpu.split_planes(g, yuv)).reshape(-1), rgb1)
+    want = orc.decode_rgb(data)[1].reshape(-1)
+    tiles_g = rgb1.reshape(-1, 4096).astype(np.uint64).sum(1)
+    tiles_w = want.reshape(-1, 4096).astype(np.uint64).sum(1)
+    assert np.array_equal(tiles_g, tiles_w)
+    assert np.array_equal(rgb1, want)
+
+
+def test_linearity_in_dc(gpu):
+    """Domain property: adding 8*k to every DC (unit quantisers) adds k to every
+    unclamped output sample (dct.c scaling S[0]*S[0] = 1/8 exactly in float32)."""
+    from jpeg_gpu_amd import abi
+    from test_layout_abi import make_header
+    g = gpu.geom_from_header(make_header(abi, 512, 8, [(1, 1)]))
+    rng = np.random.default_rng(9)
+    base = np.zeros(g.coef_shorts, np.int16)
+    base.reshape(-1, 64)[:, 0] = rng.integers(-50, 50, 64) * 8
+    q = np.ones((3, 64), np.uint16)
+    a = run_device(gpu, g, base, q, rgb=False).astype(np.int32)
+    shifted = base.copy()
+    shifted.reshape(-1, 64)[:, 0] += 8 * 5
+    b = run_device(gpu, g, shifted, q, rgb=False).astype(np.int32)
+    assert np.array_equal(b, a + 5)
+
+
+def test_plugin_gpu_stages(gpu, orc, synth):
+    """HIPJPEG vtable YUV + RGB through the reference's call order, with reset
+    between frames and a different file of the same geometry on the same ctx."""
+    import oracle
+    from jpeg_gpu_amd import abi
+    d1 = synth.synthetic_jpeg(322, 241, "420", seed=1)
+    d2 = synth.synthetic_jpeg(322, 241, "420", seed=2, quality=70)
+    with gpu.Decoder(d1) as d:
+        d.read_header()
+        d.init_image()
+        for data in (d1, d2, d1):
+            d.reset(data)
+            d.read_header()
+            d.decode(abi.JPEG_DECODE_YUV)
+            info, planes = orc.decode(data, oracle.YUV)
+            for a, b in zip(d.planes(), planes):
+                assert np.array_equal(a, b)
+            d.reset()
+            d.read_header()
+            d.decode(abi.JPEG_DECODE_RGB)
+            assert np.array_equal(d.pixels(), orc.planes_to_rgb(info, planes))
+    g = synth.synthetic_jpeg(77, 33, "grey")
+    with gpu.Decoder(g) as d:
+        d.read_header()
+        d.init_image()
+        d.decode(abi.JPEG_DECODE_RGB)
+        info, planes = orc.decode(g, oracle.YUV)
+        assert np.array_equal(d.pixels(), planes[0][:33, :77])
+
+
+def test_pipeline(gpu, orc, synth):
+    """Pipelined batch decoder: mixed geometries, copy-back to host, results equal
+    the oracle's whole-path decode."""
+    from jpeg_gpu_amd import abi
+    specs = [(320, 200, "420"), (128, 64, "444"), (200, 100, "422"), (64, 64, "grey"),
+             (320, 200, "420"), (97, 55, "420")] * 3
+    datas = [synth.synthetic_jpeg(w, h, s, seed=i, restart_interval=(i % 3) * 4)
+             for i, (w, h, s) in enumerate(specs)]
+    outs = [np.zeros(w * h * (1 if s == "grey" else 3), np.uint8) for (w, h, s) in specs]
+    pl = gpu.Pipeline(device=0, nthreads=3, out=abi.JPEG_DECODE_RGB, copy_back=True)
+    try:
+        rc, jobs = pl.run(datas, host_outs=outs)
+        assert rc == 0
+        for i, d in enumerate(datas):
+            assert jobs[i].status == 0
+            assert np.array_equal(outs[i], orc.decode_rgb(d)[1].reshape(-1)), i
+        # a corrupt job fails alone
+        bad = list(datas[:4])
+        bad[1] = bad[1][:200]
+        rc, jobs = pl.run(bad, host_outs=outs[:4])
+        assert rc == 1 and [jobs[i].status for i in range(4)] == [0, 1, 0, 0]
+    finally:
+        pl.close()
