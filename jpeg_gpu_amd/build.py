@@ -92,7 +92,7 @@ def build(force=False, verbose=False):
     for s in HIP_SOURCES:
         o = os.path.join(OBJ, s + ".o")
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
-               "-fvisibility=hidden", "-ffp-contract=off", "-Wall",
+               "-fvisibility=hidden", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
                "-c", os.path.join(CSRC, s), "-o", o]
         if s.endswith(".hip"):
             cmd.insert(1, "-save-temps=obj")

@@ -34,9 +34,25 @@
 #include "kernel_params.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
 #define DEV static __device__ __forceinline__
+
+// Output pixels are written once and never re-read by the kernel: nontemporal
+// (streaming) stores keep them from thrashing L2 — on MI355X a read+write stream
+// runs 5.7 TB/s with nt stores vs 3.6-4.8 TB/s with plain ones (tools/membench2,
+// profiles/r1_membench2.txt).  Coefficients are read once: nt loads too.
+DEV void st_nt(uint4 *p, const uint4 v) {
+  __builtin_nontemporal_store(__builtin_bit_cast(v4u, v), reinterpret_cast<v4u *>(p));
+}
+DEV void st_nt(uint2 *p, const uint2 v) {
+  __builtin_nontemporal_store(__builtin_bit_cast(v2u, v), reinterpret_cast<v2u *>(p));
+}
+DEV uint4 ld_nt(const uint4 *p) {
+  return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p)));
+}
 
 // n / d for n < 2^31 with a host-precomputed reciprocal (kernel_params.h):
 // keeps integer division (which hipcc expands through float rcp + fma) out of
@@ -119,16 +135,13 @@ DEV void load_row(const uint4 raw, const uint32_t *__restrict__ q /*4 dwords*/,
   }
 }
 
-// Full 2-D transform of one block held by this lane.  rows[r] = 16 bytes of
-// coefficient row r; q = 32 dwords (64 u16, natural order).  On return
-// t[k*8+i] = floor(idct)(row k, col i) as an integer-valued float, already
-// passed through the (short) wrap of dct.c:118 when it can matter.
+// Scale + row pass (dct.c:105-111) of the block held by this lane.  rows[r] =
+// 16 bytes of coefficient row r; q = 64 u16 natural order as 32 dwords.
+// z[r*8+i] = row-pass output i of row r.
 template <bool DEQUANT>
-DEV void idct_block(const uint4 (&rows)[8], const uint32_t *__restrict__ q,
- float (&t)[64]) {
+DEV void row_pass(const uint4 (&rows)[8], const uint32_t *__restrict__ q,
+ float (&z)[64]) {
   const float sj[8] = {S0, S1, S2, S3, S4, S5, S6, S7};
-  float z[64];
-  // scale + row pass (dct.c:105-111)
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     float y[8];
@@ -137,8 +150,33 @@ DEV void idct_block(const uint4 (&rows)[8], const uint32_t *__restrict__ q,
      z[r*8 + 1], z[r*8 + 2], z[r*8 + 3], z[r*8 + 4], z[r*8 + 5], z[r*8 + 6],
      z[r*8 + 7]);
   }
-  // column pass: vector i = row-pass outputs at column i over rows 0..7,
-  // +0.5 on its first entry (dct.c:112-115)
+}
+
+// Same, with the quantisation rows fetched one at a time from LDS (per-lane
+// table pointer: lanes of one wave may belong to different planes).
+template <bool DEQUANT>
+DEV void row_pass_ldsq(const uint4 (&rows)[8], const uint4 *qp, float (&z)[64]) {
+  const float sj[8] = {S0, S1, S2, S3, S4, S5, S6, S7};
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    float y[8];
+    uint32_t q[4] = {0, 0, 0, 0};
+    if (DEQUANT) {
+      const uint4 q4 = qp[r];
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    }
+    load_row<DEQUANT>(rows[r], q, sj[r], y);
+    idct8(y[0], y[1], y[2], y[3], y[4], y[5], y[6], y[7], z[r*8 + 0],
+     z[r*8 + 1], z[r*8 + 2], z[r*8 + 3], z[r*8 + 4], z[r*8 + 5], z[r*8 + 6],
+     z[r*8 + 7]);
+  }
+}
+
+// Column pass: vector i = row-pass outputs at column i over rows 0..7, +0.5 on
+// its first entry (dct.c:112-115), floor (118).  On return t[k*8+i] =
+// floor(idct)(row k, col i) as an integer-valued float, already passed through
+// the (short) wrap of dct.c:118 when it can matter.
+DEV void col_pass(const float (&z)[64], float (&t)[64]) {
   float m = 0.0f;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -151,14 +189,11 @@ DEV void idct_block(const uint4 (&rows)[8], const uint32_t *__restrict__ q,
       float f = __builtin_floorf(o[k]);          // dct.c:118 floor
       t[k*8 + i] = f;
     }
-    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[0*8 + i]),
-     __builtin_fabsf(t[1*8 + i])));
-    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[2*8 + i]),
-     __builtin_fabsf(t[3*8 + i])));
-    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[4*8 + i]),
-     __builtin_fabsf(t[5*8 + i])));
-    m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(t[6*8 + i]),
-     __builtin_fabsf(t[7*8 + i])));
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t[k*8 + i])),
+       __builtin_fabsf(t[(k + 1)*8 + i]));       // one v_max3_f32 with |abs|
+    }
   }
   // (short) cast of dct.c:118: x86-64 converts through int32 and keeps the
   // low 16 bits.  Only reachable with |coefficients| far outside what a JPEG
@@ -168,6 +203,15 @@ DEV void idct_block(const uint4 (&rows)[8], const uint32_t *__restrict__ q,
     for (int n = 0; n < 64; n++) t[n] = (float)(short)(int)t[n];
   }
 }
+
+template <bool DEQUANT>
+DEV void idct_block(const uint4 (&rows)[8], const uint32_t *__restrict__ q,
+ float (&t)[64]) {
+  float z[64];
+  row_pass<DEQUANT>(rows, q, z);
+  col_pass(z, t);
+}
+
 
 DEV uint32_t pack_u8x4(float a, float b, float c, float d) {
   // v_cvt_pk_u8_f32 converts with saturation to [0,255]; inputs here are
@@ -179,14 +223,82 @@ DEV uint32_t pack_u8x4(float a, float b, float c, float d) {
   return r;
 }
 
-// u8 = (int)(clamp(c,0,255) + 0.5f)   == sat_u8(floor(c+0.5f))
-DEV float unorm8(float c) { return __builtin_floorf(c + 0.5f); }
+// RGB stage arithmetic: with Y the clamped luma sample and
+// u = Cb-128, v = Cr-128,
+//   R = Y + 1.402f*v;  G = (Y + (-0.34414f)*u) + (-0.71414f)*v;  B = Y + 1.772f*u
+//   u8 = (int)(clamp(c,0,255) + 0.5f)                     (round half up)
+// The kernels evaluate three cheaper forms that are PROVEN bit-identical to it
+// over the whole input domain (Y in 0..255, u,v in -128..127: 2x65536 + 16.7M
+// cases, exhaustive check in tests/test_rgb_rounding.py).  With yc = Y-128 (the
+// clamped IDCT output, an integer-valued float):
+//   G = sat(floor((yc + fl(a*u + 128.5)) + b*v))   the +0.5 and the level shift
+//       ride on the per-chroma-sample product; Y+x.5 sums are exact where it matters
+//   R = sat(rne(yc + fl(1.402f*v + (128 + 2^-12))))  v_cvt_pk_u8_f32 rounds to
+//   B = sat(rne(yc + fl(1.772f*u + (128 + 2^-12))))  nearest-even + saturates; it
+//       differs from round-half-up only on exact .5 ties, and the 2^-12 nudge
+//       lifts every tie without carrying any other value across a boundary.
+// Per pixel: 1 med3 + 4 add + 1 floor + 3 cvt_pk (was 15 ops), per chroma sample
+// 4 mul + 3 add.
+#define Y_HALF 128.5f
+#define Y_TIE 128.000244140625f      /* 128 + 2^-12 */
+
+// Chroma products of one chroma row segment (CW samples).
+template <int CW>
+struct chroma_row {
+  float r[CW], g1[CW], g2[CW], b[CW];
+  __device__ __forceinline__ void set(const float *u, const float *v) {
+#pragma unroll
+    for (int c = 0; c < CW; c++) {
+      r[c] = 1.402f*v[c] + Y_TIE;
+      g1[c] = (-0.34414f)*u[c] + Y_HALF;
+      g2[c] = (-0.71414f)*v[c];
+      b[c] = 1.772f*u[c] + Y_TIE;
+    }
+  }
+};
+
+// One output row (8 pixels) of a luma block -> 24 RGB bytes in 6 dwords.
+template <int XDEC, int CW>
+DEV void rgb_row(const float *t8, const chroma_row<CW> &cr, uint4 &a, uint2 &b2) {
+  float rgb[24];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const float yc = __builtin_amdgcn_fmed3f(t8[i], -128.0f, 127.0f);
+    const int c = i >> XDEC;
+    rgb[3*i + 0] = yc + cr.r[c];
+    rgb[3*i + 1] = __builtin_floorf((yc + cr.g1[c]) + cr.g2[c]);
+    rgb[3*i + 2] = yc + cr.b[c];
+  }
+  a.x = pack_u8x4(rgb[0], rgb[1], rgb[2], rgb[3]);
+  a.y = pack_u8x4(rgb[4], rgb[5], rgb[6], rgb[7]);
+  a.z = pack_u8x4(rgb[8], rgb[9], rgb[10], rgb[11]);
+  a.w = pack_u8x4(rgb[12], rgb[13], rgb[14], rgb[15]);
+  b2.x = pack_u8x4(rgb[16], rgb[17], rgb[18], rgb[19]);
+  b2.y = pack_u8x4(rgb[20], rgb[21], rgb[22], rgb[23]);
+}
+
+// Store one RGB row: vector stores when the row is dword-aligned and fully
+// inside the image, byte stores at the right edge / for unaligned pitches.
+DEV void store_rgb_row(uint8_t *o, const uint4 a, const uint2 b2, bool fast,
+ int x0, int width) {
+  if (fast) {
+    st_nt(reinterpret_cast<uint4 *>(o), a);
+    st_nt(reinterpret_cast<uint2 *>(o + 16), b2);
+  }
+  else {
+    const uint32_t w[6] = {a.x, a.y, a.z, a.w, b2.x, b2.y};
+#pragma unroll
+    for (int n = 0; n < 24; n++) {
+      if (x0 + n/3 < width) o[n] = (uint8_t)((w[n >> 2] >> (8*(n & 3))) & 255u);
+    }
+  }
+}
 
 // Fetch the 8 coefficient rows of the block at `src` (128 contiguous bytes).
 DEV void load_block_direct(const int16_t *__restrict__ src, uint4 (&rows)[8]) {
   const uint4 *p = reinterpret_cast<const uint4 *>(src);
 #pragma unroll
-  for (int r = 0; r < 8; r++) rows[r] = p[r];
+  for (int r = 0; r < 8; r++) rows[r] = p[r];   // plain loads: the 8 rows share L1 lines
 }
 
 // Coalesced fetch of a wave's 64 consecutive blocks (8 KB) through LDS: each
@@ -217,44 +329,12 @@ DEV void load_block_staged(const int16_t *__restrict__ wave_src, int lane,
   }
 }
 
-// Same LDS image, filled by the LDS-DMA path (global_load_lds_dwordx4): each
-// instruction lands 1 KB at wave-uniform base + lane*16, so the swizzle goes on
-// the per-lane SOURCE address; no VGPR round trip.
-DEV void load_block_dma(const int16_t *__restrict__ wave_src, int lane,
- uint4 *__restrict__ lds /* 512 slots of this wave */, uint4 (&rows)[8]) {
-  typedef __attribute__((address_space(1))) const void gptr_t;
-  typedef __attribute__((address_space(3))) void lptr_t;
-  const uint4 *p = reinterpret_cast<const uint4 *>(wave_src);
-  const int j = lane & 7, rr = lane >> 3;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int r = rr ^ ((k >> 1) & 1);
-    __builtin_amdgcn_global_load_lds((gptr_t *)(p + k*64 + j*8 + r),
-     (lptr_t *)(lds + k*64), 16, 0, 0);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0): DMA landed
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const int k = lane >> 3;
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    rows[r] = lds[k*64 + ((r ^ ((k >> 1) & 1))*8 + j)];
-  }
-}
-
-template <int LOADMODE>
-DEV void load_block_wave(const int16_t *__restrict__ wave_src, int lane,
- uint4 *__restrict__ lds, uint4 (&rows)[8]) {
-  if (LOADMODE == 2) load_block_dma(wave_src, lane, lds, rows);
-  else load_block_staged(wave_src, lane, lds, rows);
-}
-
 // ---------------------------------------------------------------------------
 // YUV stage: coefficient planes -> padded u8 planes (JPEG_DECODE_YUV).
 // ---------------------------------------------------------------------------
-template <bool DEQUANT, int LOADMODE>
+template <bool DEQUANT, bool STAGED>
 __global__ __launch_bounds__(256) void jga_idct_yuv_kernel(const jga_kparams P) {
-  __shared__ uint4 stage[LOADMODE ? 4*512 : 1];
+  __shared__ uint4 stage[STAGED ? 4*512 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int img = blockIdx.y;
@@ -276,8 +356,8 @@ __global__ __launch_bounds__(256) void jga_idct_yuv_kernel(const jga_kparams P) 
 
   const int16_t *cbase = P.coef + (long long)img*P.coef_stride;
   uint4 rows[8];
-  if (LOADMODE != 0 && wslot + 64 <= P.slots_per_image) {
-    load_block_wave<LOADMODE>(cbase + (long long)wslot*64, lane, stage + wave*512,
+  if (STAGED && wslot + 64 <= P.slots_per_image) {
+    load_block_staged(cbase + (long long)wslot*64, lane, stage + wave*512,
      rows);
   }
   else load_block_direct(cbase + (long long)s*64, rows);
@@ -301,46 +381,52 @@ __global__ __launch_bounds__(256) void jga_idct_yuv_kernel(const jga_kparams P) 
      t[k*8 + 2] + 128.0f, t[k*8 + 3] + 128.0f);
     v.y = pack_u8x4(t[k*8 + 4] + 128.0f, t[k*8 + 5] + 128.0f,
      t[k*8 + 6] + 128.0f, t[k*8 + 7] + 128.0f);
-    *reinterpret_cast<uint2 *>(dst + k*pitch) = v;
+    st_nt(reinterpret_cast<uint2 *>(dst + k*pitch), v);
   }
 }
 
 // ---------------------------------------------------------------------------
 // RGB stage: coefficient planes -> interleaved RGB8 (JPEG_DECODE_RGB).
-// Tile = 64 MCUs of one MCU row.  Waves [0, NLW) are luma, NLW = Cb, NLW+1 = Cr.
+// A workgroup is a tile of TILE MCUs of one MCU row: its LW*LH*TILE luma blocks
+// fill NLW waves (row-major over the tile's luma block rows), its TILE Cb and
+// TILE Cr blocks fill the chroma wave(s).  TILE = 32 gives small 3-wave groups
+// (two luma waves + one wave holding Cb in lanes 0-31 and Cr in lanes 32-63),
+// so many groups interleave on a CU and the one barrier couples few waves;
+// 4:4:4 keeps TILE = 64 (one wave each for Y, Cb, Cr).
 // ---------------------------------------------------------------------------
 template <int XDEC, int YDEC>
 struct rgb_cfg {
   static constexpr int LW = 1 << XDEC, LH = 1 << YDEC;
-  static constexpr int NLW = LW*LH;           // luma waves per tile
-  static constexpr int THREADS = (NLW + 2)*64;
-  static constexpr int CW = 8 >> XDEC, CH = 8 >> YDEC;   // chroma patch per luma block
-  // LDS (uint4 slots): coefficient staging (8 KB per wave) and, after a
-  // barrier, the chroma hand-off [comp][row][chroma block][8 floats] = 32 KB
-  static constexpr int CHROMA_SLOTS = 2*8*64*2;
+  static constexpr int TILE = (LW*LH == 1) ? 64 : 32;     // MCUs per tile
+  static constexpr int ROWLEN = TILE*LW;                   // luma blocks per tile row
+  static constexpr int NLW = LW*LH*TILE/64;                // luma waves
+  static constexpr int NCW = 2*TILE/64;                    // chroma waves
+  static constexpr int THREADS = (NLW + NCW)*64;
+  static constexpr int CW = 8 >> XDEC, CH = 8 >> YDEC;     // chroma patch per luma block
+  // LDS floats: hand-off [comp][row][chroma block][8] + the image's 3 q tables
+  static constexpr int CHROMA_FLOATS = 2*8*TILE*8;
+  static constexpr int LDS_FLOATS = CHROMA_FLOATS + 3*32;
 };
 
-template <int XDEC, int YDEC, bool DEQUANT, int LOADMODE>
+template <int XDEC, int YDEC, bool DEQUANT>
 __global__ __launch_bounds__((rgb_cfg<XDEC, YDEC>::THREADS))
 void jga_idct_rgb_kernel(const jga_kparams P) {
   typedef rgb_cfg<XDEC, YDEC> cfg;
-  constexpr int STAGE_SLOTS = LOADMODE ? (cfg::NLW + 2)*512 : 0;
-  __shared__ uint4 lds[STAGE_SLOTS > cfg::CHROMA_SLOTS ? STAGE_SLOTS : cfg::CHROMA_SLOTS];
-  uint4 *stage = lds;
-  float *chroma = reinterpret_cast<float *>(lds);
+  __shared__ float lds[cfg::LDS_FLOATS];
+  float *chroma = lds;
+  uint4 *qlds = reinterpret_cast<uint4 *>(lds + cfg::CHROMA_FLOATS);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tx = blockIdx.x, mrow = blockIdx.y, img = blockIdx.z;
-  const int cbx0 = tx*64;                      // first chroma block / MCU of tile
-  const int16_t *cbase = P.coef + (long long)img*P.coef_stride;
+  const int cbx0 = tx*cfg::TILE;               // first MCU / chroma block of the tile
   const long long rs = (long long)P.w0_blocks*64;
 
   const bool is_luma = wave < cfg::NLW;
-  int pl, bx, by, cb = 0, subx = 0, suby = 0;
+  int pl, bx, by, cb, comp = 0, subx = 0, suby = 0;
   if (is_luma) {
-    const int lxw = wave & (cfg::LW - 1);
-    suby = wave >> XDEC;
-    const int lx = lxw*64 + lane;
+    const int idx = wave*64 + lane;
+    suby = idx/cfg::ROWLEN;
+    const int lx = idx - suby*cfg::ROWLEN;
     pl = 0;
     bx = cbx0*cfg::LW + lx;
     by = mrow*cfg::LH + suby;
@@ -348,42 +434,35 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
     subx = lx & (cfg::LW - 1);
   }
   else {
-    pl = 1 + (wave - cfg::NLW);
-    bx = cbx0 + lane;
+    const int cidx = (wave - cfg::NLW)*64 + lane;
+    comp = cidx/cfg::TILE;
+    cb = cidx - comp*cfg::TILE;
+    pl = 1 + comp;
+    bx = cbx0 + cb;
     by = mrow;
   }
   const int hblocks = P.plane_hblocks[pl];
   const bool valid = bx < hblocks;
-  const int cbxl = valid ? bx : hblocks - 1;   // clamp: tail lanes reload a real block
+  const int cbxl = valid ? bx : hblocks - 1;   // tail lanes reload a real block
   const int xdec = is_luma ? 0 : XDEC;
-  const long long boff = P.plane_coef_off[pl] + rs*(by >> xdec)
-   + (rs >> xdec)*(by & ((1 << xdec) - 1));
+  const int16_t *src = P.coef + (long long)img*P.coef_stride + P.plane_coef_off[pl]
+   + rs*(by >> xdec) + (rs >> xdec)*(by & ((1 << xdec) - 1)) + (long long)cbxl*64;
 
   uint4 rows[8];
-  // staged (coalesced) load needs the wave's 64 blocks to exist contiguously
-  const int wbx0 = is_luma ? cbx0*cfg::LW + (wave & (cfg::LW - 1))*64 : cbx0;
-  if (LOADMODE != 0 && wbx0 + 64 <= hblocks) {
-    load_block_wave<LOADMODE>(cbase + boff + (long long)wbx0*64, lane,
-     stage + wave*512, rows);
-  }
-  else load_block_direct(cbase + boff + (long long)cbxl*64, rows);
-
-  const uint32_t *q = reinterpret_cast<const uint32_t *>(P.qtab)
-   + ((long long)img*3 + pl)*32;
-  uint32_t qv[32];
+  load_block_direct(src, rows);                // in flight across the barrier below
   if (DEQUANT) {
-#pragma unroll
-    for (int n = 0; n < 32; n++) qv[n] = q[n];
+    if (threadIdx.x < 24) {
+      qlds[threadIdx.x] = reinterpret_cast<const uint4 *>(P.qtab + (long long)img*192)[threadIdx.x];
+    }
+    __syncthreads();
   }
-  float t[64];
-  idct_block<DEQUANT>(rows, qv, t);
+  float z[64], t[64];
+  row_pass_ldsq<DEQUANT>(rows, qlds + pl*8, z);
+  col_pass(z, t);
 
-  // the hand-off area aliases the staging slots: every wave must have pulled
-  // its coefficients into registers first
-  if (LOADMODE) __syncthreads();
   if (!is_luma) {
     // publish (sample-128) clamped to [-128,127] == clamp255(s+128)-128
-    float *dst = chroma + (((wave - cfg::NLW)*8)*64 + lane)*8;
+    float *dst = chroma + ((comp*8)*cfg::TILE + cb)*8;
 #pragma unroll
     for (int n = 0; n < 64; n += 4) {
       v4f v;
@@ -391,76 +470,44 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
       v.y = __builtin_amdgcn_fmed3f(t[n + 1], -128.0f, 127.0f);
       v.z = __builtin_amdgcn_fmed3f(t[n + 2], -128.0f, 127.0f);
       v.w = __builtin_amdgcn_fmed3f(t[n + 3], -128.0f, 127.0f);
-      *reinterpret_cast<v4f *>(dst + (n >> 3)*512 + (n & 4)) = v;
+      *reinterpret_cast<v4f *>(dst + (n >> 3)*(cfg::TILE*8) + (n & 4)) = v;
     }
   }
   __syncthreads();
   if (!is_luma || !valid) return;
 
   // chroma patch of this luma block: rows suby*CH.., cols subx*CW..
-  float u[cfg::CH*cfg::CW], v[cfg::CH*cfg::CW];
-  {
-    const float *ub = chroma + ((suby*cfg::CH)*64 + cb)*8 + subx*cfg::CW;
-    const float *vb = ub + 8*64*8;
-#pragma unroll
-    for (int r = 0; r < cfg::CH; r++) {
-#pragma unroll
-      for (int c = 0; c < cfg::CW; c++) {
-        u[r*cfg::CW + c] = ub[r*512 + c];
-        v[r*cfg::CW + c] = vb[r*512 + c];
-      }
-    }
-  }
+  const float *ub = chroma + ((suby*cfg::CH)*cfg::TILE + cb)*8 + subx*cfg::CW;
+  const float *vb = ub + 8*cfg::TILE*8;
   const int x0 = bx*8, y0 = by*8;
   const long long pitch = (long long)P.width*3;
   uint8_t *obase = P.out + (long long)img*P.out_stride + (long long)y0*pitch
    + (long long)x0*3;
   const bool fast = P.out_aligned && x0 + 8 <= P.width;
+  chroma_row<cfg::CW> cr;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    float rgb[24];
+    if ((k & (cfg::LH - 1)) == 0) {
+      float u[cfg::CW], v[cfg::CW];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const float Y = __builtin_amdgcn_fmed3f(t[k*8 + i], -128.0f, 127.0f) + 128.0f;
-      const float uu = u[(k >> YDEC)*cfg::CW + (i >> XDEC)];
-      const float vv = v[(k >> YDEC)*cfg::CW + (i >> XDEC)];
-      // unyuv.fs.glsl:12-16,48 in mat3*vec3 column order
-      rgb[3*i + 0] = unorm8(Y + 1.402f*vv);
-      rgb[3*i + 1] = unorm8((Y + (-0.34414f)*uu) + (-0.71414f)*vv);
-      rgb[3*i + 2] = unorm8(Y + 1.772f*uu);
-    }
-    if (y0 + k >= P.height) continue;
-    uint8_t *o = obase + k*pitch;
-    if (fast) {
-      uint4 a;
-      uint2 b;
-      a.x = pack_u8x4(rgb[0], rgb[1], rgb[2], rgb[3]);
-      a.y = pack_u8x4(rgb[4], rgb[5], rgb[6], rgb[7]);
-      a.z = pack_u8x4(rgb[8], rgb[9], rgb[10], rgb[11]);
-      a.w = pack_u8x4(rgb[12], rgb[13], rgb[14], rgb[15]);
-      b.x = pack_u8x4(rgb[16], rgb[17], rgb[18], rgb[19]);
-      b.y = pack_u8x4(rgb[20], rgb[21], rgb[22], rgb[23]);
-      *reinterpret_cast<uint4 *>(o) = a;
-      *reinterpret_cast<uint2 *>(o + 16) = b;
-    }
-    else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        if (x0 + i < P.width) {
-          o[3*i + 0] = (uint8_t)(pack_u8x4(rgb[3*i + 0], 0, 0, 0) & 255u);
-          o[3*i + 1] = (uint8_t)(pack_u8x4(rgb[3*i + 1], 0, 0, 0) & 255u);
-          o[3*i + 2] = (uint8_t)(pack_u8x4(rgb[3*i + 2], 0, 0, 0) & 255u);
-        }
+      for (int c = 0; c < cfg::CW; c++) {
+        u[c] = ub[(k >> YDEC)*(cfg::TILE*8) + c];
+        v[c] = vb[(k >> YDEC)*(cfg::TILE*8) + c];
       }
+      cr.set(u, v);
     }
+    uint4 a;
+    uint2 b;
+    rgb_row<XDEC, cfg::CW>(t + k*8, cr, a, b);
+    if (y0 + k < P.height) store_rgb_row(obase + k*pitch, a, b, fast, x0, P.width);
   }
 }
 
 // Grey: one plane, img->pixels is 1 B/px at the true size (ungrey.fs.glsl:18;
 // pixel layout src/jpeg_wrap.c:215-219).  Flat over the luma raster.
-template <bool DEQUANT, int LOADMODE>
+template <bool DEQUANT, bool STAGED>
 __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P) {
-  __shared__ uint4 stage[LOADMODE ? 4*512 : 1];
+  __shared__ uint4 stage[STAGED ? 4*512 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int img = blockIdx.y;
@@ -471,8 +518,8 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
   const int by = (int)fastdiv(s, P.div_w0), bx = s - by*P.w0_blocks;
   const int16_t *cbase = P.coef + (long long)img*P.coef_stride;
   uint4 rows[8];
-  if (LOADMODE != 0 && wslot + 64 <= P.slots_per_image) {
-    load_block_wave<LOADMODE>(cbase + (long long)wslot*64, lane, stage + wave*512,
+  if (STAGED && wslot + 64 <= P.slots_per_image) {
+    load_block_staged(cbase + (long long)wslot*64, lane, stage + wave*512,
      rows);
   }
   else load_block_direct(cbase + (long long)s*64, rows);
@@ -497,7 +544,7 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
      t[k*8 + 2] + 128.0f, t[k*8 + 3] + 128.0f);
     v.y = pack_u8x4(t[k*8 + 4] + 128.0f, t[k*8 + 5] + 128.0f,
      t[k*8 + 6] + 128.0f, t[k*8 + 7] + 128.0f);
-    if (fast) *reinterpret_cast<uint2 *>(o) = v;
+    if (fast) st_nt(reinterpret_cast<uint2 *>(o), v);
     else {
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -512,69 +559,42 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
 // live in device_api.cpp).
 // ---------------------------------------------------------------------------
 template <int XDEC, int YDEC>
-static hipError_t launch_rgb_t(const jga_kparams &P, int loadmode,
- hipStream_t st) {
+static hipError_t launch_rgb_t(const jga_kparams &P, hipStream_t st) {
   typedef rgb_cfg<XDEC, YDEC> cfg;
-  dim3 grid(P.tiles_per_row, P.nvmb, P.nimages), block(cfg::THREADS);
-#define JGA_RGB_LAUNCH(DQ, LM) hipLaunchKernelGGL((jga_idct_rgb_kernel<XDEC, YDEC, DQ, LM>), grid, block, 0, st, P)
-  if (P.dequant) {
-    if (loadmode == 2) JGA_RGB_LAUNCH(true, 2);
-    else if (loadmode == 1) JGA_RGB_LAUNCH(true, 1);
-    else JGA_RGB_LAUNCH(true, 0);
-  }
-  else {
-    if (loadmode == 2) JGA_RGB_LAUNCH(false, 2);
-    else if (loadmode == 1) JGA_RGB_LAUNCH(false, 1);
-    else JGA_RGB_LAUNCH(false, 0);
-  }
-#undef JGA_RGB_LAUNCH
+  dim3 grid((P.nhmb + cfg::TILE - 1)/cfg::TILE, P.nvmb, P.nimages), block(cfg::THREADS);
+  if (P.dequant) hipLaunchKernelGGL((jga_idct_rgb_kernel<XDEC, YDEC, true>), grid, block, 0, st, P);
+  else hipLaunchKernelGGL((jga_idct_rgb_kernel<XDEC, YDEC, false>), grid, block, 0, st, P);
   return hipGetLastError();
 }
 
 extern "C" int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec,
- int loadmode, void *stream) {
+ int staged, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipErrorInvalidValue;
   if (P->nplanes == 1) {
     dim3 grid((P->slots_per_image + 255)/256, P->nimages), block(256);
-#define JGA_GREY_LAUNCH(DQ, LM) hipLaunchKernelGGL((jga_idct_grey_kernel<DQ, LM>), grid, block, 0, st, *P)
-    if (P->dequant) {
-      if (loadmode == 2) JGA_GREY_LAUNCH(true, 2);
-      else if (loadmode == 1) JGA_GREY_LAUNCH(true, 1);
-      else JGA_GREY_LAUNCH(true, 0);
-    }
-    else {
-      if (loadmode == 2) JGA_GREY_LAUNCH(false, 2);
-      else if (loadmode == 1) JGA_GREY_LAUNCH(false, 1);
-      else JGA_GREY_LAUNCH(false, 0);
-    }
+#define JGA_GREY_LAUNCH(DQ, ST) hipLaunchKernelGGL((jga_idct_grey_kernel<DQ, ST>), grid, block, 0, st, *P)
+    if (P->dequant) { if (staged) JGA_GREY_LAUNCH(true, true); else JGA_GREY_LAUNCH(true, false); }
+    else { if (staged) JGA_GREY_LAUNCH(false, true); else JGA_GREY_LAUNCH(false, false); }
 #undef JGA_GREY_LAUNCH
     e = hipGetLastError();
   }
   else {
-    if (xdec == 0 && ydec == 0) e = launch_rgb_t<0, 0>(*P, loadmode, st);
-    else if (xdec == 1 && ydec == 0) e = launch_rgb_t<1, 0>(*P, loadmode, st);
-    else if (xdec == 1 && ydec == 1) e = launch_rgb_t<1, 1>(*P, loadmode, st);
-    else if (xdec == 0 && ydec == 1) e = launch_rgb_t<0, 1>(*P, loadmode, st);
-    else if (xdec == 2 && ydec == 0) e = launch_rgb_t<2, 0>(*P, loadmode, st);
+    if (xdec == 0 && ydec == 0) e = launch_rgb_t<0, 0>(*P, st);
+    else if (xdec == 1 && ydec == 0) e = launch_rgb_t<1, 0>(*P, st);
+    else if (xdec == 1 && ydec == 1) e = launch_rgb_t<1, 1>(*P, st);
+    else if (xdec == 0 && ydec == 1) e = launch_rgb_t<0, 1>(*P, st);
+    else if (xdec == 2 && ydec == 0) e = launch_rgb_t<2, 0>(*P, st);
   }
   return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int jga_launch_yuv(const jga_kparams *P, int loadmode, void *stream) {
+extern "C" int jga_launch_yuv(const jga_kparams *P, int staged, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((P->slots_per_image + 255)/256, P->nimages), block(256);
-#define JGA_YUV_LAUNCH(DQ, LM) hipLaunchKernelGGL((jga_idct_yuv_kernel<DQ, LM>), grid, block, 0, st, *P)
-  if (P->dequant) {
-    if (loadmode == 2) JGA_YUV_LAUNCH(true, 2);
-    else if (loadmode == 1) JGA_YUV_LAUNCH(true, 1);
-    else JGA_YUV_LAUNCH(true, 0);
-  }
-  else {
-    if (loadmode == 2) JGA_YUV_LAUNCH(false, 2);
-    else if (loadmode == 1) JGA_YUV_LAUNCH(false, 1);
-    else JGA_YUV_LAUNCH(false, 0);
-  }
+#define JGA_YUV_LAUNCH(DQ, ST) hipLaunchKernelGGL((jga_idct_yuv_kernel<DQ, ST>), grid, block, 0, st, *P)
+  if (P->dequant) { if (staged) JGA_YUV_LAUNCH(true, true); else JGA_YUV_LAUNCH(true, false); }
+  else { if (staged) JGA_YUV_LAUNCH(false, true); else JGA_YUV_LAUNCH(false, false); }
 #undef JGA_YUV_LAUNCH
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

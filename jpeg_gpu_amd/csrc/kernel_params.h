@@ -23,7 +23,7 @@ typedef struct jga_kparams {
   int width, height;          /* true size */
   int w0_blocks;              /* luma blocks per row; RS = w0_blocks*64 shorts */
   int slots_per_image;        /* 128-byte slots in one coefficient buffer */
-  int tiles_per_row;          /* RGB kernel: 64-MCU tiles per MCU row */
+  int nhmb;                   /* MCUs per row */
   int nvmb;                   /* MCU rows */
   jga_divisor div_w0;         /* by w0_blocks */
   jga_divisor div_hb[3];      /* by w0_blocks >> xdec of each plane */
@@ -39,9 +39,9 @@ typedef struct jga_kparams {
 #ifdef __cplusplus
 extern "C" {
 #endif
-int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec, int loadmode,
+int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec, int staged,
  void *stream);
-int jga_launch_yuv(const jga_kparams *P, int loadmode, void *stream);
+int jga_launch_yuv(const jga_kparams *P, int staged, void *stream);
 #ifdef __cplusplus
 }
 #endif

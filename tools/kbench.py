@@ -47,9 +47,18 @@ if __name__ == "__main__":
         print("RESULT " + json.dumps(one(w, h, samp, n)))
         sys.exit(0)
     args = sys.argv[1:] or ["3840", "2160", "420", "32"]
-    for mode in ("0", "1", "2"):
-        env = dict(os.environ, JGA_LOADMODE=mode)
+    configs = [dict(JGA_STAGED="1"), dict(JGA_STAGED="0")]
+    if os.environ.get("KBENCH_CONFIGS"):
+        configs = json.loads(os.environ["KBENCH_CONFIGS"])
+    for cfg in configs:
+        env = dict(os.environ, **cfg)
         r = subprocess.run([sys.executable, __file__, "--child"] + args, env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-        print("loadmode", mode, args, line[0][7:] if line else r.stdout[-2000:])
+        if line:
+            d = json.loads(line[0][7:])
+            print("%-70s rgb %.4f ms %5.0f GB/s | yuv %.4f ms %5.0f GB/s" % (
+                json.dumps(cfg).replace("JGA_", ""), d["rgb"]["ms"], d["rgb"]["gbps"],
+                d["yuv"]["ms"], d["yuv"]["gbps"]))
+        else:
+            print(cfg, r.stdout[-1500:])
