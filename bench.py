@@ -125,7 +125,7 @@ def main():
     import ctypes as C
     import __graft_entry__
     __graft_entry__.build()
-    from jpeg_gpu_amd import abi, lib, synth
+    from jpeg_gpu_amd import abi, lib, shard, synth
 
     if not torch.cuda.is_available() or lib.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible (no CPU fallback exists)")
@@ -175,10 +175,10 @@ def main():
     ev_ms = launch(args.steps)            # K launches, HIP events on `stream`
     fence()
     dt = time.perf_counter() - t0
+    # whole-job rate = pixels of all ranks / max time over ranks (no data-path collective)
+    rate, _, dt = shard.aggregate_throughput(args.batch * W * H * args.steps, dt,
+                                              dist if world > 1 else None, device="cuda")
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         e = torch.tensor([ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         ev_ms = float(e.item())
@@ -193,8 +193,7 @@ def main():
         if not ok:
             raise SystemExit("bench.py: device output differs from the oracle")
 
-    pixels_per_step = B * W * H
-    value = world * pixels_per_step * args.steps / dt / 1e6
+    value = rate / 1e6
     alg_bytes = B * (g.coef_blocks * 128 + g.rgb_bytes)
     achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
     traffic = None
