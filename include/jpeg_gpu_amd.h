@@ -305,6 +305,25 @@ jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);
 int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);
 void jga_pipeline_destroy(jga_pipeline *pl);
 
+/* --- GPU entropy stage (BASELINE config 5): the scan is
+ *     decoded ON THE GPU by self-synchronising parallel Huffman decoding —
+ *     replaces the serial host loop src/xjpeg.c:449-632 (restart handling
+ *     593-629) for callers that want no host Huffman work and 8x fewer PCIe
+ *     bytes.  Works with or without DRI; restart intervals are extra hard sync
+ *     points.  Output = the same QUANT-stage buffers as jga_entropy_decode().
+ *     prepare(): host parses headers, uploads tables + compressed scan bytes
+ *     (async on `stream`).  decode(): device only; callable repeatedly. ------ */
+typedef struct jga_huff_batch jga_huff_batch;
+jga_huff_batch *jga_huff_create(int max_images, long long max_scan_bytes);
+void jga_huff_destroy(jga_huff_batch *b);
+int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *jpegs,
+ const int *sizes, int n, jga_geom *geom, void *stream);
+int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ void *stream);
+long long jga_huff_upload_bytes(const jga_huff_batch *b);
+int jga_huff_last_rounds(const jga_huff_batch *b);
+const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

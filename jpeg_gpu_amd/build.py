@@ -21,8 +21,9 @@ OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
 C_SOURCES = ["layout.c", "entropy.c"]
-HIP_SOURCES = ["idct_kernels.hip"]                    # device code: hipcc
-CXX_SOURCES = ["device_api.cpp", "vtbl.cpp", "pipeline.cpp"]  # host only: g++ + HIP API
+HIP_SOURCES = ["idct_kernels.hip", "huff_kernels.hip"]   # device code: hipcc
+CXX_SOURCES = ["device_api.cpp", "vtbl.cpp", "pipeline.cpp", "huff_prepare.cpp",
+               "huff_api.cpp"]                           # host only: g++ + HIP API
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 LIB = os.path.join(HERE, "libjpeg_gpu_amd.so")
 SYNTH_LIB = os.path.join(HERE, "libjga_synth.so")
@@ -65,7 +66,8 @@ def check_no_fma(asm_path):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in ("jga_internal.h", "kernel_params.h")]
+    headers = [os.path.join(CSRC, h) for h in ("jga_internal.h", "kernel_params.h", "huff_common.h",
+                                               "huff_kernels.h", "huff_prepare.h")]
     headers.append(os.path.join(HERE, "..", "include", "jpeg_gpu_amd.h"))
     all_src = [os.path.join(CSRC, s) for s in C_SOURCES + HIP_SOURCES + CXX_SOURCES] + headers
 
@@ -98,7 +100,7 @@ def build(force=False, verbose=False):
             cmd.insert(1, "-save-temps=obj")
         _run(cmd)
         objs.append(o)
-        if s.endswith(".hip"):
+        if s == "idct_kernels.hip":      # the float path; huff_kernels is integer/byte code
             stem = s[:-4]
             asm = os.path.join(OBJ, "%s-hip-amdgcn-amd-amdhsa-%s.s" % (stem, ARCH))
             if not os.path.exists(asm):

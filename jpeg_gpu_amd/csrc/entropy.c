@@ -49,6 +49,8 @@ typedef struct parser {
   comp_info comp[3];
   jpeg_quant quant[NQUANT_MAX];
   htab dc[4], ac[4];
+  uint8_t dht_bits[8][16];        /* raw DHT (tc*4+th), for the GPU entropy stage */
+  uint8_t dht_vals[8][256];
 } parser;
 
 static int DEZZ[64];   /* zig-zag position -> natural index (T.81 Fig. A.6) */
@@ -158,6 +160,9 @@ static int parse_dht(parser *ps, long end) {
     if (build_htab(tc ? &ps->ac[th] : &ps->dc[th], counts, ps->buf + ps->pos, tc)) {
       return jga_fail("Error invalid DHT.");
     }
+    memcpy(ps->dht_bits[tc*4 + th], counts, 16);
+    memset(ps->dht_vals[tc*4 + th], 0, 256);
+    memcpy(ps->dht_vals[tc*4 + th], ps->buf + ps->pos, (size_t)n);
     if (!tc) {
       for (i = 0; i < n; i++) {
         if (ps->buf[ps->pos + i] > 15) return jga_fail("Error invalid DC symbol.");
@@ -332,6 +337,29 @@ JGA_EXPORT int jga_parse_header(const unsigned char *buf, int size,
   if (!ps) return jga_fail("Out of memory");
   rc = parse_to_scan(ps, buf, size);
   if (rc == EXIT_SUCCESS) fill_header(ps, header);
+  free(ps);
+  return rc;
+}
+
+int jga_scan_describe(const unsigned char *buf, int size, jga_scan_desc *d) {
+  parser *ps = (parser *)malloc(sizeof(parser));
+  int rc, i;
+  if (!ps) return jga_fail("Out of memory");
+  rc = parse_to_scan(ps, buf, size);
+  if (rc == EXIT_SUCCESS) {
+    memset(d, 0, sizeof(*d));
+    fill_header(ps, &d->header);
+    d->scan_off = (int)ps->pos;
+    for (i = 0; i < ps->ncomps; i++) {
+      d->td[i] = ps->comp[i].td;
+      d->ta[i] = ps->comp[i].ta;
+    }
+    for (i = 0; i < 8; i++) {
+      d->dht_valid[i] = i < 4 ? ps->dc[i].valid : ps->ac[i - 4].valid;
+      memcpy(d->dht_bits[i], ps->dht_bits[i], 16);
+      memcpy(d->dht_vals[i], ps->dht_vals[i], 256);
+    }
+  }
   free(ps);
   return rc;
 }

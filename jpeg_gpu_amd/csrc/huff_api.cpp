@@ -1,0 +1,224 @@
+// huff_api.cpp — C-ABI of the GPU entropy stage (BASELINE config 5).
+//   jga_huff_create / _prepare / _decode / _destroy
+// prepare(): host parses the marker segments of a batch of same-geometry JPEGs,
+//   builds device tables / restart segments / initial lane states and uploads them
+//   together with the entropy-coded bytes (compressed: ~0.4 B/px instead of 3 B/px).
+// decode(): everything on the GPU: zero the coefficient planes, synchronisation
+//   rounds until no lane moves, per-segment prefix sums, scatter pass.  The output is
+//   the same packed QUANT-stage buffer jga_entropy_decode() produces on the host.
+#include <hip/hip_runtime_api.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "huff_kernels.h"
+#include "huff_prepare.h"
+
+#define HOK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+  return jga_fail("huff: HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #call); } while (0)
+
+struct jga_huff_batch {
+  int max_images;
+  long long max_scan;
+  // host staging (pinned)
+  unsigned char *h_blob;       // images | segs | sub_seg | tables | S | scan, one upload
+  size_t blob_cap;
+  // device
+  unsigned char *d_blob;
+  uint64_t *d_last_in;
+  hj_run *d_R;
+  uint32_t *d_B;
+  int16_t *d_D;
+  uint32_t *d_ran, *d_errors;
+  uint32_t *h_ran;             // pinned readback
+  size_t sub_cap;
+  // current batch
+  int nimages;
+  uint32_t total_sub, total_seg, max_nsub;
+  size_t off_images, off_segs, off_subseg, off_tables, off_S, off_scan, blob_size;
+  jga_geom geom;
+  std::vector<unsigned short> qtab;
+  int last_rounds;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1)/a*a; }
+
+extern "C" {
+
+JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_bytes) {
+  jga_huff_batch *b = new jga_huff_batch();
+  memset(static_cast<void *>(b), 0, offsetof(jga_huff_batch, qtab));
+  b->max_images = max_images;
+  b->max_scan = max_scan_bytes;
+  b->sub_cap = (size_t)(max_scan_bytes/HJ_SUB_BYTES) + (size_t)max_images*4096 + 1024;
+  const size_t seg_cap = b->sub_cap;   // worst case one segment per subsequence
+  b->blob_cap = align_up(sizeof(hj_image)*max_images, 256) + align_up(sizeof(hj_segment)*seg_cap, 256)
+   + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_table)*6*max_images, 256)
+   + align_up(8*(b->sub_cap + seg_cap), 256) + align_up((size_t)max_scan_bytes + 64*max_images, 256);
+  bool ok = hipHostMalloc((void **)&b->h_blob, b->blob_cap, hipHostMallocDefault) == hipSuccess
+   && hipMalloc((void **)&b->d_blob, b->blob_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_last_in, 8*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_R, sizeof(hj_run)*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_B, 4*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_D, 6*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS) == hipSuccess
+   && hipMalloc((void **)&b->d_errors, 4*(size_t)max_images) == hipSuccess
+   && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    jga_fail("huff: allocation failed (%d images, %lld scan bytes)", max_images, max_scan_bytes);
+    jga_huff_destroy(b);
+    return NULL;
+  }
+  return b;
+}
+
+JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
+  if (!b) return;
+  if (b->h_blob) (void)hipHostFree(b->h_blob);
+  if (b->h_ran) (void)hipHostFree(b->h_ran);
+  if (b->d_blob) (void)hipFree(b->d_blob);
+  if (b->d_last_in) (void)hipFree(b->d_last_in);
+  if (b->d_R) (void)hipFree(b->d_R);
+  if (b->d_B) (void)hipFree(b->d_B);
+  if (b->d_D) (void)hipFree(b->d_D);
+  if (b->d_ran) (void)hipFree(b->d_ran);
+  if (b->d_errors) (void)hipFree(b->d_errors);
+  delete b;
+}
+
+// Parse + stage a batch.  All images must share one geometry (returned in *geom).
+JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *jpegs,
+ const int *sizes, int n, jga_geom *geom, void *stream) {
+  if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
+  std::vector<hj_prepared> prep((size_t)n);
+  size_t total_sub = 0, total_seg = 0, total_scan = 0;
+  uint32_t max_nsub = 0;
+  for (int i = 0; i < n; i++) {
+    if (hj_prepare_image(jpegs[i], sizes[i], &prep[i]) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (i && (prep[i].geom.coef_shorts != prep[0].geom.coef_shorts
+     || prep[i].geom.width != prep[0].geom.width || prep[i].geom.height != prep[0].geom.height
+     || prep[i].geom.subsamp != prep[0].geom.subsamp)) {
+      return jga_fail("huff: images of one batch must share a geometry");
+    }
+    total_sub += prep[i].im.nsub;
+    total_seg += prep[i].segs.size();
+    total_scan += align_up(prep[i].scan_len + 16, 16);
+    if (prep[i].im.nsub > max_nsub) max_nsub = prep[i].im.nsub;
+  }
+  if (total_sub > b->sub_cap || total_seg > b->sub_cap || (long long)total_scan > b->max_scan + 64ll*n) {
+    return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
+  }
+  b->nimages = n;
+  b->total_sub = (uint32_t)total_sub;
+  b->total_seg = (uint32_t)total_seg;
+  b->max_nsub = max_nsub;
+  b->geom = prep[0].geom;
+  size_t o = 0;
+  b->off_images = o; o += align_up(sizeof(hj_image)*n, 256);
+  b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
+  b->off_subseg = o; o += align_up(4*total_sub, 256);
+  b->off_tables = o; o += align_up(sizeof(hj_table)*6*n, 256);
+  b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
+  b->off_scan = o; o += align_up(total_scan, 256);
+  b->blob_size = o;
+  hj_image *images = (hj_image *)(b->h_blob + b->off_images);
+  hj_segment *segs = (hj_segment *)(b->h_blob + b->off_segs);
+  uint32_t *sub_seg = (uint32_t *)(b->h_blob + b->off_subseg);
+  hj_table *tables = (hj_table *)(b->h_blob + b->off_tables);
+  uint64_t *S = (uint64_t *)(b->h_blob + b->off_S);
+  unsigned char *scan = b->h_blob + b->off_scan;
+  b->qtab.assign((size_t)n*192, 0);
+  uint32_t sub0 = 0, seg0 = 0, scan_off = 0;
+  for (int i = 0; i < n; i++) {
+    hj_prepared &p = prep[i];
+    p.im.sub0 = sub0;
+    p.im.seg0 = seg0;
+    p.im.scan_off = scan_off;
+    images[i] = p.im;
+    memcpy(tables + 6*i, p.tabs, sizeof(p.tabs));
+    memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
+    memcpy(scan + scan_off, p.scan, p.scan_len);
+    memset(scan + scan_off + p.scan_len, 0xFF, align_up(p.scan_len + 16, 16) - p.scan_len);
+    for (size_t si = 0; si < p.segs.size(); si++) {
+      const hj_segment &sg = p.segs[si];
+      segs[seg0 + si] = sg;
+      for (uint32_t k = 0; k < sg.nsub; k++) {
+        sub_seg[sub0 + sg.sub0 + k] = (uint32_t)si;
+        uint32_t byte = sg.start + k*HJ_SUB_BYTES;       // guess: a symbol starts on this byte
+        if (k > 0 && byte < sg.end && p.scan[byte] == 0x00 && p.scan[byte - 1] == 0xFF) byte++;
+        S[sub0 + seg0 + sg.sub0 + si + k] = hj_pack((uint64_t)byte*8, 0, 0);
+      }
+      S[sub0 + seg0 + sg.sub0 + si + sg.nsub] = 0;
+    }
+    sub0 += p.im.nsub;
+    seg0 += (uint32_t)p.segs.size();
+    scan_off += (uint32_t)align_up(p.scan_len + 16, 16);
+  }
+  HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->blob_size, hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (geom) *geom = b->geom;
+  return EXIT_SUCCESS;
+}
+
+// Bytes uploaded by the last prepare() (tables + states + compressed scan data).
+JGA_EXPORT long long jga_huff_upload_bytes(const jga_huff_batch *b) { return (long long)b->blob_size; }
+JGA_EXPORT int jga_huff_last_rounds(const jga_huff_batch *b) { return b->last_rounds; }
+// Quantisation tables of the prepared batch: nimages*3*64 uint16 (host memory).
+JGA_EXPORT const unsigned short *jga_huff_qtabs(const jga_huff_batch *b) { return b->qtab.data(); }
+
+// Decode the prepared batch into d_coef (image i at d_coef + i*coef_stride shorts).
+// May be called repeatedly on the same prepared batch (state is reset each time).
+JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!b->nimages) return jga_fail("huff: nothing prepared");
+  if (coef_stride < b->geom.coef_shorts) return jga_fail("huff: coef_stride too small");
+  hj_args A;
+  memset(&A, 0, sizeof(A));
+  A.images = (const hj_image *)(b->d_blob + b->off_images);
+  A.segs = (const hj_segment *)(b->d_blob + b->off_segs);
+  A.sub_seg = (const uint32_t *)(b->d_blob + b->off_subseg);
+  A.tables = (const hj_table *)(b->d_blob + b->off_tables);
+  A.scan = b->d_blob + b->off_scan;
+  A.S = (uint64_t *)(b->d_blob + b->off_S);
+  A.last_in = b->d_last_in;
+  A.R = b->d_R;
+  A.B = b->d_B;
+  A.D = b->d_D;
+  A.ran = b->d_ran;
+  A.errors = b->d_errors;
+  A.coef = (int16_t *)d_coef;
+  A.coef_stride = coef_stride;
+  A.nimages = b->nimages;
+  // reset: states back to the guesses, "never ran", planes zero (only non-zeros are written)
+  HOK(hipMemcpyAsync(b->d_blob + b->off_S, b->h_blob + b->off_S, 8*(size_t)(b->total_sub + b->total_seg),
+   hipMemcpyHostToDevice, st));
+  HOK(hipMemsetAsync(b->d_last_in, 0xFF, 8*(size_t)b->total_sub, st));
+  HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));
+  HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
+  HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, st));
+  int round = 0;
+  const int GROUP = 8;
+  for (;;) {
+    for (int k = 0; k < GROUP && round < HJ_MAX_ROUNDS; k++, round++) {
+      if (hj_launch_round(&A, (int)b->max_nsub, round, st)) return jga_fail("huff: launch failed");
+    }
+    HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
+    HOK(hipStreamSynchronize(st));
+    if (b->h_ran[round - 1] == 0) break;                   // a round in which nothing moved
+    if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
+  }
+  b->last_rounds = 0;
+  while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;
+  if (hj_launch_scan(&A, (int)b->total_seg, st)) return jga_fail("huff: launch failed");
+  if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+  HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
+  HOK(hipStreamSynchronize(st));
+  for (int i = 0; i < b->nimages; i++) {
+    if (b->h_ran[HJ_MAX_ROUNDS + i]) {
+      return jga_fail("huff: image %d: %s", i, (b->h_ran[HJ_MAX_ROUNDS + i] & 2)
+       ? "Error indexing outside block." : "Error, entropy data ended early.");
+    }
+  }
+  return EXIT_SUCCESS;
+}
+
+}  // extern "C"

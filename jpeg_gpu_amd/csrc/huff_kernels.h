@@ -1,0 +1,35 @@
+/* huff_kernels.h — launch arguments of the GPU entropy stage (huff_kernels.hip). */
+#ifndef JGA_HUFF_KERNELS_H
+#define JGA_HUFF_KERNELS_H (1)
+#include "huff_common.h"
+
+#define HJ_MAX_ROUNDS 256
+
+typedef struct hj_args {
+  const hj_image *images;      /* [nimages] */
+  const hj_segment *segs;      /* all images' segments, image-major */
+  const uint32_t *sub_seg;     /* per subsequence: segment index local to its image */
+  const hj_table *tables;      /* [nimages*6] */
+  const uint8_t *scan;         /* all images' entropy-coded bytes */
+  uint64_t *S;                 /* states: nsub + nseg entries per image */
+  uint64_t *last_in;           /* start state of each lane's latest run */
+  hj_run *R;                   /* result of each lane's latest run */
+  uint32_t *B;                 /* blocks before the lane, within its segment */
+  int16_t *D;                  /* [3*sub] DC sums before the lane */
+  uint32_t *ran;               /* [HJ_MAX_ROUNDS] non-zero if any lane ran in that round */
+  uint32_t *errors;            /* [nimages] bit0 inconsistent stream, bit1 bad coefficient index */
+  int16_t *coef;               /* image i at coef + i*coef_stride */
+  long long coef_stride;
+  int nimages;
+} hj_args;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int hj_launch_round(const hj_args *A, int max_nsub, int round, void *stream);
+int hj_launch_scan(const hj_args *A, int total_segs, void *stream);
+int hj_launch_write(const hj_args *A, int max_nsub, void *stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -19,6 +19,17 @@ int jga_subsamp_of(int xdec, int ydec, int ncomps);
 /* Entropy decode with an explicit stage (entropy.c). */
 enum { JGA_STAGE_PACK = 0, JGA_STAGE_QUANT = 1, JGA_STAGE_DCT = 2 };
 
+/* What the GPU entropy stage (huff_api.cpp) needs from the marker segments. */
+typedef struct jga_scan_desc {
+  jpeg_header header;
+  int scan_off;                 /* first byte of entropy-coded data */
+  int td[3], ta[3];             /* DC / AC table selectors per component (SOS) */
+  int dht_valid[8];             /* index tc*4 + th */
+  unsigned char dht_bits[8][16];
+  unsigned char dht_vals[8][256];
+} jga_scan_desc;
+int jga_scan_describe(const unsigned char *buf, int size, jga_scan_desc *d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,8 @@ EXPORTED = [
     "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
     "jga_stream_sync", "jga_set_device", "jga_stream_create", "jga_stream_destroy",
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
-    "jga_pipeline_destroy",
+    "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
+    "jga_huff_decode", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_qtabs",
 ]
 
 
@@ -86,6 +87,18 @@ L.jga_pipeline_create.restype = _vp
 L.jga_pipeline_run.argtypes = [_vp, C.POINTER(abi.jga_job), _i]
 L.jga_pipeline_destroy.argtypes = [_vp]
 L.jga_pipeline_destroy.restype = None
+
+L.jga_huff_create.argtypes = [_i, _ll]
+L.jga_huff_create.restype = _vp
+L.jga_huff_destroy.argtypes = [_vp]
+L.jga_huff_destroy.restype = None
+L.jga_huff_prepare.argtypes = [_vp, C.POINTER(C.c_char_p), C.POINTER(_i), _i, _G, _vp]
+L.jga_huff_decode.argtypes = [_vp, _vp, _ll, _vp]
+L.jga_huff_upload_bytes.argtypes = [_vp]
+L.jga_huff_upload_bytes.restype = _ll
+L.jga_huff_last_rounds.argtypes = [_vp]
+L.jga_huff_qtabs.argtypes = [_vp]
+L.jga_huff_qtabs.restype = C.POINTER(C.c_ushort)
 
 VTBL = abi.jpeg_decode_ctx_vtbl.in_dll(L, "HIPJPEG_DECODE_CTX_VTBL")
 
@@ -340,3 +353,59 @@ class Pipeline:
         if self.ptr:
             L.jga_pipeline_destroy(self.ptr)
             self.ptr = None
+
+
+# ---- GPU entropy stage ------------------------------------------------------------
+
+class HuffBatch:
+    """jga_huff_*: Huffman decode of a same-geometry batch on the GPU."""
+
+    def __init__(self, max_images, max_scan_bytes):
+        self.ptr = L.jga_huff_create(max_images, max_scan_bytes)
+        if not self.ptr:
+            raise JgaError((L.jga_last_error() or b"jga_huff_create failed").decode())
+        self.n = 0
+        self.geom = None
+
+    def prepare(self, jpegs, stream=None):
+        n = len(jpegs)
+        self._keep = [bytes(j) for j in jpegs]
+        arr = (C.c_char_p * n)(*self._keep)
+        sizes = (C.c_int * n)(*[len(j) for j in self._keep])
+        g = abi.jga_geom()
+        check(L.jga_huff_prepare(self.ptr, arr, sizes, n, C.byref(g), stream))
+        self.n, self.geom = n, g
+        return g
+
+    def qtabs(self):
+        p = L.jga_huff_qtabs(self.ptr)
+        return np.ctypeslib.as_array(p, (self.n, 3, 64)).copy()
+
+    def decode(self, d_coef_ptr, coef_stride, stream=None):
+        check(L.jga_huff_decode(self.ptr, d_coef_ptr, coef_stride, stream))
+        return L.jga_huff_last_rounds(self.ptr)
+
+    def upload_bytes(self):
+        return L.jga_huff_upload_bytes(self.ptr)
+
+    def close(self):
+        if self.ptr:
+            L.jga_huff_destroy(self.ptr)
+            self.ptr = None
+
+
+def gpu_entropy_decode(jpegs):
+    """Decode the scans of same-geometry JPEGs on the GPU -> (geom, (n, coef_shorts) int16, rounds)."""
+    hb = HuffBatch(len(jpegs), sum(len(j) for j in jpegs) + 4096)
+    try:
+        g = hb.prepare(jpegs)
+        stride = _align(g.coef_shorts * 2) // 2
+        d = DeviceBuffer(stride * 2 * len(jpegs))
+        try:
+            rounds = hb.decode(d.ptr, stride)
+            raw = d.download(dtype=np.int16).reshape(len(jpegs), stride)
+            return g, raw[:, :g.coef_shorts].copy(), rounds
+        finally:
+            d.free()
+    finally:
+        hb.close()

@@ -268,3 +268,54 @@ def test_pipeline(gpu, orc, synth):
         assert rc == 1 and [jobs[i].status for i in range(4)] == [0, 1, 0, 0]
     finally:
         pl.close()
+
+
+# ---- GPU entropy stage ---------------------------------------------
+
+@pytest.mark.parametrize("sampling", SAMPLINGS)
+@pytest.mark.parametrize("ri", [0, -1, 3])
+def test_gpu_huffman_equals_host_entropy_stage(gpu, synth, sampling, ri):
+    datas = [synth.synthetic_jpeg(333, 211, sampling, quality=q, restart_interval=ri, seed=q)
+             for q in (90, 60, 30)]
+    g, coefs, rounds = gpu.gpu_entropy_decode(datas)
+    for d, c in zip(datas, coefs):
+        assert np.array_equal(c, gpu.entropy_decode(d, g)), (sampling, ri)
+
+
+def test_gpu_huffman_golden_jpegs(gpu, golden_jpegs):
+    """Pillow-made files (optimised tables, DRI) + ours, against the reference's QUANT planes."""
+    for name in golden_jpegs.names:
+        g, coefs, _ = gpu.gpu_entropy_decode([golden_jpegs.jpeg(name)])
+        assert np.array_equal(coefs[0], golden_jpegs[name + ".quant"]), name
+
+
+def test_gpu_huffman_full_size_and_end_to_end(gpu, orc, synth):
+    """4K 4:2:0 (no DRI) and 8K 4:2:0 with DRI per MCU row (BASELINE config 5): scan
+    decoded on the GPU, then the fused RGB kernel; equal to the oracle's whole decode."""
+    import ctypes as C
+    for w, h, ri in ((3840, 2160, 0), (7680, 4320, -1)):
+        data = synth.synthetic_jpeg(w, h, "420", quality=90, restart_interval=ri, seed=5)
+        hb = gpu.HuffBatch(1, len(data) + 4096)
+        g = hb.prepare([data])
+        stride = (g.coef_shorts * 2 + 255) // 256 * 128
+        d_coef = gpu.DeviceBuffer(stride * 2)
+        d_q = gpu.DeviceBuffer(3 * 64 * 2)
+        d_rgb = gpu.DeviceBuffer(g.rgb_bytes)
+        rounds = hb.decode(d_coef.ptr, stride)
+        assert np.array_equal(d_coef.download(dtype=np.int16)[:g.coef_shorts],
+                              gpu.entropy_decode(data, g))
+        d_q.upload(hb.qtabs())
+        gpu.check(gpu.L.jga_idct_rgb_batch(C.byref(g), 1, d_coef.ptr, stride, d_q.ptr, 1,
+                                           d_rgb.ptr, g.rgb_bytes, None))
+        gpu.check(gpu.L.jga_stream_sync(None))
+        assert np.array_equal(d_rgb.download(), orc.decode_rgb(data)[1].reshape(-1))
+        assert 1 <= rounds < 64
+        hb.close()
+        for b in (d_coef, d_q, d_rgb):
+            b.free()
+
+
+def test_gpu_huffman_rejects_truncated_scan(gpu, synth):
+    data = synth.synthetic_jpeg(320, 200, "420", seed=3)
+    with pytest.raises(gpu.JgaError):
+        gpu.gpu_entropy_decode([data[:len(data) // 2]])

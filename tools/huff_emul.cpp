@@ -1,0 +1,112 @@
+// huff_emul.cpp — CPU emulation of the GPU entropy stage (test infrastructure).
+// Runs the SAME host+device core (csrc/huff_common.h) and the same pass structure
+// as csrc/huff_kernels.hip, one "lane" at a time, so that the synchronisation
+// algorithm can be validated on a machine without a GPU (tests/test_huff_emul.py).
+// Built into tools/bin/libhuff_emul.so by the test; never part of the product library.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../jpeg_gpu_amd/csrc/huff_prepare.h"
+
+static const int DEZZ_INIT = 0;
+static int DEZZ[64];
+static void init_dezz() {
+  int k = 0;
+  for (int s = 0; s < 15; s++) for (int i = 0; i <= s; i++) {
+    int r = (s & 1) ? i : s - i, c = s - r;
+    if (r < 8 && c < 8) DEZZ[k++] = r*8 + c;
+  }
+}
+
+struct write_sink {
+  const hj_image *im; const hj_segment *seg; short *coef; uint32_t b0, total; int16_t pred[3];
+  int64_t off; bool ok;
+  void block_begin(uint32_t n, int c) {
+    const uint32_t b = b0 + n;
+    ok = b < total;
+    if (ok) off = hj_block_offset(*im, seg->mcu0 + b/(uint32_t)im->nslots, c);
+  }
+  void dc(int comp, int v) { pred[comp] = (int16_t)(pred[comp] + v); if (ok) coef[off] = pred[comp]; }
+  void ac(int k, int v) { if (ok) coef[off + DEZZ[k]] = (short)v; }
+};
+
+extern "C" __attribute__((visibility("default")))
+int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long coef_shorts,
+ int jacobi, int *rounds_out, int *nsub_out, long long *runs_out) {
+  hj_prepared P;
+  (void)DEZZ_INIT;
+  if (hj_prepare_image(jpeg, size, &P) != EXIT_SUCCESS) return 1;
+  if (coef_shorts < P.geom.coef_shorts) return 2;
+  init_dezz();
+  const uint16_t *fast[6];
+  for (int i = 0; i < 6; i++) fast[i] = P.tabs[i].fast;
+  const uint32_t nsub = P.im.nsub;
+  std::vector<uint64_t> S(nsub + P.segs.size()), last_in(nsub, ~0ull);
+  std::vector<hj_run> R(nsub);
+  std::vector<uint32_t> sub_seg(nsub);
+  // initial states: true start for lane 0 of each segment, guesses elsewhere
+  for (size_t si = 0; si < P.segs.size(); si++) {
+    const hj_segment &sg = P.segs[si];
+    for (uint32_t i = 0; i < sg.nsub; i++) {
+      sub_seg[sg.sub0 + i] = (uint32_t)si;
+      uint32_t byte = sg.start + i*HJ_SUB_BYTES;
+      if (i > 0 && byte < sg.end && P.scan[byte] == 0x00 && P.scan[byte - 1] == 0xFF) byte++;
+      S[sg.sub0 + si + i] = hj_pack((uint64_t)byte*8, 0, 0);
+    }
+    S[sg.sub0 + si + sg.nsub] = 0;
+  }
+  int rounds = 0;
+  long long runs = 0;
+  for (;;) {
+    bool ran = false;
+    // jacobi: every lane of a round reads the states as they were when the round
+    // began (what a GPU launch does at worst); otherwise lanes see earlier lanes' updates
+    std::vector<uint64_t> snap;
+    if (jacobi) snap = S;
+    for (uint32_t g = 0; g < nsub; g++) {                 // "lanes"
+      const uint32_t si = sub_seg[g];
+      const hj_segment &sg = P.segs[si];
+      const uint32_t i = g - sg.sub0;
+      const uint64_t start = jacobi ? snap[g + si] : S[g + si];
+      if (start == last_in[g]) continue;
+      uint32_t stop_byte = sg.start + (i + 1)*HJ_SUB_BYTES;
+      if (stop_byte > sg.end) stop_byte = sg.end;
+      hj_null_sink ns;
+      R[g] = hj_decode(P.scan, sg.end, P.im, P.tabs, fast, start, (uint64_t)stop_byte*8, 0xFFFFFFFFu, ns);
+      last_in[g] = start;
+      if (i + 1 < sg.nsub) S[g + si + 1] = R[g].end_state;
+      ran = true;
+      runs++;
+    }
+    if (!ran) break;
+    rounds++;
+    if (rounds > (int)nsub + 4) return 3;
+  }
+  // per-segment exclusive prefix sums + write pass
+  for (size_t si = 0; si < P.segs.size(); si++) {
+    const hj_segment &sg = P.segs[si];
+    uint32_t b = 0;
+    int16_t dc[3] = {0, 0, 0};
+    const uint32_t total = sg.nmcu*(uint32_t)P.im.nslots;
+    for (uint32_t i = 0; i < sg.nsub; i++) {
+      const uint32_t g = sg.sub0 + i;
+      const uint64_t start = S[g + si];
+      if (hj_slot(start) != (int)(b % (uint32_t)P.im.nslots) && b < total) return 4;
+      write_sink ws;
+      ws.off = 0; ws.ok = false;
+      ws.im = &P.im; ws.seg = &sg; ws.coef = coef; ws.b0 = b; ws.total = total;
+      ws.pred[0] = dc[0]; ws.pred[1] = dc[1]; ws.pred[2] = dc[2];
+      const uint64_t stop = i + 1 < sg.nsub ? hj_pos(S[g + si + 1]) : (uint64_t)sg.end*8;
+      hj_run r = hj_decode(P.scan, sg.end, P.im, P.tabs, fast, start, stop,
+       b < total ? total - b : 0, ws);
+      if (r.error && b < total) return 5;
+      b += R[g].nblocks;
+      for (int c = 0; c < 3; c++) dc[c] = (int16_t)(dc[c] + R[g].dcsum[c]);
+    }
+    if (b < total) return 6;
+  }
+  if (rounds_out) *rounds_out = rounds;
+  if (nsub_out) *nsub_out = (int)nsub;
+  if (runs_out) *runs_out = runs;
+  return 0;
+}
