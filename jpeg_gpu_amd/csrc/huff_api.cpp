@@ -7,8 +7,11 @@
 //   rounds until no lane moves, per-segment prefix sums, scatter pass.  The output is
 //   the same packed QUANT-stage buffer jga_entropy_decode() produces on the host.
 #include <hip/hip_runtime_api.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "huff_kernels.h"
 #include "huff_prepare.h"
@@ -52,7 +55,7 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   b->sub_cap = (size_t)(max_scan_bytes/HJ_SUB_BYTES) + (size_t)max_images*4096 + 1024;
   const size_t seg_cap = b->sub_cap;   // worst case one segment per subsequence
   b->blob_cap = align_up(sizeof(hj_image)*max_images, 256) + align_up(sizeof(hj_segment)*seg_cap, 256)
-   + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_table)*6*max_images, 256)
+   + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_tables)*max_images, 256)
    + align_up(8*(b->sub_cap + seg_cap), 256) + align_up((size_t)max_scan_bytes + 64*max_images, 256);
   bool ok = hipHostMalloc((void **)&b->h_blob, b->blob_cap, hipHostMallocDefault) == hipSuccess
    && hipMalloc((void **)&b->d_blob, b->blob_cap) == hipSuccess
@@ -92,8 +95,27 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   std::vector<hj_prepared> prep((size_t)n);
   size_t total_sub = 0, total_seg = 0, total_scan = 0;
   uint32_t max_nsub = 0;
+  {
+    // per-image host work (marker parse, table build, unstuffing) is independent: fan out
+    std::atomic<int> next(0), failed(0);
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? hw : 4);
+    if (nt > n) nt = n;
+    if (nt > 64) nt = 64;
+    auto work = [&]() {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) break;
+        if (hj_prepare_image(jpegs[i], sizes[i], &prep[i]) != EXIT_SUCCESS) failed.fetch_add(1);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
+  }
   for (int i = 0; i < n; i++) {
-    if (hj_prepare_image(jpegs[i], sizes[i], &prep[i]) != EXIT_SUCCESS) return EXIT_FAILURE;
     if (i && (prep[i].geom.coef_shorts != prep[0].geom.coef_shorts
      || prep[i].geom.width != prep[0].geom.width || prep[i].geom.height != prep[0].geom.height
      || prep[i].geom.subsamp != prep[0].geom.subsamp)) {
@@ -116,14 +138,14 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   b->off_images = o; o += align_up(sizeof(hj_image)*n, 256);
   b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
   b->off_subseg = o; o += align_up(4*total_sub, 256);
-  b->off_tables = o; o += align_up(sizeof(hj_table)*6*n, 256);
+  b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
   b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
   b->off_scan = o; o += align_up(total_scan, 256);
   b->blob_size = o;
   hj_image *images = (hj_image *)(b->h_blob + b->off_images);
   hj_segment *segs = (hj_segment *)(b->h_blob + b->off_segs);
   uint32_t *sub_seg = (uint32_t *)(b->h_blob + b->off_subseg);
-  hj_table *tables = (hj_table *)(b->h_blob + b->off_tables);
+  hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
   uint64_t *S = (uint64_t *)(b->h_blob + b->off_S);
   unsigned char *scan = b->h_blob + b->off_scan;
   b->qtab.assign((size_t)n*192, 0);
@@ -134,17 +156,16 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
     p.im.seg0 = seg0;
     p.im.scan_off = scan_off;
     images[i] = p.im;
-    memcpy(tables + 6*i, p.tabs, sizeof(p.tabs));
+    tables[i] = p.tabs;
     memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
-    memcpy(scan + scan_off, p.scan, p.scan_len);
+    memcpy(scan + scan_off, p.clean.data(), p.scan_len);
     memset(scan + scan_off + p.scan_len, 0xFF, align_up(p.scan_len + 16, 16) - p.scan_len);
     for (size_t si = 0; si < p.segs.size(); si++) {
       const hj_segment &sg = p.segs[si];
       segs[seg0 + si] = sg;
       for (uint32_t k = 0; k < sg.nsub; k++) {
         sub_seg[sub0 + sg.sub0 + k] = (uint32_t)si;
-        uint32_t byte = sg.start + k*HJ_SUB_BYTES;       // guess: a symbol starts on this byte
-        if (k > 0 && byte < sg.end && p.scan[byte] == 0x00 && p.scan[byte - 1] == 0xFF) byte++;
+        const uint32_t byte = sg.start + k*HJ_SUB_BYTES; // guess: a symbol starts on this byte
         S[sub0 + seg0 + sg.sub0 + si + k] = hj_pack((uint64_t)byte*8, 0, 0);
       }
       S[sub0 + seg0 + sg.sub0 + si + sg.nsub] = 0;
@@ -164,6 +185,15 @@ JGA_EXPORT int jga_huff_last_rounds(const jga_huff_batch *b) { return b->last_ro
 // Quantisation tables of the prepared batch: nimages*3*64 uint16 (host memory).
 JGA_EXPORT const unsigned short *jga_huff_qtabs(const jga_huff_batch *b) { return b->qtab.data(); }
 
+// Debug/test hook: copy the lane start states (nsub + nseg entries per image) to the host.
+JGA_EXPORT long long jga_huff_debug_states(jga_huff_batch *b, unsigned long long *out, long long cap) {
+  const long long n = (long long)b->total_sub + b->total_seg;
+  if (out && cap >= n) {
+    if (hipMemcpy(out, b->d_blob + b->off_S, 8*(size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  }
+  return n;
+}
+
 // Decode the prepared batch into d_coef (image i at d_coef + i*coef_stride shorts).
 // May be called repeatedly on the same prepared batch (state is reset each time).
 JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
@@ -176,7 +206,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   A.images = (const hj_image *)(b->d_blob + b->off_images);
   A.segs = (const hj_segment *)(b->d_blob + b->off_segs);
   A.sub_seg = (const uint32_t *)(b->d_blob + b->off_subseg);
-  A.tables = (const hj_table *)(b->d_blob + b->off_tables);
+  A.tables = (const hj_tables *)(b->d_blob + b->off_tables);
   A.scan = b->d_blob + b->off_scan;
   A.S = (uint64_t *)(b->d_blob + b->off_S);
   A.last_in = b->d_last_in;
@@ -196,10 +226,16 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
   HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, st));
   int round = 0;
-  const int GROUP = 8;
+  static int it0 = -1, it1 = -1, group = -1;
+  if (it0 < 0) {
+    const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group" (tuning knob)
+    it0 = 3; it1 = 2; group = 6;
+    if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
+  }
+  const int GROUP = group;
   for (;;) {
     for (int k = 0; k < GROUP && round < HJ_MAX_ROUNDS; k++, round++) {
-      if (hj_launch_round(&A, (int)b->max_nsub, round, st)) return jga_fail("huff: launch failed");
+      if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, st)) return jga_fail("huff: launch failed");
     }
     HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
     HOK(hipStreamSynchronize(st));

@@ -37,18 +37,22 @@
 #define HJ_SUB_BYTES 128          /* subsequence length in raw scan bytes */
 #define HJ_MAX_SLOTS 10           /* blocks per MCU (4:1:1 / 4:2:0 = 6) */
 
-// One Huffman table in device form.
-struct hj_table {
-  uint16_t fast[1 << HJ_FAST_BITS];  // (len << 8) | symbol; 0 = code longer than FAST_BITS
-  uint32_t maxcode[18];              // left-aligned 16-bit exclusive bounds per length
-  int32_t delta[17];                 // symbol index = code + delta[len]
-  uint8_t sym[256];
+// The Huffman tables of one image in device form: a two-level lookup that never
+// leaves LDS.  Level 1 is indexed by the next 9 bits: (len << 8) | symbol for codes
+// of up to 9 bits, or 0x8000 | n for a longer code whose remaining bits select an
+// entry of level-2 block n (128 entries, indexed by bits 9..15): (len << 8) | symbol
+// again, 0 for bit patterns that are no code.  With SIMT divergence a rarely taken
+// slow path is taken by every wave, so it has to be as cheap as the fast one.
+#define HJ_L2_BLOCKS 16
+struct hj_tables {
+  uint16_t l1[6][1 << HJ_FAST_BITS];   // [2*comp] = DC, [2*comp + 1] = AC of that component
+  uint16_t l2[HJ_L2_BLOCKS*128];
 };
 
 // Everything a lane needs to know about one image.
 struct hj_image {
-  uint32_t scan_off;                 // offset of this image's scan bytes in the batch buffer
-  uint32_t scan_len;
+  uint32_t scan_off;                 // offset of this image's clean scan bytes in the batch buffer
+  uint32_t scan_len;                 // clean length
   uint32_t sub0;                     // first subsequence (batch-global index)
   uint32_t nsub;
   uint32_t seg0;                     // first segment (batch-global index)
@@ -66,14 +70,14 @@ struct hj_image {
 };
 
 struct hj_segment {                  // one restart interval (or the whole scan)
-  uint32_t start, end;               // raw byte range inside the image's scan
+  uint32_t start, end;               // byte range inside the image's CLEAN scan (unstuffed, marker-free)
   uint32_t sub0;                     // first subsequence, image-local index
   uint32_t nsub;
   uint32_t mcu0;                     // first MCU of the interval
   uint32_t nmcu;
 };
 
-// state word: p (bit position, raw coordinates inside the image's scan) << 16 | c << 8 | k
+// state word: p (bit position inside the image's clean scan) << 16 | c << 8 | k
 HJ_HD uint64_t hj_pack(uint64_t p, int c, int k) { return (p << 16) | ((uint64_t)c << 8) | (uint64_t)k; }
 HJ_HD uint64_t hj_pos(uint64_t s) { return s >> 16; }
 HJ_HD int hj_slot(uint64_t s) { return (int)((s >> 8) & 255); }
@@ -87,131 +91,157 @@ struct hj_run {
   uint16_t error;                    // coefficient index ran past 63 / bad code
 };
 
-// MSB-first bit reader over the raw scan bytes: unstuffs FF 00 on the fly, keeps
-// enough bookkeeping to report the RAW position of the next unread bit.
-struct hj_reader {
+// Bit source over plain memory (host emulation): 32 bits, MSB first, starting at bit p.
+struct hj_mem_src {
   const uint8_t *s;
-  uint32_t pos, end;                 // next raw byte to load / end of the segment
-  uint64_t bits;                     // MSB-aligned window
-  int nbits;
-  uint32_t skipped;                  // bit j set: the j-th most recent byte was followed by a skipped 00
-
-  HJ_HD void refill() {
-    while (nbits <= 56) {
-      uint32_t b = 0xFF;             // beyond the segment: padding ones, position keeps counting
-      uint32_t skip = 0;
-      if (pos < end) {
-        b = s[pos];
-        if (b == 0xFF && pos + 1 < end && s[pos + 1] == 0x00) skip = 1;
-      }
-      pos += 1 + skip;
-      skipped = (skipped << 1) | skip;
-      bits |= (uint64_t)b << (56 - nbits);
-      nbits += 8;
-    }
+  HJ_HD uint32_t window32(uint32_t p) const {
+    const uint8_t *b = s + (p >> 3);
+    const uint64_t v = ((uint64_t)b[0] << 32) | ((uint64_t)b[1] << 24) | ((uint64_t)b[2] << 16)
+     | ((uint64_t)b[3] << 8) | (uint64_t)b[4];
+    return (uint32_t)(v >> (8 - (p & 7)));
   }
-  HJ_HD void init(const uint8_t *scan, uint32_t seg_end, uint64_t p) {
-    s = scan;
-    end = seg_end;
-    pos = (uint32_t)(p >> 3);
-    bits = 0;
-    nbits = 0;
-    skipped = 0;
-    refill();
-    const int skip = (int)(p & 7);
-    bits <<= skip;
-    nbits -= skip;
-  }
-  // raw bit position of the next unread bit
-  HJ_HD uint64_t tell() const {
-    const int nb = (nbits + 7) >> 3;                       // unread (incl. partly read) bytes
-    const uint32_t sk = skipped & ((1u << nb) - 1u);
-    const uint32_t byte = pos - (uint32_t)nb - (uint32_t)__builtin_popcount(sk);
-    return ((uint64_t)byte << 3) + (uint64_t)(8*nb - nbits);
-  }
-  HJ_HD uint32_t peek(int n) const { return (uint32_t)(bits >> (64 - n)); }
-  HJ_HD void skip(int n) { bits <<= n; nbits -= n; }
 };
 
-HJ_HD int hj_symbol(hj_reader &br, const hj_table *t, const uint16_t *fast) {
-  const uint32_t e = fast[br.peek(HJ_FAST_BITS)];
-  if (e) {
-    br.skip((int)(e >> 8));
-    return (int)(e & 255);
-  }
-  const uint32_t code = br.peek(16);
-  int len = HJ_FAST_BITS + 1;
-  while (len <= 16 && code >= t->maxcode[len]) len++;
-  if (len > 16) {                    // not a code (only reachable from a wrong guess / bad data)
-    br.skip(16);
-    return 0;
-  }
-  br.skip(len);
-  return t->sym[((int)(code >> (16 - len)) + t->delta[len]) & 255];
+// Bit reader over the CLEAN scan bytes of an image: byte stuffing (FF 00) and
+// restart markers were removed when the batch was prepared, so a position is
+// simply a bit count.  It is STATELESS apart from that position: every symbol
+// fetches its own 32-bit window (a code is <= 16 bits, its magnitude <= 15), which
+// on the GPU is one two-dword LDS read and a funnel shift — no refill branch and no
+// 64-bit buffer to keep in step across divergent lanes.  Segments are byte aligned
+// and lie back to back; bits past the end of a segment are never part of a block
+// that gets written.
+template <class Src>
+struct hj_reader {
+  Src src;
+  uint32_t p;                        // bit position in the image's clean scan
+  HJ_HD void init(const Src &source, uint64_t pos) { src = source; p = (uint32_t)pos; }
+  HJ_HD uint32_t window() const { return src.window32(p); }
+  HJ_HD void skip(int n) { p += (uint32_t)n; }
+  HJ_HD uint64_t tell() const { return p; }
+};
+
+// Look up the symbol at the top of window `w` in table `ti`: returns (len << 8) | symbol
+// (len = 16, symbol = 0 for a bit pattern that is no code).
+HJ_HD uint32_t hj_lookup(const hj_tables *T, int ti, uint32_t w) {
+  uint32_t e = T->l1[ti][w >> (32 - HJ_FAST_BITS)];
+  if (e & 0x8000u) e = T->l2[((e & 0x7fffu) << 7) | ((w >> 16) & 127u)];
+  return e ? e : (16u << 8);
 }
 
-HJ_HD int hj_extend(hj_reader &br, int s) {
-  int v = (int)br.peek(s);
-  br.skip(s);
-  if (v < (1 << (s - 1))) v -= (1 << s) - 1;
-  return v;
+// The `s` magnitude bits that follow a `len`-bit code in window `w`, extended (T.81 F.2.2.1).
+HJ_HD int hj_value(uint32_t w, int len, int s) {
+  if (!s) return 0;
+  const int v = (int)((w << len) >> (32 - s));
+  return v - ((v >> (s - 1)) ? 0 : (1 << s) - 1);
 }
 
 // A sink receives decoded values; the sync/count passes use hj_null_sink.
 struct hj_null_sink {
-  HJ_HD void block_begin(uint32_t, int) {}
+  HJ_HD void block_begin(uint32_t, int, int) {}
   HJ_HD void dc(int, int) {}
   HJ_HD void ac(int, int) {}
+  HJ_HD void finish(int) {}
 };
 
 // Decode from `start` until the first symbol boundary whose raw bit position is
 // >= stop_bit (or until max_blocks blocks are complete).  `tabs[2*comp]`/`[2*comp+1]`
 // and the matching `fast` arrays (possibly LDS copies) are the DC/AC tables.
-template <class Sink>
-HJ_HD hj_run hj_decode(const uint8_t *scan, uint32_t seg_end, const hj_image &im,
- const hj_table *tabs, const uint16_t *const *fast, uint64_t start,
- uint64_t stop_bit, uint32_t max_blocks, Sink &sink) {
-  hj_reader br;
+// Sink protocol: block_begin(n, slot, k) when the run's n-th block becomes current
+// (k != 0 only for n == 0: a block some earlier lane began), dc()/ac() for its
+// values, finish(k) at the end of the run (k != 0: the current block is incomplete).
+// `T` = the image's tables (an LDS copy on the GPU); `slot_comp_bits` = component of
+// MCU slot c in bits [2c, 2c+1] (keeps the per-symbol lookups free of indexed
+// private arrays, which would live in scratch).
+template <class Src, class Sink>
+HJ_HD hj_run hj_decode(const Src &src, const hj_image &im, const hj_tables *T,
+ uint64_t start, uint64_t stop_bit, uint32_t max_blocks, Sink &sink) {
+  uint32_t slot_comp_bits = 0;
+  for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+  const int nslots = im.nslots;
+  hj_reader<Src> br;
   hj_run r;
   int k = hj_k(start), c = hj_slot(start);
+  int dc0 = 0, dc1 = 0, dc2 = 0;     // scalars, not an indexed array (would live in scratch)
   r.nblocks = 0;
-  r.dcsum[0] = r.dcsum[1] = r.dcsum[2] = 0;
   r.error = 0;
-  br.init(scan, seg_end, hj_pos(start));
-  const uint32_t stop_byte = (uint32_t)(stop_bit >> 3);
-  sink.block_begin(0, c);            // block 0 of this run may be one a previous lane began
-  for (;;) {
-    // exact position check only when the window may reach the stop byte
-    if (br.pos >= stop_byte && br.tell() >= stop_bit) break;
-    if (r.nblocks >= max_blocks) break;
-    br.refill();
-    const int comp = im.slot_comp[c];
+  br.init(src, hj_pos(start));
+  sink.block_begin(0, c, k);         // block 0 of this run may be one a previous lane began
+  int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+  while (br.tell() < stop_bit && r.nblocks < max_blocks) {
+    const uint32_t w = br.window();
+    const uint32_t e = hj_lookup(T, 2*comp + (k != 0), w);  // DC table for k == 0, else AC
+    const int len = (int)(e >> 8), rs = (int)(e & 255u), s = rs & 15;
+    const int v = hj_value(w, len, s);
+    br.skip(len + s);
     if (k == 0) {
-      const int s = hj_symbol(br, &tabs[2*comp], fast[2*comp]) & 15;
-      const int v = s ? hj_extend(br, s) : 0;
-      r.dcsum[comp] = (int16_t)(r.dcsum[comp] + v);
+      dc0 += comp == 0 ? v : 0;
+      dc1 += comp == 1 ? v : 0;
+      dc2 += comp == 2 ? v : 0;
       sink.dc(comp, v);
       k = 1;
     }
+    else if (rs == 0) k = 64;                               // EOB
     else {
-      const int rs = hj_symbol(br, &tabs[2*comp + 1], fast[2*comp + 1]);
-      if (rs == 0) k = 64;                                   // EOB
-      else {
-        const int s = rs & 15;
-        k += rs >> 4;
-        const int v = s ? hj_extend(br, s) : 0;
-        if (k > 63) { r.error = 1; k = 63; }
-        else if (s) sink.ac(k, v);
-        k++;
-      }
+      k += rs >> 4;
+      if (k > 63) { r.error = 1; k = 63; }
+      else if (s) sink.ac(k, v);
+      k++;
     }
     if (k >= 64) {
       r.nblocks++;
-      c = c + 1 == im.nslots ? 0 : c + 1;
+      c = c + 1 == nslots ? 0 : c + 1;
+      comp = (int)((slot_comp_bits >> (2*c)) & 3u);
       k = 0;
-      sink.block_begin(r.nblocks, c);
+      sink.block_begin(r.nblocks, c, 0);
     }
   }
+  sink.finish(k);
+  r.dcsum[0] = (int16_t)dc0; r.dcsum[1] = (int16_t)dc1; r.dcsum[2] = (int16_t)dc2;
+  r.end_state = hj_pack(br.tell(), c, k);
+  return r;
+}
+
+// Lean, branch-light variant of hj_decode for the synchronisation rounds: same
+// trajectory and the same hj_run (end state, block count, DC sums), no sink, no
+// coefficient values except the DC differences.  Every lane of a wave executes
+// every instruction of a divergent loop, so the per-symbol instruction count is
+// what the rounds cost.
+template <class Src>
+HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables *T,
+ uint64_t start, uint64_t stop_bit) {
+  uint32_t slot_comp_bits = 0;
+  for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+  const int nslots = im.nslots;
+  hj_reader<Src> br;
+  hj_run r;
+  int k = hj_k(start), c = hj_slot(start);
+  int dc0 = 0, dc1 = 0, dc2 = 0;
+  uint32_t nblocks = 0;
+  br.init(src, hj_pos(start));
+  int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+  while (br.tell() < stop_bit) {
+    const uint32_t w = br.window();
+    const int isdc = k == 0;
+    const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
+    const int len = (int)(e >> 8), sym = (int)(e & 255u), s = sym & 15;
+    br.skip(len + s);
+    if (isdc) {                                            // DC difference, extended
+      const int v = hj_value(w, len, s);
+      dc0 += comp == 0 ? v : 0;
+      dc1 += comp == 1 ? v : 0;
+      dc2 += comp == 2 ? v : 0;
+    }
+    int kn = sym ? k + (sym >> 4) + 1 : 64;                // AC: run, then the coefficient; EOB
+    kn = isdc ? 1 : kn;
+    const int done = kn >= 64;
+    nblocks += (uint32_t)done;
+    c = done ? (c + 1 == nslots ? 0 : c + 1) : c;
+    comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+    k = done ? 0 : kn;
+  }
+  r.nblocks = nblocks;
+  r.error = 0;
+  r.dcsum[0] = (int16_t)dc0; r.dcsum[1] = (int16_t)dc1; r.dcsum[2] = (int16_t)dc2;
   r.end_state = hj_pack(br.tell(), c, k);
   return r;
 }

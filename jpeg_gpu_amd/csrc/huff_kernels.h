@@ -9,7 +9,7 @@ typedef struct hj_args {
   const hj_image *images;      /* [nimages] */
   const hj_segment *segs;      /* all images' segments, image-major */
   const uint32_t *sub_seg;     /* per subsequence: segment index local to its image */
-  const hj_table *tables;      /* [nimages*6] */
+  const hj_tables *tables;     /* [nimages] */
   const uint8_t *scan;         /* all images' entropy-coded bytes */
   uint64_t *S;                 /* states: nsub + nseg entries per image */
   uint64_t *last_in;           /* start state of each lane's latest run */
@@ -26,7 +26,7 @@ typedef struct hj_args {
 #ifdef __cplusplus
 extern "C" {
 #endif
-int hj_launch_round(const hj_args *A, int max_nsub, int round, void *stream);
+int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, void *stream);
 int hj_launch_write(const hj_args *A, int max_nsub, void *stream);
 #ifdef __cplusplus

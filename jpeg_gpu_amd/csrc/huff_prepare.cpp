@@ -6,35 +6,36 @@
 #include <string.h>
 #include "huff_prepare.h"
 
-static int build_table(hj_table *t, const unsigned char bits[16], const unsigned char *vals) {
+// Build the two-level lookup of one table into T->l1[ti] (+ level-2 blocks taken
+// from *l2_used).  Returns 0, 1 = malformed DHT, 2 = out of level-2 blocks.
+static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char bits[16],
+ const unsigned char *vals) {
   unsigned code = 0;
   int k = 0;
-  unsigned char size[256];
-  unsigned short codes[256];
-  memset(t, 0, sizeof(*t));
+  uint16_t *l1 = T->l1[ti];
+  memset(l1, 0, sizeof(T->l1[ti]));
   for (int len = 1; len <= 16; len++) {
-    for (int i = 0; i < bits[len - 1]; i++) {
-      if (k >= 256) return 1;
-      size[k] = (unsigned char)len;
-      codes[k] = (unsigned short)code;
-      t->sym[k] = vals[k];
-      k++;
-      code++;
-    }
-    if (code > (1u << len)) return 1;
-    t->delta[len] = k - (int)code;
-    t->maxcode[len] = code << (16 - len);
-    code <<= 1;
-  }
-  t->maxcode[17] = 0xFFFFFFFFu;
-  for (int i = 0; i < k; i++) {
-    const int s = size[i];
-    if (s <= HJ_FAST_BITS) {
-      const unsigned c = (unsigned)codes[i] << (HJ_FAST_BITS - s);
-      for (unsigned j = 0; j < (1u << (HJ_FAST_BITS - s)); j++) {
-        t->fast[c + j] = (uint16_t)((s << 8) | t->sym[i]);
+    for (int i = 0; i < bits[len - 1]; i++, k++, code++) {
+      if (k >= 256 || code >= (1u << len)) return 1;
+      const uint16_t entry = (uint16_t)((len << 8) | vals[k]);
+      if (len <= HJ_FAST_BITS) {
+        const unsigned c = code << (HJ_FAST_BITS - len);
+        for (unsigned j = 0; j < (1u << (HJ_FAST_BITS - len)); j++) l1[c + j] = entry;
+      }
+      else {
+        const unsigned prefix = code >> (len - HJ_FAST_BITS);
+        if (!(l1[prefix] & 0x8000u)) {
+          if (l1[prefix]) return 1;                       // prefix of a shorter code: not prefix-free
+          if (*l2_used >= HJ_L2_BLOCKS) return 2;
+          memset(T->l2 + 128*(*l2_used), 0, 256);
+          l1[prefix] = (uint16_t)(0x8000u | (unsigned)(*l2_used)++);
+        }
+        uint16_t *blk = T->l2 + 128*(l1[prefix] & 0x7fffu);
+        const unsigned c = (code & ((1u << (len - HJ_FAST_BITS)) - 1u)) << (16 - len);
+        for (unsigned j = 0; j < (1u << (16 - len)); j++) blk[c + j] = entry;
       }
     }
+    code <<= 1;
   }
   return 0;
 }
@@ -50,7 +51,8 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
   const jga_geom &g = out->geom;
   hj_image &im = out->im;
   memset(&im, 0, sizeof(im));
-  int slot = 0;
+  int slot = 0, l2_used = 0;
+  memset(&out->tabs, 0, sizeof(out->tabs));
   for (int c = 0; c < g.nplanes; c++) {
     const jpeg_component &cp = d->header.comp[c];
     im.comp_hs[c] = (uint8_t)cp.hsamp;
@@ -66,10 +68,21 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
         slot++;
       }
     }
-    if (build_table(&out->tabs[2*c], d->dht_bits[d->td[c]], d->dht_vals[d->td[c]])
-     || build_table(&out->tabs[2*c + 1], d->dht_bits[4 + d->ta[c]], d->dht_vals[4 + d->ta[c]])) {
-      free(d);
-      return jga_fail("Error invalid DHT.");
+    {
+      // components that select the same DHT (Cb/Cr usually do) share its level-2 blocks
+      int rc = 0;
+      for (int w = 0; w < 2 && !rc; w++) {
+        const int id = w ? 4 + d->ta[c] : d->td[c];
+        int same = -1;
+        for (int pc = 0; pc < c; pc++) if ((w ? 4 + d->ta[pc] : d->td[pc]) == id) same = pc;
+        if (same >= 0) memcpy(out->tabs.l1[2*c + w], out->tabs.l1[2*same + w], sizeof(out->tabs.l1[0]));
+        else rc = build_table(&out->tabs, 2*c + w, &l2_used, d->dht_bits[id], d->dht_vals[id]);
+      }
+      if (rc) {
+        free(d);
+        return jga_fail(rc == 2 ? "Huffman table too irregular for the GPU entropy stage"
+         : "Error invalid DHT.");
+      }
     }
     memcpy(out->qtab + 64*c, cp.quant->tbl, 64*sizeof(unsigned short));
   }
@@ -78,26 +91,29 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
   im.nhmb = g.nhmb;
   im.w0_blocks = g.w0/8;
 
-  // entropy-coded bytes: split at RSTn markers, stop at the first other marker
+  // entropy-coded bytes: split at RSTn markers, stop at the first other marker; copy
+  // them into a clean stream (stuffed zeros and markers dropped) as we go
   const unsigned char *scan = jpeg + d->scan_off;
   const uint32_t avail = (uint32_t)(size - d->scan_off);
   const uint32_t total_mcus = (uint32_t)g.nhmb*(uint32_t)g.nvmb;
   const uint32_t ri = (uint32_t)d->header.restart_interval;
-  out->scan = scan;
   out->segs.clear();
-  uint32_t seg_start = 0, pos = 0, mcu0 = 0, nsub = 0;
+  out->clean.clear();
+  out->clean.reserve(avail + 32);
+  uint32_t pos = 0, mcu0 = 0, nsub = 0, clean_start = 0;
   int expect = 0;
   bool done = false;
   while (!done) {
     const unsigned char *ff = pos < avail ? (const unsigned char *)memchr(scan + pos, 0xFF, avail - pos) : NULL;
-    uint32_t at = ff ? (uint32_t)(ff - scan) : avail;
-    int marker = (ff && at + 1 < avail) ? scan[at + 1] : 0xD9;     // running off the end == EOI
-    if (ff && marker == 0x00) { pos = at + 2; continue; }          // stuffed zero
-    if (ff && marker == 0xFF) { pos = at + 1; continue; }          // fill byte
+    const uint32_t at = ff ? (uint32_t)(ff - scan) : avail;
+    const int marker = (ff && at + 1 < avail) ? scan[at + 1] : 0xD9;   // running off the end == EOI
+    out->clean.insert(out->clean.end(), scan + pos, scan + at);
+    if (ff && marker == 0x00) { out->clean.push_back(0xFF); pos = at + 2; continue; }   // stuffed zero
+    if (ff && marker == 0xFF) { pos = at + 1; continue; }               // fill byte
     // a real marker (or the end of the buffer) closes the current segment
     hj_segment s;
-    s.start = seg_start;
-    s.end = at;
+    s.start = clean_start;
+    s.end = (uint32_t)out->clean.size();
     s.sub0 = nsub;
     s.nsub = (s.end - s.start + HJ_SUB_BYTES - 1)/HJ_SUB_BYTES;
     if (s.nsub == 0) s.nsub = 1;
@@ -106,14 +122,17 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
     out->segs.push_back(s);
     nsub += s.nsub;
     mcu0 += s.nmcu;
+    out->raw_len = at;
     if (marker >= 0xD0 && marker <= 0xD7 && ri && mcu0 < total_mcus) {
       if (marker != 0xD0 + (expect & 7)) { free(d); return jga_fail("Error invalid RST counter in marker."); }
       expect++;
-      seg_start = pos = at + 2;
+      pos = at + 2;
+      clean_start = s.end;
     }
     else done = true;
-    out->scan_len = at;
   }
+  out->scan_len = (uint32_t)out->clean.size();
+  out->clean.insert(out->clean.end(), 16, (unsigned char)0xFF);
   free(d);
   if (mcu0 != total_mcus) return jga_fail("Error, entropy data ended early.");
   im.nsub = nsub;

@@ -10,10 +10,11 @@ struct hj_prepared {
   hj_image im;                      // scan_off / sub0 / seg0 are filled by the batch builder
   jga_geom geom;
   std::vector<hj_segment> segs;
-  hj_table tabs[6];                 // [2*comp] DC, [2*comp+1] AC
+  hj_tables tabs;                   // two-level LUTs, [2*comp] DC, [2*comp+1] AC
   unsigned short qtab[3*64];        // per plane, natural order
-  const unsigned char *scan;        // points into the caller's JPEG bytes
-  uint32_t scan_len;                // entropy-coded bytes incl. RST markers, excl. EOI
+  std::vector<unsigned char> clean; // entropy-coded bytes with FF00 -> FF and RSTn removed, + 16 pad
+  uint32_t scan_len;                // clean length (without the pad)
+  uint32_t raw_len;                 // entropy-coded bytes in the file incl. stuffing and RST markers
 };
 
 // Returns EXIT_SUCCESS / EXIT_FAILURE (message via jga_fail).

@@ -1,0 +1,45 @@
+"""GPU entropy stage benchmark: JPEG bytes resident in HBM -> coefficient planes -> RGB.
+Usage: python tools/hbench.py [W H sampling nimages restart_interval]"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from jpeg_gpu_amd import lib, synth  # noqa: E402
+
+w, h, samp, n, ri = (sys.argv[1:] + [None] * 5)[:5]
+w, h, samp, n, ri = int(w or 3840), int(h or 2160), samp or "420", int(n or 48), int(ri or 0)
+distinct = [synth.synthetic_jpeg(w, h, samp, quality=90, restart_interval=ri, seed=1234 + i)
+            for i in range(min(n, 6))]
+jpegs = [distinct[i % len(distinct)] for i in range(n)]
+hb = lib.HuffBatch(n, sum(map(len, jpegs)) + 4096 * n)
+t0 = time.perf_counter()
+g = hb.prepare(jpegs)
+lib.check(lib.L.jga_stream_sync(None))
+t_prep = time.perf_counter() - t0
+stride = (g.coef_shorts * 2 + 255) // 256 * 128
+ostride = (g.rgb_bytes + 255) // 256 * 256
+d_coef = lib.DeviceBuffer(stride * 2 * n)
+d_q = lib.DeviceBuffer(3 * 64 * 2 * n)
+d_rgb = lib.DeviceBuffer(ostride * n)
+d_q.upload(hb.qtabs())
+for rep in range(3):
+    t0 = time.perf_counter()
+    rounds = hb.decode(d_coef.ptr, stride)
+    t_h = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lib.check(lib.L.jga_idct_rgb_batch(C.byref(g), n, d_coef.ptr, stride, d_q.ptr, 1, d_rgb.ptr,
+                                       ostride, None))
+    lib.check(lib.L.jga_stream_sync(None))
+    t_i = time.perf_counter() - t0
+    mp = n * w * h / 1e6
+    print("%dx%d %s x%d ri=%d: prepare(host parse+H2D %.1f MB) %.1f ms | huffman %.3f ms (%d rounds, "
+          "%.0f Mpix/s) | idct+rgb %.3f ms | device total %.0f Mpix/s" % (
+              w, h, samp, n, ri, hb.upload_bytes() / 1e6, t_prep * 1e3, t_h * 1e3, rounds,
+              mp / t_h, t_i * 1e3, mp / (t_h + t_i)))
+want = lib.entropy_decode(jpegs[0], g)
+got = d_coef.download(g.coef_shorts * 2, dtype=np.int16)
+print("coefficients equal host stage:", bool(np.array_equal(got, want)))

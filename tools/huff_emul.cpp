@@ -21,7 +21,8 @@ static void init_dezz() {
 struct write_sink {
   const hj_image *im; const hj_segment *seg; short *coef; uint32_t b0, total; int16_t pred[3];
   int64_t off; bool ok;
-  void block_begin(uint32_t n, int c) {
+  void finish(int) {}
+  void block_begin(uint32_t n, int c, int) {
     const uint32_t b = b0 + n;
     ok = b < total;
     if (ok) off = hj_block_offset(*im, seg->mcu0 + b/(uint32_t)im->nslots, c);
@@ -38,8 +39,6 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
   if (hj_prepare_image(jpeg, size, &P) != EXIT_SUCCESS) return 1;
   if (coef_shorts < P.geom.coef_shorts) return 2;
   init_dezz();
-  const uint16_t *fast[6];
-  for (int i = 0; i < 6; i++) fast[i] = P.tabs[i].fast;
   const uint32_t nsub = P.im.nsub;
   std::vector<uint64_t> S(nsub + P.segs.size()), last_in(nsub, ~0ull);
   std::vector<hj_run> R(nsub);
@@ -49,8 +48,7 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
     const hj_segment &sg = P.segs[si];
     for (uint32_t i = 0; i < sg.nsub; i++) {
       sub_seg[sg.sub0 + i] = (uint32_t)si;
-      uint32_t byte = sg.start + i*HJ_SUB_BYTES;
-      if (i > 0 && byte < sg.end && P.scan[byte] == 0x00 && P.scan[byte - 1] == 0xFF) byte++;
+      const uint32_t byte = sg.start + i*HJ_SUB_BYTES;
       S[sg.sub0 + si + i] = hj_pack((uint64_t)byte*8, 0, 0);
     }
     S[sg.sub0 + si + sg.nsub] = 0;
@@ -71,8 +69,8 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
       if (start == last_in[g]) continue;
       uint32_t stop_byte = sg.start + (i + 1)*HJ_SUB_BYTES;
       if (stop_byte > sg.end) stop_byte = sg.end;
-      hj_null_sink ns;
-      R[g] = hj_decode(P.scan, sg.end, P.im, P.tabs, fast, start, (uint64_t)stop_byte*8, 0xFFFFFFFFu, ns);
+      hj_mem_src src; src.s = P.clean.data();
+      R[g] = hj_sync_decode(src, P.im, &P.tabs, start, (uint64_t)stop_byte*8);
       last_in[g] = start;
       if (i + 1 < sg.nsub) S[g + si + 1] = R[g].end_state;
       ran = true;
@@ -97,7 +95,8 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
       ws.im = &P.im; ws.seg = &sg; ws.coef = coef; ws.b0 = b; ws.total = total;
       ws.pred[0] = dc[0]; ws.pred[1] = dc[1]; ws.pred[2] = dc[2];
       const uint64_t stop = i + 1 < sg.nsub ? hj_pos(S[g + si + 1]) : (uint64_t)sg.end*8;
-      hj_run r = hj_decode(P.scan, sg.end, P.im, P.tabs, fast, start, stop,
+      hj_mem_src src; src.s = P.clean.data();
+      hj_run r = hj_decode(src, P.im, &P.tabs, start, stop,
        b < total ? total - b : 0, ws);
       if (r.error && b < total) return 5;
       b += R[g].nblocks;
