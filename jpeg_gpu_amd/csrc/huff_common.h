@@ -246,6 +246,57 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
   return r;
 }
 
+// Final pass, lean like hj_sync_decode: every coefficient goes through `out`:
+//   out.put(natural_index, value)       into the lane's block buffer
+//   out.flush(n, slot, complete, head)  the run's n-th block is over: `complete` = its
+//       last coefficient was decoded here, `head` = its first one was too (so the
+//       buffer holds the whole block iff complete && head); the buffer must be
+//       zero again afterwards
+// DC values are integrated from `pred` (predictors at the start of the run).
+template <class Src, class Out>
+HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T,
+ const uint8_t *dezz, uint64_t start, uint64_t stop_bit, uint32_t max_blocks,
+ int pred0, int pred1, int pred2, Out &out) {
+  uint32_t slot_comp_bits = 0;
+  for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+  const int nslots = im.nslots;
+  hj_reader<Src> br;
+  int k = hj_k(start), c = hj_slot(start), error = 0;
+  bool head = k == 0;
+  uint32_t n = 0;
+  br.init(src, hj_pos(start));
+  int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+  while (br.tell() < stop_bit && n < max_blocks) {
+    const uint32_t w = br.window();
+    const int isdc = k == 0;
+    const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
+    const int len = (int)(e >> 8), sym = (int)(e & 255u), s = sym & 15;
+    int v = hj_value(w, len, s);
+    br.skip(len + s);
+    if (isdc) {
+      pred0 += comp == 0 ? v : 0;
+      pred1 += comp == 1 ? v : 0;
+      pred2 += comp == 2 ? v : 0;
+      v = (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);    // wraps like xjpeg.c:480
+    }
+    const int kk = isdc ? 0 : k + (sym >> 4);              // zig-zag index of this coefficient
+    if (kk > 63) error = 1;
+    else if (isdc || s) out.put(dezz[kk], v);
+    const int kn = isdc ? 1 : (sym ? kk + 1 : 64);
+    if (kn >= 64) {
+      out.flush(n, c, true, head);
+      n++;
+      c = c + 1 == nslots ? 0 : c + 1;
+      comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+      k = 0;
+      head = true;
+    }
+    else k = kn;
+  }
+  if (k != 0 && n < max_blocks) out.flush(n, c, false, head);   // a later lane finishes this block
+  return error;
+}
+
 // Offset (shorts) of block `b` of the scan (MCU order) in the image's coefficient buffer:
 // inverse of the MCU loop nest + block placement of src/xjpeg.c:461-472, 556-561.
 HJ_HD int64_t hj_block_offset(const hj_image &im, uint32_t mcu, int slot) {

@@ -19,25 +19,26 @@
 #include "huff_kernels.h"
 
 #define HJ_BLOCK 256
-// staged window: 256 subsequences (segments lie back to back in the clean stream) + look-ahead
-#define HJ_WIN_BYTES (HJ_BLOCK*HJ_SUB_BYTES + 96)
-#define HJ_WIN_DWORDS ((HJ_WIN_BYTES + (HJ_WIN_BYTES >> 7)*4)/4 + 8)
-#define HJ_BLK_STRIDE 36            /* dwords per lane's block buffer (144 B) */
+// staged scan bytes: 256 subsequences x 35 dwords (3 alignment + 128 + look-ahead bytes)
+#define HJ_SUB_DWORDS 35
+#define HJ_SUB_STRIDE 35            /* odd: lanes walking their own copies hit different banks */
+#define HJ_WIN_DWORDS (HJ_BLOCK*HJ_SUB_STRIDE + 8)
+#define HJ_BLK_STRIDE 33            /* dwords per lane's block buffer (32 + 1 against conflicts) */
 
 __device__ const uint8_t HJ_DEZZ[64] = {     // T.81 Figure A.6: zig-zag index -> natural index
   0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
   13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59,
   52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-// Bit source over the LDS image of [w0, w1) of the image's clean scan: big-endian
-// dwords (byte-swapped once when staged), one pad dword per 32 so that lanes reading
-// at a 128-byte stride hit different banks.
+// Bit source over one subsequence staged in LDS: its 128 bytes + look-ahead as
+// big-endian dwords (byte-swapped once when staged).
 struct hj_lds_src {
-  const uint32_t *lds;
-  uint32_t w0_bits;                  // first bit of the window (w0 is 16-byte aligned)
+  const uint32_t *base;              // first dword of this subsequence's copy
+  uint32_t bit0;                     // clean-scan bit position of that dword
   __device__ __forceinline__ uint32_t window32(uint32_t p) const {
-    const uint32_t r = p - w0_bits, i = r >> 5, j = i + 1;
-    const uint64_t v = ((uint64_t)lds[i + (i >> 5)] << 32) | lds[j + (j >> 5)];
+    const uint32_t r = p - bit0;
+    const uint32_t *q = base + (r >> 5);
+    const uint64_t v = ((uint64_t)q[0] << 32) | q[1];
     return (uint32_t)(v >> (32 - (r & 31)));
   }
 };
@@ -48,15 +49,25 @@ struct hj_lane_ctx {                 // what a lane knows about its subsequence
   uint32_t stop_byte;                // end of this subsequence (raw byte, exclusive)
 };
 
-// Common prologue: lane context, staged tables + scan window.  Returns false for
-// lanes beyond the image's last subsequence (they still took part in staging).
+// Image descriptor -> LDS, dword by dword (a struct assignment through a private copy
+// would be promoted to 84 B x 256 lanes of LDS by the compiler).
+static __device__ __forceinline__ void hj_stage_image(hj_image *dst, const hj_image *src) {
+  static_assert(sizeof(hj_image) % 4 == 0, "hj_image is copied as dwords");
+  if (threadIdx.x < sizeof(hj_image)/4) {
+    reinterpret_cast<uint32_t *>(dst)[threadIdx.x] = reinterpret_cast<const uint32_t *>(src)[threadIdx.x];
+  }
+}
+
+// Common prologue: lane context, tables and the group's subsequences staged in LDS.
+// Returns false for lanes beyond the image's last subsequence (they still took part
+// in staging).  lds_start[t] receives the clean-scan byte offset of subsequence t.
 static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_image &im,
- hj_tables *lds_tabs, uint32_t *lds_win, uint32_t *lds_misc, hj_lds_src &src,
- hj_lane_ctx &L) {
+ hj_tables *lds_tabs, uint32_t *lds_win, uint32_t *lds_start, hj_lane_ctx &L) {
   const uint32_t li = blockIdx.x*HJ_BLOCK + threadIdx.x;
   const bool in_range = li < im.nsub;
   L.g = 0; L.si = 0; L.i = 0; L.stop_byte = 0;
   L.seg_start = L.seg_end = L.seg_nsub = L.seg_mcu0 = L.seg_nmcu = 0;
+  uint32_t my_start = 0;
   if (in_range) {
     L.g = im.sub0 + li;
     L.si = A.sub_seg[L.g];
@@ -64,41 +75,43 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
     L.i = li - sg.sub0;
     L.seg_start = sg.start; L.seg_end = sg.end; L.seg_nsub = sg.nsub;
     L.seg_mcu0 = sg.mcu0; L.seg_nmcu = sg.nmcu;
-    L.stop_byte = sg.start + (L.i + 1)*HJ_SUB_BYTES;
+    my_start = sg.start + L.i*HJ_SUB_BYTES;
+    L.stop_byte = my_start + HJ_SUB_BYTES;
     if (L.stop_byte > sg.end) L.stop_byte = sg.end;
-    if (threadIdx.x == 0) lds_misc[0] = (sg.start + L.i*HJ_SUB_BYTES) & ~15u;   // window start
-    if (threadIdx.x == HJ_BLOCK - 1 || li + 1 == im.nsub) lds_misc[1] = L.stop_byte;
   }
-  // tables of this image -> LDS (14 KB, 16-byte chunks)
+  lds_start[threadIdx.x] = my_start;
+  // tables of this image -> LDS (16-byte chunks)
   {
     const uint4 *tsrc = reinterpret_cast<const uint4 *>(A.tables + blockIdx.y);
     uint4 *tdst = reinterpret_cast<uint4 *>(lds_tabs);
     for (int k = threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += HJ_BLOCK) tdst[k] = tsrc[k];
   }
   __syncthreads();
-  const uint32_t w0 = lds_misc[0];
-  uint32_t w1 = lds_misc[1] + 48;                     // look-ahead of the last lane
-  const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;   // bytes present in the batch buffer
-  if (w1 > padded) w1 = padded;
-  if (w1 > w0 + HJ_WIN_BYTES) w1 = w0 + HJ_WIN_BYTES;
-  const uint4 *gsrc = reinterpret_cast<const uint4 *>(A.scan + im.scan_off + w0);
-  const uint32_t nchunks = (w1 - w0 + 15) >> 4;
-  for (uint32_t c = threadIdx.x; c < nchunks; c += HJ_BLOCK) {
-    const uint4 v = gsrc[c];
-    const uint32_t a = c << 4;
-    uint32_t *d = lds_win + ((a + ((a >> 7) << 2)) >> 2);
-    d[0] = __builtin_bswap32(v.x); d[1] = __builtin_bswap32(v.y);
-    d[2] = __builtin_bswap32(v.z); d[3] = __builtin_bswap32(v.w);
+  // subsequence t: HJ_SUB_DWORDS dwords from (start & ~3)
+  const uint8_t *scan = A.scan + im.scan_off;
+  const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;      // bytes present in the batch buffer
+  const uint32_t nsubs = im.nsub - blockIdx.x*HJ_BLOCK < HJ_BLOCK ? im.nsub - blockIdx.x*HJ_BLOCK : HJ_BLOCK;
+  for (uint32_t c = threadIdx.x; c < nsubs*HJ_SUB_DWORDS; c += HJ_BLOCK) {
+    const uint32_t sub = c/HJ_SUB_DWORDS, d = c - sub*HJ_SUB_DWORDS;
+    uint32_t a = (lds_start[sub] & ~3u) + 4*d;
+    if (a + 4 > padded) a = padded - 4;
+    lds_win[sub*HJ_SUB_STRIDE + d] = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(scan + a));
   }
   __syncthreads();
-  src.lds = lds_win;
-  src.w0_bits = w0 << 3;
   return in_range;
 }
 
+// Bit source of subsequence `sub` of the group.
+static __device__ __forceinline__ hj_lds_src hj_source(const uint32_t *lds_win,
+ const uint32_t *lds_start, uint32_t sub) {
+  hj_lds_src s;
+  s.base = lds_win + sub*HJ_SUB_STRIDE;
+  s.bit0 = (lds_start[sub] & ~3u) << 3;
+  return s;
+}
+
 // Result of a run, packed for LDS.
-struct hj_run16 {
-  uint64_t end_state;
+struct hj_run16 {                    // (the end state lives in lds_S / S)
   uint16_t nblocks;
   int16_t dcsum[3];
 };
@@ -109,11 +122,11 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
   __shared__ uint64_t lds_S[HJ_BLOCK + 1];       // start state of each subsequence of the group
   __shared__ hj_run16 lds_R[HJ_BLOCK];           // result of its latest run
   __shared__ uint32_t lds_stop[HJ_BLOCK];        // stop byte | bit 31: has a successor in its segment
-  __shared__ uint32_t lds_sidx[HJ_BLOCK];        // its entry of the global S array
+  __shared__ uint32_t lds_sidx_last;             // entry of the group's last subsequence in the global S array
   __shared__ uint8_t lds_dirty[HJ_BLOCK], lds_ran[HJ_BLOCK];
   __shared__ uint16_t lds_act[HJ_BLOCK];
   __shared__ uint32_t lds_wcnt[HJ_BLOCK/64];
-  __shared__ uint32_t lds_misc[4];
+  __shared__ uint32_t lds_start[HJ_BLOCK];
   __shared__ hj_image s_im;
   const hj_image im = A.images[blockIdx.y];      // scalar fields only; indexed ones via s_im
   const uint32_t t = threadIdx.x;
@@ -127,10 +140,9 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
     }
     if (!__syncthreads_or(need)) return;
   }
-  if (t == 0) s_im = im;
-  hj_lds_src src;
+  hj_stage_image(&s_im, A.images + blockIdx.y);
   hj_lane_ctx L;
-  const bool on = hj_prologue(A, im, &lds_tabs, lds_win, lds_misc, src, L);
+  const bool on = hj_prologue(A, im, &lds_tabs, lds_win, lds_start, L);
   const uint32_t sidx = L.g + im.seg0 + L.si;          // this subsequence's entry of S
   {
     const uint64_t st = on ? A.S[sidx] : 0;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
     lds_dirty[t] = on && st != A.last_in[L.g];
     lds_ran[t] = 0;
     lds_stop[t] = L.stop_byte | (on && L.i + 1 < L.seg_nsub ? 0x80000000u : 0u);
-    lds_sidx[t] = sidx;
+    if (t == HJ_BLOCK - 1) lds_sidx_last = sidx;
   }
   __syncthreads();
   // Iterate inside the group.  Each iteration packs the subsequences whose start state
@@ -168,9 +180,10 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
       const uint32_t sub = lds_act[t];
       const uint64_t start = lds_S[sub];
       const uint32_t sb = lds_stop[sub];
-      const hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)(sb & 0x7fffffffu)*8);
+      const hj_run r = hj_sync_decode(hj_source(lds_win, lds_start, sub), s_im, &lds_tabs, start,
+       (uint64_t)(sb & 0x7fffffffu)*8);
       hj_run16 r16;
-      r16.end_state = r.end_state; r16.nblocks = (uint16_t)r.nblocks;
+      r16.nblocks = (uint16_t)r.nblocks;
       r16.dcsum[0] = r.dcsum[0]; r16.dcsum[1] = r.dcsum[1]; r16.dcsum[2] = r.dcsum[2];
       lds_R[sub] = r16;
       lds_ran[sub] = 1;
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
         if (sub + 1 < HJ_BLOCK) {
           if (lds_S[sub + 1] != r.end_state) { lds_S[sub + 1] = r.end_state; lds_dirty[sub + 1] = 1; }
         }
-        else A.S[lds_sidx[sub] + 1] = r.end_state;         // first subsequence of the next group
+        else A.S[lds_sidx_last + 1] = r.end_state;         // first subsequence of the next group
       }
     }
     __syncthreads();
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
     if (lds_ran[t]) {
       const hj_run16 r16 = lds_R[t];
       hj_run r;
-      r.end_state = r16.end_state; r.nblocks = r16.nblocks; r.error = 0;
+      r.end_state = 0; r.nblocks = r16.nblocks; r.error = 0;
       r.dcsum[0] = r16.dcsum[0]; r.dcsum[1] = r16.dcsum[1]; r.dcsum[2] = r16.dcsum[2];
       A.R[L.g] = r;
       // clean: its latest run started from st.  dirty: the state moved after that run
@@ -258,57 +271,39 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_scan(const hj_args A) {
   if (bad) atomicOr(&A.errors[img], 1u);
 }
 
-// Write sink.  A block this lane decodes from its first coefficient ("owned") is
-// built in the lane's LDS buffer and stored as one 128-byte line when complete;
-// everything else (the tail of a block begun by an earlier lane, the head of a
-// block this lane cannot finish) goes straight to the pre-zeroed planes as
-// 2-byte stores — disjoint positions, so no ordering is needed between lanes.
-struct hj_write_sink {
+// Output side of hj_write_decode.  Every coefficient lands in the lane's LDS block
+// buffer first.  A block decoded here from its first to its last coefficient leaves as
+// one 128-byte line; a piece of a block shared with a neighbouring lane is scattered
+// as 2-byte stores onto the pre-zeroed planes (disjoint positions, so the lanes need
+// no ordering between them).
+typedef int16_t __attribute__((may_alias)) hj_i16_alias;    // 16-bit view of the dword buffer
+struct hj_block_out {
   const hj_image *im;
   int16_t *coef;
-  uint32_t *blk;                     // this lane's 36-dword LDS buffer (zero between blocks)
-  uint32_t mcu0, b0, total;
-  int pred0, pred1, pred2;           // DC predictors (scalars: no indexed private array)
-  int64_t off;
-  bool ok, owned;
-
-  __device__ __forceinline__ void flush_owned() {
-    uint4 *dst = reinterpret_cast<uint4 *>(coef + off);
-    const uint4 *s = reinterpret_cast<const uint4 *>(blk);
-    const uint4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int n = 0; n < 8; n++) {
-      dst[n] = s[n];
-      reinterpret_cast<uint4 *>(blk)[n] = z;
-    }
-  }
-  __device__ __forceinline__ void block_begin(uint32_t n, int c, int k) {
-    if (n && owned && ok) flush_owned();               // the previous block is complete
-    const uint32_t b = b0 + n;
-    ok = b < total;
-    owned = k == 0;
-    if (ok) off = hj_block_offset(*im, mcu0 + b/(uint32_t)im->nslots, c);
-  }
+  uint32_t *blk;                     // this lane's 32-dword LDS buffer (zero between blocks)
+  uint32_t mcu0, b0;
   __device__ __forceinline__ void put(int idx, int v) {
-    if (!ok) return;
-    if (owned) reinterpret_cast<int16_t *>(blk)[idx] = (int16_t)v;
-    else coef[off + idx] = (int16_t)v;
+    reinterpret_cast<hj_i16_alias *>(blk)[idx] = (int16_t)v;
   }
-  __device__ __forceinline__ void dc(int comp, int v) {
-    pred0 += comp == 0 ? v : 0;
-    pred1 += comp == 1 ? v : 0;
-    pred2 += comp == 2 ? v : 0;
-    put(0, (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2));   // wraps like xjpeg.c:480
-  }
-  __device__ __forceinline__ void ac(int k, int v) { put(HJ_DEZZ[k], v); }
-  // end of the run with the current block incomplete (k != 0): a later lane adds the
-  // rest, so this lane's part is scattered; a complete block was flushed by block_begin
-  __device__ __forceinline__ void finish(int k) {
-    if (!(ok && owned && k != 0)) return;
-    const int16_t *s = reinterpret_cast<const int16_t *>(blk);
-    for (int n = 0; n < 64; n++) {
-      const int16_t v = s[n];
-      if (v) coef[off + n] = v;
+  __device__ __forceinline__ void flush(uint32_t n, int slot, bool complete, bool head) {
+    const uint32_t b = b0 + n;
+    int16_t *dst = coef + hj_block_offset(*im, mcu0 + b/(uint32_t)im->nslots, slot);
+    if (complete && head) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        uint4 v;
+        v.x = blk[4*q]; v.y = blk[4*q + 1]; v.z = blk[4*q + 2]; v.w = blk[4*q + 3];
+        reinterpret_cast<uint4 *>(dst)[q] = v;
+        blk[4*q] = 0; blk[4*q + 1] = 0; blk[4*q + 2] = 0; blk[4*q + 3] = 0;
+      }
+    }
+    else {
+      for (int q = 0; q < 32; q++) {
+        const uint32_t two = blk[q];
+        if (two & 0xffffu) dst[2*q] = (int16_t)(two & 0xffffu);
+        if (two >> 16) dst[2*q + 1] = (int16_t)(two >> 16);
+        blk[q] = 0;
+      }
     }
   }
 };
@@ -316,16 +311,23 @@ struct hj_write_sink {
 __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
   __shared__ uint32_t lds_win[HJ_WIN_DWORDS];
-  __shared__ __attribute__((aligned(16))) uint32_t lds_blk[HJ_BLOCK*HJ_BLK_STRIDE];
-  __shared__ uint32_t lds_misc[4];
+  __shared__ uint32_t lds_blk[HJ_BLOCK*HJ_BLK_STRIDE];
   __shared__ hj_image s_im;
+  __shared__ uint8_t s_dezz[64];
   const hj_image im0 = A.images[blockIdx.y];
   if (blockIdx.x*HJ_BLOCK >= im0.nsub) return;              // grid.x covers the largest image
-  if (threadIdx.x == 0) s_im = im0;
-  for (int k = threadIdx.x; k < HJ_BLOCK*HJ_BLK_STRIDE; k += HJ_BLOCK) lds_blk[k] = 0;
-  hj_lds_src src;
+  hj_stage_image(&s_im, A.images + blockIdx.y);
+  if (threadIdx.x < 64) s_dezz[threadIdx.x] = HJ_DEZZ[threadIdx.x];
+  // the subsequence start offsets are only needed while staging: they borrow the first
+  // 1 KB of the block buffers, which are zeroed afterwards
+  uint32_t *lds_start = lds_blk;
   hj_lane_ctx L;
-  const bool on = hj_prologue(A, im0, &lds_tabs, lds_win, lds_misc, src, L);   // syncs: s_im, lds_blk ready
+  const bool on = hj_prologue(A, im0, &lds_tabs, lds_win, lds_start, L);   // syncs: s_im ready
+  hj_lds_src src = hj_source(lds_win, lds_start, threadIdx.x);
+  __syncthreads();
+  uint32_t *blk = lds_blk + threadIdx.x*HJ_BLK_STRIDE;
+#pragma unroll
+  for (int k = 0; k < 32; k++) blk[k] = 0;                  // own buffer only: no barrier needed
   if (!on) return;
   const hj_image &im = s_im;
   const uint32_t total = L.seg_nmcu*(uint32_t)im.nslots;
@@ -334,15 +336,14 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   const uint32_t sidx = L.g + im.seg0 + L.si;
   const uint64_t start = A.S[sidx];
   const uint64_t stop = L.i + 1 < L.seg_nsub ? hj_pos(A.S[sidx + 1]) : (uint64_t)L.seg_end*8;
-  hj_write_sink ws;
-  ws.im = &im;
-  ws.coef = A.coef + (long long)blockIdx.y*A.coef_stride;
-  ws.blk = lds_blk + threadIdx.x*HJ_BLK_STRIDE;
-  ws.mcu0 = L.seg_mcu0; ws.b0 = b0; ws.total = total;
-  ws.pred0 = A.D[3*L.g + 0]; ws.pred1 = A.D[3*L.g + 1]; ws.pred2 = A.D[3*L.g + 2];
-  ws.off = 0; ws.ok = false; ws.owned = false;
-  const hj_run r = hj_decode(src, im, &lds_tabs, start, stop, total - b0, ws);
-  if (r.error) atomicOr(&A.errors[blockIdx.y], 2u);
+  hj_block_out out;
+  out.im = &im;
+  out.coef = A.coef + (long long)blockIdx.y*A.coef_stride;
+  out.blk = blk;
+  out.mcu0 = L.seg_mcu0; out.b0 = b0;
+  const int err = hj_write_decode(src, im, &lds_tabs, s_dezz,
+   start, stop, total - b0, A.D[3*L.g + 0], A.D[3*L.g + 1], A.D[3*L.g + 2], out);
+  if (err) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, void *stream) {

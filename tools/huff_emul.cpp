@@ -3,6 +3,7 @@
 // as csrc/huff_kernels.hip, one "lane" at a time, so that the synchronisation
 // algorithm can be validated on a machine without a GPU (tests/test_huff_emul.py).
 // Built into tools/bin/libhuff_emul.so by the test; never part of the product library.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -18,17 +19,18 @@ static void init_dezz() {
   }
 }
 
-struct write_sink {
-  const hj_image *im; const hj_segment *seg; short *coef; uint32_t b0, total; int16_t pred[3];
-  int64_t off; bool ok;
-  void finish(int) {}
-  void block_begin(uint32_t n, int c, int) {
+struct block_out {
+  const hj_image *im; const hj_segment *seg; short *coef; uint32_t b0; short blk[64];
+  void put(int idx, int v) { blk[idx] = (short)v; }
+  void flush(uint32_t n, int slot, bool complete, bool head) {
     const uint32_t b = b0 + n;
-    ok = b < total;
-    if (ok) off = hj_block_offset(*im, seg->mcu0 + b/(uint32_t)im->nslots, c);
+    short *dst = coef + hj_block_offset(*im, seg->mcu0 + b/(uint32_t)im->nslots, slot);
+    for (int q = 0; q < 64; q++) {
+      if (complete && head) dst[q] = blk[q];
+      else if (blk[q]) dst[q] = blk[q];
+      blk[q] = 0;
+    }
   }
-  void dc(int comp, int v) { pred[comp] = (int16_t)(pred[comp] + v); if (ok) coef[off] = pred[comp]; }
-  void ac(int k, int v) { if (ok) coef[off + DEZZ[k]] = (short)v; }
 };
 
 extern "C" __attribute__((visibility("default")))
@@ -77,6 +79,14 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
       runs++;
     }
     if (!ran) break;
+    if (getenv("EMUL_VERBOSE")) {
+      long changed = 0, only_c = 0;
+      if (jacobi) for (size_t q = 0; q < S.size(); q++) if (S[q] != snap[q]) {
+        changed++;
+        if ((S[q] >> 16) == (snap[q] >> 16) && (S[q] & 255) == (snap[q] & 255)) only_c++;
+      }
+      fprintf(stderr, "round %d: states changed %ld (only slot differs: %ld)\n", rounds, changed, only_c);
+    }
     rounds++;
     if (rounds > (int)nsub + 4) return 3;
   }
@@ -90,15 +100,16 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
       const uint32_t g = sg.sub0 + i;
       const uint64_t start = S[g + si];
       if (hj_slot(start) != (int)(b % (uint32_t)P.im.nslots) && b < total) return 4;
-      write_sink ws;
-      ws.off = 0; ws.ok = false;
-      ws.im = &P.im; ws.seg = &sg; ws.coef = coef; ws.b0 = b; ws.total = total;
-      ws.pred[0] = dc[0]; ws.pred[1] = dc[1]; ws.pred[2] = dc[2];
+      block_out bo;
+      memset(bo.blk, 0, sizeof(bo.blk));
+      bo.im = &P.im; bo.seg = &sg; bo.coef = coef; bo.b0 = b;
       const uint64_t stop = i + 1 < sg.nsub ? hj_pos(S[g + si + 1]) : (uint64_t)sg.end*8;
       hj_mem_src src; src.s = P.clean.data();
-      hj_run r = hj_decode(src, P.im, &P.tabs, start, stop,
-       b < total ? total - b : 0, ws);
-      if (r.error && b < total) return 5;
+      uint8_t dz[64];
+      for (int q = 0; q < 64; q++) dz[q] = (uint8_t)DEZZ[q];
+      const int err = b < total ? hj_write_decode(src, P.im, &P.tabs, dz, start, stop, total - b,
+       dc[0], dc[1], dc[2], bo) : 0;
+      if (err) return 5;
       b += R[g].nblocks;
       for (int c = 0; c < 3; c++) dc[c] = (int16_t)(dc[c] + R[g].dcsum[c]);
     }
