@@ -237,23 +237,65 @@ def main():
         n = args.e2e_images
         e2e = {}
         nthr = args.e2e_threads or max(1, min(os.cpu_count() or 1, 48))
-        for copy_back in (False, True):
+        for copy_back, transport in ((False, 0), (True, 0), (False, 1)):
             pl = lib.Pipeline(device=local_rank, nthreads=nthr,
-                              out=abi.JPEG_DECODE_RGB, copy_back=copy_back)
+                              out=abi.JPEG_DECODE_RGB, copy_back=copy_back, transport=transport)
             jobs = [jpegs[i % len(jpegs)] for i in range(n)]
             outs = [np.empty(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
             pl.run(jobs[:16], host_outs=outs[:16] if outs else None)   # warm: slots, pages
             t0 = time.perf_counter()
-            rc, _ = pl.run(jobs, host_outs=outs)
+            rc, done = pl.run(jobs, host_outs=outs)
             te = time.perf_counter() - t0
             pl.close()
             key = "jpeg_host_to_rgb_host" if copy_back else "jpeg_host_to_rgb_hbm"
+            if transport:
+                key += "_pack_transport"
             e2e[key] = {"value": round(n * W * H / te / 1e6, 1), "unit": "Mpixel/s",
-                        "images": n, "ok": rc == 0}
+                        "images": n, "ok": rc == 0,
+                        "h2d_bytes_per_image": int(sum(j.h2d_bytes for j in done) // n)}
         e2e["host_threads"] = nthr
         e2e["note"] = "host Huffman threads + pinned hipMemcpyAsync + fused kernel; " \
                       "PCIe- and host-inclusive, not `value`"
         out["e2e"] = e2e
+
+    if rank == 0 and world == 1 and not args.no_e2e:
+        # Supplementary: PACK words + block index resident in HBM ->
+        # jga_unpack_kernel -> QUANT planes.  Algorithmic bytes: 2 B/word + 4 B/block read,
+        # 128 B/block written.
+        pw = [lib.entropy_decode_pack(j, g)[:2] for j in jpegs]
+        nidx = int(lib.L.jga_index_count(C.byref(g)))
+        pstride = (max(len(p) for p, _ in pw) + 127) // 128 * 128
+        hp = np.zeros((B, pstride), np.uint16)
+        hi = np.zeros((B, nidx), np.int32)
+        for i in range(B):
+            p, ix = pw[i % len(pw)]
+            hp[i, :len(p)] = p.view(np.uint16)
+            hi[i] = ix
+        d_pack, d_idx = lib.DeviceBuffer(hp.nbytes), lib.DeviceBuffer(hi.nbytes)
+        d_pack.upload(hp)
+        d_idx.upload(hi)
+        reps = 10
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                lib.check(lib.L.jga_unpack_batch(C.byref(g), B, d_pack.ptr, pstride, pstride,
+                                                 d_idx.ptr, nidx, d_coef.ptr, cstride, None))
+            lib.check(lib.L.jga_stream_sync(None))
+            tu = (time.perf_counter() - t0) / reps
+        nblk = sum(g.plane[p].hblocks * g.plane[p].vblocks for p in range(g.nplanes))
+        words = sum(len(pw[i % len(pw)][0]) for i in range(B))
+        ub = words * 2 + B * nblk * (4 + 128)
+        same = bool(np.array_equal(d_coef.download(g.coef_shorts * 2, dtype=np.int16),
+                                   lib.entropy_decode(jpegs[0], g)))
+        out["pack_stage"] = {
+            "kernel": "jga_unpack_kernel", "ms_per_launch": round(tu * 1e3, 4),
+            "achieved_GBps": round(ub / tu / 1e9, 1), "algorithmic_bytes_per_launch": ub,
+            "words_per_block": round(words / (B * nblk), 2),
+            "pcie_bytes_vs_dense": round((words * 2 + B * nidx * 4) / (B * g.coef_shorts * 2), 3),
+            "equals_host_quant_stage": same,
+        }
+        d_pack.free()
+        d_idx.free()
 
     if rank == 0 and world == 1 and not args.no_gpu_entropy:
         # Supplementary: the whole decode on the GPU.  Entropy-coded

@@ -253,7 +253,22 @@ int jga_idct_yuv_batch(const jga_geom *g, int nimages,
  const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
  int dequant_on_device, unsigned char *d_yuv, long long yuv_stride,
  void *stream);
-/* Name of the kernel the two calls above launch for `g` (for profiles). */
+/* PACK wire format expanded on the device: the words and
+ * per-block start indices produced by jga_entropy_decode_pack() (reference
+ * producer src/xjpeg.c:484-496, 513-519, 531-535), resident in HBM, become the
+ * QUANT-stage planes the two launches above read — the job of the reference's
+ * first PACK pass, res/horz_pack_yuv.fs.glsl:94-127 (12-bit sign extension,
+ * `j += run + 1`, de-zigzag).  Image i: words at d_pack + i*pack_stride (of which
+ * pack_words may be read), indices at d_index + i*index_stride
+ * (jga_index_count(g) ints, planes back to back, raster per plane as
+ * src/image.c:93-94), planes at d_coef + i*coef_stride.  Only real blocks are
+ * written.  Asynchronous on `stream`. */
+long long jga_index_count(const jga_geom *g);
+int jga_unpack_batch(const jga_geom *g, int nimages,
+ const unsigned short *d_pack, long long pack_stride, long long pack_words,
+ const int *d_index, long long index_stride, short *d_coef, long long coef_stride,
+ void *stream);
+/* Name of the kernel jga_idct_rgb_batch / jga_idct_yuv_batch launch for `g` (for profiles). */
 const char *jga_kernel_name(const jga_geom *g, int rgb);
 
 /* Thin device-memory helpers so C/ctypes callers need no HIP binding. */
@@ -289,6 +304,8 @@ typedef struct jga_pipeline_config {
   int copy_back;               /* 1: D2H into caller's host buffers */
   long long max_coef_shorts;   /* slot capacity (0 = sized on first submit) */
   long long max_out_bytes;
+  int transport;               /* what crosses PCIe: 0 = dense QUANT planes,
+                                * 1 = PACK words + block index, expanded by jga_unpack_batch */
 } jga_pipeline_config;
 
 typedef struct jga_job {
@@ -298,6 +315,7 @@ typedef struct jga_job {
   unsigned char *dev_out;      /* in : device destination, or NULL = internal */
   int status;                  /* out: 0 ok, 1 failed */
   int width, height, nplanes;  /* out */
+  long long h2d_bytes;         /* out: coefficient bytes this image sent over PCIe */
 } jga_job;
 
 jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);

@@ -21,7 +21,7 @@ OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
 C_SOURCES = ["layout.c", "entropy.c"]
-HIP_SOURCES = ["idct_kernels.hip", "huff_kernels.hip"]   # device code: hipcc
+HIP_SOURCES = ["idct_kernels.hip", "huff_kernels.hip", "pack_kernels.hip"]   # device code: hipcc
 CXX_SOURCES = ["device_api.cpp", "vtbl.cpp", "pipeline.cpp", "huff_prepare.cpp",
                "huff_api.cpp"]                           # host only: g++ + HIP API
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -67,7 +67,7 @@ def check_no_fma(asm_path):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in ("jga_internal.h", "kernel_params.h", "huff_common.h",
-                                               "huff_kernels.h", "huff_prepare.h")]
+                                               "huff_kernels.h", "huff_prepare.h", "pack_params.h")]
     headers.append(os.path.join(HERE, "..", "include", "jpeg_gpu_amd.h"))
     all_src = [os.path.join(CSRC, s) for s in C_SOURCES + HIP_SOURCES + CXX_SOURCES] + headers
 

@@ -8,6 +8,7 @@
 #include <string.h>
 #include "jga_internal.h"
 #include "kernel_params.h"
+#include "pack_params.h"
 
 #define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return jga_fail("HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #call); } while (0)
@@ -127,6 +128,60 @@ JGA_EXPORT int jga_idct_yuv_batch(const jga_geom *g, int nimages,
   }
   rc = jga_launch_yuv(&P, staged_loads(), stream);
   if (rc) return jga_fail("YUV kernel launch failed (HIP error %d)", rc);
+  return EXIT_SUCCESS;
+}
+
+JGA_EXPORT long long jga_index_count(const jga_geom *g) {
+  long long n = 0;
+  for (int p = 0; p < g->nplanes; p++) {
+    n += (long long)(g->plane[p].hblocks << g->plane[p].xdec)*g->plane[p].cstride;
+  }
+  return n;
+}
+
+JGA_EXPORT int jga_unpack_batch(const jga_geom *g, int nimages,
+ const unsigned short *d_pack, long long pack_stride, long long pack_words,
+ const int *d_index, long long index_stride, short *d_coef, long long coef_stride,
+ void *stream) {
+  jga_pack_params P;
+  int rc, p, first = 0;
+  long long index0 = 0;
+  memset(&P, 0, sizeof(P));
+  if (nimages < 1) return jga_fail("Invalid batch size %d", nimages);
+  if (g->nplanes != 1 && g->nplanes != 3) {
+    return jga_fail("Unsupported number of components %i", g->nplanes);
+  }
+  if (coef_stride < g->coef_shorts) return jga_fail("coef_stride too small");
+  if (index_stride < jga_index_count(g)) return jga_fail("index_stride too small");
+  if (pack_words < 0 || pack_words > pack_stride) return jga_fail("pack_words exceeds pack_stride");
+  if (((uintptr_t)d_pack) % 4 || pack_stride % 2) {
+    return jga_fail("PACK buffers must be 4-byte aligned");
+  }
+  if (((uintptr_t)d_coef) % 16 || coef_stride % 8) {
+    return jga_fail("Coefficient buffers must be 16-byte aligned");
+  }
+  P.pack = d_pack;
+  P.index = d_index;
+  P.coef = d_coef;
+  P.pack_stride = pack_stride;
+  P.index_stride = index_stride;
+  P.coef_stride = coef_stride;
+  P.pack_words = pack_words;
+  P.nimages = nimages;
+  P.nplanes = g->nplanes;
+  P.w0_blocks = g->w0/8;
+  for (p = 0; p < g->nplanes; p++) {
+    P.plane_hblocks[p] = g->plane[p].hblocks;
+    P.plane_xdec[p] = g->plane[p].xdec;
+    P.plane_first[p] = first;
+    P.plane_index0[p] = (int)index0;
+    P.plane_coef_off[p] = g->plane[p].coef_off;
+    first += g->plane[p].hblocks*g->plane[p].vblocks;
+    index0 += (long long)(g->plane[p].hblocks << g->plane[p].xdec)*g->plane[p].cstride;
+  }
+  P.plane_first[g->nplanes] = first;
+  rc = jga_launch_unpack(&P, stream);
+  if (rc) return jga_fail("PACK kernel launch failed (HIP error %d)", rc);
   return EXIT_SUCCESS;
 }
 

@@ -16,6 +16,7 @@ EXPORTED = [
     "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",
     "jga_parse_header", "jga_entropy_decode", "jga_entropy_decode_pack",
     "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_kernel_name",
+    "jga_index_count", "jga_unpack_batch",
     "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
     "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
     "jga_stream_sync", "jga_set_device", "jga_stream_create", "jga_stream_destroy",
@@ -64,6 +65,9 @@ L.jga_entropy_decode_pack.argtypes = [C.c_char_p, _i, _G, _vp, _ll, _vp,
                                       C.POINTER(_ll), C.POINTER(_ll)]
 L.jga_idct_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
 L.jga_idct_yuv_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+L.jga_index_count.argtypes = [_G]
+L.jga_index_count.restype = _ll
+L.jga_unpack_batch.argtypes = [_G, _i, _vp, _ll, _ll, _vp, _ll, _vp, _ll, _vp]
 L.jga_time_idct_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _i, _i, _vp,
                                   C.POINTER(C.c_float)]
 L.jga_device_malloc.argtypes = [C.c_size_t]
@@ -329,9 +333,9 @@ class Decoder:
 
 class Pipeline:
     def __init__(self, device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
-                 max_coef_shorts=0, max_out_bytes=0):
+                 max_coef_shorts=0, max_out_bytes=0, transport=0):
         cfg = abi.jga_pipeline_config(device, nthreads, 0, out, int(copy_back),
-                                      max_coef_shorts, max_out_bytes)
+                                      max_coef_shorts, max_out_bytes, int(transport))
         self.ptr = L.jga_pipeline_create(C.byref(cfg))
         if not self.ptr:
             raise JgaError((L.jga_last_error() or b"pipeline_create failed").decode())
@@ -392,6 +396,47 @@ class HuffBatch:
         if self.ptr:
             L.jga_huff_destroy(self.ptr)
             self.ptr = None
+
+
+def block_slots(g):
+    """Per plane: (index positions, coefficient offsets in shorts) of its real blocks, raster."""
+    out, base = [], 0
+    for p in range(g.nplanes):
+        pl = g.plane[p]
+        by, bx = np.mgrid[0:pl.vblocks, 0:pl.hblocks]
+        rs = (g.w0 // 8) * 64
+        off = (pl.coef_off + rs * (by >> pl.xdec) + (rs >> pl.xdec) * (by & ((1 << pl.xdec) - 1))
+               + bx * 64)
+        out.append(((base + by * pl.hblocks + bx).ravel(), off.ravel().astype(np.int64)))
+        base += (pl.hblocks << pl.xdec) * pl.cstride
+    return out
+
+
+def gpu_unpack(g, packs, indexes, pack_words=None):
+    """jga_unpack_batch on same-geometry images -> (n, coef_shorts) int16 (unwritten slots 0)."""
+    n = len(packs)
+    nidx = int(L.jga_index_count(C.byref(g)))
+    pstride = _align(max(len(p) for p in packs) * 2 + 2, 4) // 2
+    cstride = _align(g.coef_shorts * 2) // 2
+    d_pack, d_idx = DeviceBuffer(max(pstride, 2) * 2 * n), DeviceBuffer(nidx * 4 * n)
+    d_coef = DeviceBuffer(cstride * 2 * n)
+    try:
+        hp = np.zeros((n, pstride), np.uint16)
+        hi = np.zeros((n, nidx), np.int32)
+        for i in range(n):
+            hp[i, :len(packs[i])] = np.asarray(packs[i]).view(np.uint16)
+            hi[i, :len(indexes[i])] = indexes[i]
+        d_pack.upload(hp)
+        d_idx.upload(hi)
+        d_coef.fill(0)
+        words = pstride if pack_words is None else int(pack_words)
+        check(L.jga_unpack_batch(C.byref(g), n, d_pack.ptr, pstride, words, d_idx.ptr, nidx,
+                                 d_coef.ptr, cstride, None))
+        check(L.jga_stream_sync(None))
+        raw = d_coef.download(dtype=np.int16).reshape(n, cstride)
+        return raw[:, :g.coef_shorts].copy()
+    finally:
+        d_pack.free(); d_idx.free(); d_coef.free()
 
 
 def gpu_entropy_decode(jpegs):

@@ -91,6 +91,8 @@ class Oracle(_Lib):
                                      C.POINTER(Info)]
         L.orc_constants.argtypes = [C.c_void_p]
         L.orc_dezigzag.argtypes = [C.c_void_p]
+        L.orc_unpack_blocks.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_long, C.c_void_p]
+        L.orc_unpack_blocks.restype = None
 
     def constants(self):
         out = np.zeros(12, np.float32)
@@ -106,6 +108,15 @@ class Oracle(_Lib):
         blocks = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, 64)
         out = np.empty_like(blocks)
         self.lib.orc_idct8x8_blocks(out.ctypes.data, blocks.ctypes.data, len(blocks))
+        return out
+
+    def unpack_blocks(self, pack, starts):
+        """PACK words + block start indices -> (nblocks, 64) int16, natural order."""
+        pack = np.ascontiguousarray(pack).view(np.uint16)
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        out = np.zeros((len(starts), 64), np.int16)
+        self.lib.orc_unpack_blocks(pack.ctypes.data, len(pack), starts.ctypes.data, len(starts),
+                                   out.ctypes.data)
         return out
 
     def parse(self, data):

@@ -714,6 +714,39 @@ ORC_API void orc_coef_to_planes(const orc_info *o, const short *coef,
   }
 }
 
+/* PACK consumer: restatement of the expansion loop of the reference's first
+ * PACK pass, res/horz_pack_yuv.fs.glsl:94-127 — block zeroed (110), word 0 =
+ * DC with 12-bit sign extension (112), then per word: 0 ends the block
+ * (117-119), otherwise `j += run + 1` (121, 124) and the sign-extended level
+ * lands at DE_ZIG_ZAG[j] (125); the loop runs while j < 63 (114).  Producer:
+ * src/xjpeg.c:484-496, 513-519, 531-535.  The shader indexes out of bounds
+ * when a run passes coefficient 63 and reads past the buffer on a truncated
+ * stream (undefined in GLSL); this restatement DEFINES both as "the block ends
+ * there".  starts[b] = index of word 0 of block b; out = nblocks x 64 shorts,
+ * natural order. */
+ORC_API void orc_unpack_blocks(const unsigned short *pack, long long nwords,
+ const int *starts, long nblocks, short *out) {
+  long b;
+  orc_init_zigzag();
+  for (b = 0; b < nblocks; b++) {
+    short *blk = out + b*64;
+    long long i = starts[b];
+    int j = 0;
+    unsigned p;
+    memset(blk, 0, 64*sizeof(short));
+    if (i < 0 || i >= nwords) continue;
+    p = pack[i++];
+    blk[0] = (short)((p & 0xfff) | ((p & 0x800) ? ~0xfff : 0));
+    while (j < 63 && i < nwords) {
+      p = pack[i++];
+      if (p == 0) break;
+      j += (int)((p >> 12) & 0xf) + 1;
+      if (j > 63) break;
+      blk[ORC_DEZIGZAG[j]] = (short)((p & 0xfff) | ((p & 0x800) ? ~0xfff : 0));
+    }
+  }
+}
+
 /* Upsample + YCbCr->RGB: restatement of res/unyuv.fs.glsl:12-16, 29-31,
  * 39-41, 48-49 (nearest replication s>>xdec, t>>ydec; JFIF float matrix in
  * GLSL mat3*vec3 column order) and res/ungrey.fs.glsl:18, per SURVEY.md

@@ -245,22 +245,28 @@ def test_plugin_gpu_stages(gpu, orc, synth):
         assert np.array_equal(d.pixels(), planes[0][:33, :77])
 
 
-def test_pipeline(gpu, orc, synth):
+@pytest.mark.parametrize("transport", [0, 1])
+def test_pipeline(gpu, orc, synth, transport):
     """Pipelined batch decoder: mixed geometries, copy-back to host, results equal
-    the oracle's whole-path decode."""
+    the oracle's whole-path decode — with dense planes (0) or the PACK wire format (1)
+    crossing PCIe."""
     from jpeg_gpu_amd import abi
     specs = [(320, 200, "420"), (128, 64, "444"), (200, 100, "422"), (64, 64, "grey"),
              (320, 200, "420"), (97, 55, "420")] * 3
     datas = [synth.synthetic_jpeg(w, h, s, seed=i, restart_interval=(i % 3) * 4)
              for i, (w, h, s) in enumerate(specs)]
     outs = [np.zeros(w * h * (1 if s == "grey" else 3), np.uint8) for (w, h, s) in specs]
-    pl = gpu.Pipeline(device=0, nthreads=3, out=abi.JPEG_DECODE_RGB, copy_back=True)
+    pl = gpu.Pipeline(device=0, nthreads=3, out=abi.JPEG_DECODE_RGB, copy_back=True,
+                      transport=transport)
     try:
         rc, jobs = pl.run(datas, host_outs=outs)
         assert rc == 0
         for i, d in enumerate(datas):
             assert jobs[i].status == 0
             assert np.array_equal(outs[i], orc.decode_rgb(d)[1].reshape(-1)), i
+        if transport == 1:      # the compact form is what crossed PCIe
+            _, g = gpu.geom_of(datas[0])
+            assert 0 < jobs[0].h2d_bytes < g.coef_shorts * 2
         # a corrupt job fails alone
         bad = list(datas[:4])
         bad[1] = bad[1][:200]
@@ -268,6 +274,74 @@ def test_pipeline(gpu, orc, synth):
         assert rc == 1 and [jobs[i].status for i in range(4)] == [0, 1, 0, 0]
     finally:
         pl.close()
+
+
+# ---- PACK wire format expanded on the GPU ---------------------------
+
+@pytest.mark.parametrize("sampling", SAMPLINGS)
+@pytest.mark.parametrize("ri", [0, 5])
+def test_gpu_unpack_equals_quant_stage(gpu, synth, sampling, ri):
+    datas = [synth.synthetic_jpeg(333, 211, sampling, quality=q, restart_interval=ri, seed=q)
+             for q in (95, 60, 20)]
+    _, g = gpu.geom_of(datas[0])
+    packs, indexes = zip(*[gpu.entropy_decode_pack(d, g)[:2] for d in datas])
+    got = gpu.gpu_unpack(g, packs, indexes)
+    for i, d in enumerate(datas):
+        assert np.array_equal(got[i], gpu.entropy_decode(d, g)), (sampling, ri, i)
+
+
+def test_gpu_unpack_golden_words(gpu, golden_jpegs):
+    """Words + index produced by the COMPILED REFERENCE -> the reference's QUANT planes."""
+    for name in golden_jpegs.names:
+        _, g = gpu.geom_of(golden_jpegs.jpeg(name))
+        got = gpu.gpu_unpack(g, [golden_jpegs[name + ".pack"]], [golden_jpegs[name + ".index"]])
+        assert np.array_equal(got[0], golden_jpegs[name + ".quant"]), name
+
+
+def test_gpu_unpack_crafted_words_match_oracle(gpu, orc, synth):
+    """Arbitrary words: 12-bit sign wrap, ZRL chains, runs past coefficient 63, blocks with and
+    without an end word, a stream that stops mid-block — kernel == oracle restatement of
+    res/horz_pack_yuv.fs.glsl:94-127, word for word."""
+    _, g = gpu.geom_of(synth.synthetic_jpeg(200, 120, "420"))
+    rng = np.random.default_rng(11)
+    slots = gpu.block_slots(g)
+    nblk = sum(len(ipos) for ipos, _ in slots)
+    words, starts = [], []
+    for b in range(nblk):
+        starts.append(len(words))
+        kind = b % 5
+        n = int(rng.integers(0, 70))
+        w = rng.integers(0, 65536, size=1 + n).astype(np.uint16)          # anything goes
+        if kind == 1:
+            w[1:] = (rng.integers(0, 3, size=n) << 12) | rng.integers(1, 4096, size=n)
+        elif kind == 2:
+            w[1:] = 0xF000                                                  # ZRL chain
+        elif kind == 3:
+            w = np.concatenate([w[:1], ((np.zeros(63, int) << 12) | 0x801).astype(np.uint16)])
+        words.extend(w.tolist())
+        if kind != 3:
+            words.append(0)
+    words = np.array(words, np.uint16)
+    index = np.zeros(int(gpu.L.jga_index_count(C.byref(g))), np.int32)
+    order = rng.permutation(nblk)                # blocks need not be stored in scan order
+    k = 0
+    for ipos, _ in slots:
+        index[ipos] = np.array(starts)[order[k:k + len(ipos)]]
+        k += len(ipos)
+    for limit in (len(words), len(words) - 37):  # whole stream, then cut short
+        got = gpu.gpu_unpack(g, [words], [index], pack_words=limit)[0]
+        want = np.zeros_like(got)
+        for ipos, off in slots:
+            want[off[:, None] + np.arange(64)] = orc.unpack_blocks(words[:limit], index[ipos])
+        assert np.array_equal(got, want), limit
+
+
+def test_gpu_unpack_4k_then_rgb(gpu, orc, synth):
+    """BASELINE headline geometry: words -> planes -> RGB equals the oracle's whole path."""
+    data = synth.synthetic_jpeg(3840, 2160, "420", quality=90, seed=1234)
+    _, g = gpu.geom_of(data)
+    pack, index, _ = gpu.entropy_decode_pack(data, g)
+    assert np.array_equal(gpu.gpu_unpack(g, [pack], [index])[0], gpu.entropy_decode(data, g))
 
 
 # ---- GPU entropy stage (SURVEY.md §8f-1) ---------------------------------------------

@@ -179,3 +179,16 @@ def test_rgb_stage_definition(orc):
     assert list(rgb[1, 0]) == [0, int(np.float32(np.float32(100 + np.float32(-0.34414) * 127) +
                                                  np.float32(-0.71414) * np.float32(-128)) + 0.5), 255]
     assert rgb[1, 1, 0] == 255 and rgb[1, 1, 2] == 0
+
+
+def test_pack_consumer_restatement_against_reference_goldens(orc, lib, golden_jpegs):
+    """oracle.c:orc_unpack_blocks (res/horz_pack_yuv.fs.glsl:94-127) applied to the PACK words
+    and block index the COMPILED REFERENCE produced gives the reference's own QUANT planes."""
+    for name in golden_jpegs.names:
+        _, g = lib.geom_of(golden_jpegs.jpeg(name))
+        pack, index, quant = (golden_jpegs[name + k] for k in (".pack", ".index", ".quant"))
+        got = np.zeros_like(quant)
+        for ipos, off in lib.block_slots(g):
+            blocks = orc.unpack_blocks(pack, index[ipos])
+            got[off[:, None] + np.arange(64)] = blocks
+        assert np.array_equal(got, quant), name
