@@ -158,7 +158,8 @@ typedef struct jpeg_decode_ctx_vtbl {
  * image, free at exit.  Stages: QUANT and DCT fill img->coef on the host (same
  * bytes as the reference, src/xjpeg.c:550-563); YUV fills every
  * img->plane[i].data and RGB fills img->pixels, both computed on the GPU.
- * PACK is rejected with "Unsupported output 'pack' for hipjpeg wrapper.". */
+ * PACK fills img->coef with the RLE words, img->index with the block starts and
+ * sets plane[i].packed / img->packed (src/xjpeg.c:484-496, 513-519, 531-535). */
 extern const jpeg_decode_ctx_vtbl HIPJPEG_DECODE_CTX_VTBL;
 
 /* ------------------------------------------------------------------------ */
@@ -253,6 +254,13 @@ int jga_idct_yuv_batch(const jga_geom *g, int nimages,
  const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
  int dequant_on_device, unsigned char *d_yuv, long long yuv_stride,
  void *stream);
+/* Pass 3 alone: YUV-stage planes resident in HBM (layout of d_yuv above) ->
+ * RGB (layout of d_rgb above).  The reference's res/yuv.fs.glsl:16-24 /
+ * res/unyuv.fs.glsl:12-16, 29-31, 39-41, 48 on u8 planes, for callers that stop
+ * the decode at JPEG_DECODE_YUV.  Same results as jga_idct_rgb_batch. */
+int jga_yuv_rgb_batch(const jga_geom *g, int nimages,
+ const unsigned char *d_yuv, long long yuv_stride, unsigned char *d_rgb,
+ long long rgb_stride, void *stream);
 /* PACK wire format expanded on the device: the words and
  * per-block start indices produced by jga_entropy_decode_pack() (reference
  * producer src/xjpeg.c:484-496, 513-519, 531-535), resident in HBM, become the

@@ -6,6 +6,8 @@
                         the emitted ISA is checked for fused multiply-adds
                         (FMA contraction changes results).
     libjga_synth.so     synthetic-JPEG writer used by tests and bench.py.
+    jpeg_gpu_hip        headless harness with the reference program's options
+                        (csrc/harness.c, plain C over the C-ABI).
 
 Usage: python -m jpeg_gpu_amd.build [--force]
 """
@@ -27,6 +29,7 @@ CXX_SOURCES = ["device_api.cpp", "vtbl.cpp", "pipeline.cpp", "huff_prepare.cpp",
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 LIB = os.path.join(HERE, "libjpeg_gpu_amd.so")
 SYNTH_LIB = os.path.join(HERE, "libjga_synth.so")
+HARNESS = os.path.join(HERE, "jpeg_gpu_hip")            # headless harness (csrc/harness.c)
 
 FMA_RE = re.compile(r"^\s+(v_fma\w*|v_fmac\w*|v_mad_f32\w*|v_mac_f32\w*|v_pk_fma\w*|v_mad_legacy\w*)\b",
                     re.M)
@@ -77,6 +80,7 @@ def build(force=False, verbose=False):
               "-fvisibility=hidden", "-o", SYNTH_LIB, synth_src, "-lm"])
 
     if not force and _newer(LIB, all_src):
+        _build_harness(force)
         return LIB
     hipcc = _hipcc()
     objs = []
@@ -114,7 +118,16 @@ def build(force=False, verbose=False):
                 print("ISA check ok: %s (%d bytes, no fma)" % (os.path.basename(asm), n))
     _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs +
          ["-lpthread"])
+    _build_harness(True)
     return LIB
+
+
+def _build_harness(force):
+    src = os.path.join(CSRC, "harness.c")
+    if force or not _newer(HARNESS, [src, LIB]):
+        _run(["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", "-o", HARNESS, src,
+              "-L" + HERE, "-ljpeg_gpu_amd", "-Wl,-rpath,$ORIGIN",
+              "-Wl,-rpath," + os.path.join(ROCM, "lib")])
 
 
 if __name__ == "__main__":

@@ -131,6 +131,43 @@ JGA_EXPORT int jga_idct_yuv_batch(const jga_geom *g, int nimages,
   return EXIT_SUCCESS;
 }
 
+JGA_EXPORT int jga_yuv_rgb_batch(const jga_geom *g, int nimages,
+ const unsigned char *d_yuv, long long yuv_stride, unsigned char *d_rgb,
+ long long rgb_stride, void *stream) {
+  jga_kparams P;
+  int rc, p;
+  memset(&P, 0, sizeof(P));
+  if (nimages < 1) return jga_fail("Invalid batch size %d", nimages);
+  if (g->nplanes != 1 && g->nplanes != 3) {
+    return jga_fail("Unsupported number of components %i", g->nplanes);
+  }
+  if (g->nplanes == 3 && (g->plane[0].xdec || g->plane[0].ydec
+   || g->plane[1].xdec != g->plane[2].xdec
+   || g->plane[1].ydec != g->plane[2].ydec)) {
+    return jga_fail("Unsupported sampling for the device stage");
+  }
+  if (yuv_stride < g->yuv_bytes) return jga_fail("yuv_stride too small");
+  if (rgb_stride < g->rgb_bytes) return jga_fail("rgb_stride too small");
+  P.coef = (const int16_t *)d_yuv;
+  P.coef_stride = yuv_stride;
+  P.out = d_rgb;
+  P.out_stride = rgb_stride;
+  P.nimages = nimages;
+  P.nplanes = g->nplanes;
+  P.width = g->width;
+  P.height = g->height;
+  for (p = 0; p < g->nplanes; p++) {
+    P.plane_hblocks[p] = g->plane[p].hblocks;
+    P.plane_data_off[p] = g->plane[p].data_off;
+  }
+  P.out_aligned = (((long long)g->width*3) % 4 == 0) && (rgb_stride % 4 == 0)
+   && (((uintptr_t)d_rgb) % 4 == 0);
+  rc = jga_launch_yuv_rgb(&P, g->nplanes == 3 ? g->plane[1].xdec : 0,
+   g->nplanes == 3 ? g->plane[1].ydec : 0, stream);
+  if (rc) return jga_fail("YUV->RGB kernel launch failed (HIP error %d)", rc);
+  return EXIT_SUCCESS;
+}
+
 JGA_EXPORT long long jga_index_count(const jga_geom *g) {
   long long n = 0;
   for (int p = 0; p < g->nplanes; p++) {

@@ -554,6 +554,54 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
   }
 }
 
+// Pass 3 on its own (the reference's "simple twin", res/yuv.fs.glsl:16-24 = the
+// matrix of res/unyuv.fs.glsl:12-16, 48 on u8 planes): Y/Cb/Cr planes resident in HBM
+// (YUV-stage layout: planes at plane_data_off, padded, pitch = plane width) ->
+// img->pixels.  Used when a caller stops the decode at the YUV stage (the harness's
+// `-o yuv`).  SURVEY.md A.5 arithmetic, evaluated literally.  One thread = 4 pixels
+// of one row; HBM-bound: reads 1 + 2/(LW*LH) bytes, writes 3 bytes per pixel.
+DEV uint32_t unorm8(float c) {
+  const float m = __builtin_fminf(__builtin_fmaxf(c, 0.0f), 255.0f);
+  return (uint32_t)(int)(m + 0.5f);
+}
+
+__global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, int xdec, int ydec) {
+  const int x0 = (blockIdx.x*256 + threadIdx.x)*4;
+  const int y = blockIdx.y, img = blockIdx.z;
+  if (x0 >= P.width) return;
+  const uint8_t *base = P.coef ? reinterpret_cast<const uint8_t *>(P.coef) + (long long)img*P.coef_stride : nullptr;
+  const uint8_t *py = base + P.plane_data_off[0] + (long long)y*(P.plane_hblocks[0]*8) + x0;
+  const int n = P.width - x0 < 4 ? P.width - x0 : 4;
+  if (P.nplanes == 1) {
+    uint8_t *o = P.out + (long long)img*P.out_stride + (long long)y*P.width + x0;
+    for (int i = 0; i < n; i++) o[i] = py[i];
+    return;
+  }
+  const uint8_t *pu = base + P.plane_data_off[1] + (long long)(y >> ydec)*(P.plane_hblocks[1]*8);
+  const uint8_t *pv = base + P.plane_data_off[2] + (long long)(y >> ydec)*(P.plane_hblocks[2]*8);
+  uint32_t px[12];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    // plane rows are padded to whole blocks, so x0+i stays inside the row
+    const float Y = (float)py[i];
+    const float u = (float)pu[(x0 + i) >> xdec] - 128.0f;
+    const float v = (float)pv[(x0 + i) >> xdec] - 128.0f;
+    px[3*i + 0] = unorm8(Y + 1.402f*v);
+    px[3*i + 1] = unorm8((Y + (-0.34414f)*u) + (-0.71414f)*v);
+    px[3*i + 2] = unorm8(Y + 1.772f*u);
+  }
+  uint8_t *o = P.out + (long long)img*P.out_stride + ((long long)y*P.width + x0)*3;
+  if (n == 4 && P.out_aligned) {
+    uint32_t *o4 = reinterpret_cast<uint32_t *>(o);
+    o4[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    o4[1] = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
+    o4[2] = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
+  }
+  else {
+    for (int i = 0; i < 3*n; i++) o[i] = (uint8_t)px[i];
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Host-side launch table (C++ linkage inside the library; the C-ABI wrappers
 // live in device_api.cpp).
@@ -596,6 +644,13 @@ extern "C" int jga_launch_yuv(const jga_kparams *P, int staged, void *stream) {
   if (P->dequant) { if (staged) JGA_YUV_LAUNCH(true, true); else JGA_YUV_LAUNCH(true, false); }
   else { if (staged) JGA_YUV_LAUNCH(false, true); else JGA_YUV_LAUNCH(false, false); }
 #undef JGA_YUV_LAUNCH
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int jga_launch_yuv_rgb(const jga_kparams *P, int xdec, int ydec, void *stream) {
+  dim3 grid((P->width + 1023)/1024, P->height, P->nimages), block(256);
+  hipLaunchKernelGGL(jga_yuv_rgb_kernel, grid, block, 0, (hipStream_t)stream, *P, xdec, ydec);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

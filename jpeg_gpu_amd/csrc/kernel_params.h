@@ -42,6 +42,8 @@ extern "C" {
 int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec, int staged,
  void *stream);
 int jga_launch_yuv(const jga_kparams *P, int staged, void *stream);
+/* P->coef = the YUV-stage bytes (as int16*), coef_stride in BYTES */
+int jga_launch_yuv_rgb(const jga_kparams *P, int xdec, int ydec, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ EXPORTED = [
     "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",
     "jga_parse_header", "jga_entropy_decode", "jga_entropy_decode_pack",
     "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_kernel_name",
-    "jga_index_count", "jga_unpack_batch",
+    "jga_index_count", "jga_unpack_batch", "jga_yuv_rgb_batch",
     "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
     "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
     "jga_stream_sync", "jga_set_device", "jga_stream_create", "jga_stream_destroy",
@@ -65,6 +65,7 @@ L.jga_entropy_decode_pack.argtypes = [C.c_char_p, _i, _G, _vp, _ll, _vp,
                                       C.POINTER(_ll), C.POINTER(_ll)]
 L.jga_idct_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
 L.jga_idct_yuv_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+L.jga_yuv_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp]
 L.jga_index_count.argtypes = [_G]
 L.jga_index_count.restype = _ll
 L.jga_unpack_batch.argtypes = [_G, _i, _vp, _ll, _ll, _vp, _ll, _vp, _ll, _vp]

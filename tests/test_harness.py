@@ -1,0 +1,138 @@
+"""The headless harness jpeg_gpu_hip (csrc/harness.c) against the reference program's
+command-line behaviour (src/jpeg_gpu.c:473-506, 508-606, 610-704): option handling,
+`--header` text, `--dump` text per stage, and the steady-state loop finishing every `-o`
+stage on the device."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "jpeg_gpu_amd", "jpeg_gpu_hip")
+SUBSAMP = ["Unknown", "4:4:4", "4:2:2", "4:2:0", "4:4:0", "4:1:1", "Mono"]
+
+
+def run(*args, ok=True):
+    r = subprocess.run([EXE] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300, env=dict(os.environ, JGA_QUIET="0"))
+    if ok:
+        assert r.returncode == 0, r.stderr
+    return r
+
+
+@pytest.fixture()
+def jpg(tmp_path, synth):
+    def make(*a, **k):
+        data = synth.synthetic_jpeg(*a, **k)
+        p = tmp_path / ("t%d.jpg" % len(list(tmp_path.iterdir())))
+        p.write_bytes(data)
+        return str(p), data
+    return make
+
+
+def numbers(text):
+    """`Plane i` sections of a --dump -> list of int arrays (row-major)."""
+    planes = []
+    for sec in text.split("Plane ")[1:]:
+        rows = [l for l in sec.split("\n")[1:] if l.strip()]
+        planes.append(np.array([[int(v) for v in l.split()] for l in rows]))
+    return planes
+
+
+def test_usage_and_bad_options(jpg):
+    path, _ = jpg(16, 16, "444")
+    r = run(ok=False)
+    assert r.returncode == 1 and r.stderr.startswith("Usage: jpeg_gpu_hip [options] jpeg_file")
+    r = run("-h", ok=False)
+    assert r.returncode == 1 and "--no-cpu" in r.stderr and "--header" in r.stderr
+    r = run("-i", "nope", path, ok=False)
+    assert r.returncode == 1 and r.stderr.startswith("Invalid decoder implementation: nope\n")
+    r = run("-o", "jpeg", path, ok=False)
+    assert r.returncode == 1 and r.stderr.startswith("Invalid decoder output format: jpeg\n")
+    r = run("/nonexistent.jpg", ok=False)
+    assert r.returncode == 1 and "Error, could not open jpeg file /nonexistent.jpg" in r.stderr
+
+
+@pytest.mark.parametrize("sampling", ["grey", "444", "422", "420", "440", "411"])
+def test_header_text(jpg, lib, sampling):
+    """Byte-for-byte the text of src/jpeg_gpu.c:614-637."""
+    path, data = jpg(123, 77, sampling, quality=60, restart_interval=5)
+    h = lib.parse_header(data)
+    want = ["Image Size         : %ix%i" % (h.width, h.height),
+            "Bits Per Pixel     : %i" % h.bits,
+            "Components         : %i" % h.ncomps,
+            "Chroma Subsampling : %s" % SUBSAMP[h.subsamp],
+            "Minimum Coded Unit : " + " ".join("%ix%i" % (h.comp[i].hsamp, h.comp[i].vsamp)
+                                               for i in range(h.ncomps)),
+            "Restart Interval   : %i" % h.restart_interval]
+    for i in range(4):
+        if h.quant[i].valid:
+            want.append("Quant Table %i Bits : %i" % (i, h.quant[i].bits))
+            t = list(h.quant[i].tbl)
+            want += ["".join("%4i" % v for v in t[r * 8:r * 8 + 8]) for r in range(8)]
+    for flag in ("-H", "--header"):
+        assert run(flag, path).stdout == "\n".join(want) + "\n"
+
+
+def test_dump_host_stages(jpg, lib, golden_jpegs, tmp_path):
+    """pack / quant / dct dumps (host stages: no device needed)."""
+    for name in golden_jpegs.names:
+        p = tmp_path / (name + ".jpg")
+        p.write_bytes(golden_jpegs.jpeg(name))
+        _, g = lib.geom_of(golden_jpegs.jpeg(name))
+        _, _, per = lib.entropy_decode_pack(golden_jpegs.jpeg(name), g)
+        want = "".join("Plane %i Packed Data: %i\n" % (i, per[i]) for i in range(g.nplanes))
+        want += "Packed Data : %i\n" % len(golden_jpegs[name + ".pack"])
+        assert run("--dump", "-o", "pack", str(p)).stdout == want, name
+        for stage in ("quant", "dct"):
+            planes = numbers(run("-d", "-o", stage, str(p)).stdout)
+            assert len(planes) == g.nplanes
+            coef = golden_jpegs["%s.%s" % (name, stage)]      # from the compiled reference
+            for i, got in enumerate(planes):
+                pl = g.plane[i]
+                w, hgt = pl.hblocks * 8, pl.vblocks * 8
+                assert got.shape == (hgt, w)
+                # the reference prints the plane's share of the buffer linearly
+                assert np.array_equal(got.ravel(), coef[pl.coef_off:pl.coef_off + w * hgt]), name
+
+
+def test_no_gpu_loop_prints_statistics(jpg):
+    path, _ = jpg(64, 48, "420")
+    out = run("--no-gpu", "-o", "quant", "--frames", "25", path).stdout
+    assert out.startswith("25 FPS (cpu ") and "gpu 0.000 ms" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampling", ["grey", "444", "420", "411"])
+def test_dump_device_stages(gpu, orc, jpg, sampling):
+    import oracle
+    path, data = jpg(100, 75, sampling, quality=85, restart_interval=3)
+    info, planes = orc.decode(data, oracle.YUV)
+    got = numbers(run("--dump", path).stdout)                 # -o yuv is the default
+    assert len(got) == info.ncomps
+    for a, b in zip(got, planes):
+        assert np.array_equal(a, b)
+    _, rgb = orc.decode_rgb(data)
+    got = numbers(run("-d", "-o", "rgb", path).stdout)
+    nc = info.ncomps
+    want = rgb.reshape(75, 100, nc)
+    for i in range(nc):
+        assert np.array_equal(got[i], want[:, :, i]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["pack", "quant", "dct", "yuv", "rgb"])
+@pytest.mark.parametrize("sampling", ["420", "444", "grey"])
+def test_main_loop_finishes_every_stage_on_the_device(gpu, orc, jpg, stage, sampling):
+    """Whatever stage the host stops at, the RGB left in HBM is the oracle's."""
+    path, data = jpg(333, 211, sampling, quality=90)
+    _, rgb = orc.decode_rgb(data)
+    out = run("-o", stage, "--frames", "3", "--check", path).stdout.strip().split("\n")
+    assert out[0].startswith("3 FPS (cpu ")
+    nc = 1 if sampling == "grey" else 3
+    assert out[-1] == "RGB 333x211x%d adler32 %08x" % (nc, zlib.adler32(rgb.tobytes())), out
+    # --no-cpu: the first decode is kept and the device still finishes it
+    out = run("-o", stage, "--no-cpu", "--frames", "2", "--check", path).stdout.strip().split("\n")
+    assert out[-1].endswith("%08x" % zlib.adler32(rgb.tobytes()))
