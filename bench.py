@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=6, help="distinct synthetic images")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the supplementary e2e leg")
+    ap.add_argument("--no-pack", action="store_true", help="skip the PACK expansion leg")
     ap.add_argument("--e2e-images", type=int, default=96)
     ap.add_argument("--e2e-threads", type=int, default=0, help="0 = min(cores, 48)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -237,19 +238,20 @@ def main():
         n = args.e2e_images
         e2e = {}
         nthr = args.e2e_threads or max(1, min(os.cpu_count() or 1, 48))
-        for copy_back, transport in ((False, 0), (True, 0), (False, 1)):
-            pl = lib.Pipeline(device=local_rank, nthreads=nthr,
-                              out=abi.JPEG_DECODE_RGB, copy_back=copy_back, transport=transport)
+        for copy_back, transport in ((False, 0), (True, 0), (False, 1), (False, 2)):
+            pl = lib.Pipeline(device=local_rank, nthreads=nthr, out=abi.JPEG_DECODE_RGB,
+                              copy_back=copy_back, transport=transport, batch=16, depth=3)
             jobs = [jpegs[i % len(jpegs)] for i in range(n)]
             outs = [np.empty(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
-            pl.run(jobs[:16], host_outs=outs[:16] if outs else None)   # warm: slots, pages
+            nw = 48 if transport == 2 else 16                          # warm: slots/lanes, pages
+            pl.run(jobs[:nw], host_outs=outs[:nw] if outs else None)
             t0 = time.perf_counter()
             rc, done = pl.run(jobs, host_outs=outs)
             te = time.perf_counter() - t0
             pl.close()
             key = "jpeg_host_to_rgb_host" if copy_back else "jpeg_host_to_rgb_hbm"
             if transport:
-                key += "_pack_transport"
+                key += ("", "_pack_transport", "_gpu_entropy")[transport]
             e2e[key] = {"value": round(n * W * H / te / 1e6, 1), "unit": "Mpixel/s",
                         "images": n, "ok": rc == 0,
                         "h2d_bytes_per_image": int(sum(j.h2d_bytes for j in done) // n)}
@@ -258,7 +260,7 @@ def main():
                       "PCIe- and host-inclusive, not `value`"
         out["e2e"] = e2e
 
-    if rank == 0 and world == 1 and not args.no_e2e:
+    if rank == 0 and world == 1 and not args.no_pack:
         # Supplementary: PACK words + block index resident in HBM ->
         # jga_unpack_kernel -> QUANT planes.  Algorithmic bytes: 2 B/word + 4 B/block read,
         # 128 B/block written.

@@ -313,7 +313,11 @@ typedef struct jga_pipeline_config {
   long long max_coef_shorts;   /* slot capacity (0 = sized on first submit) */
   long long max_out_bytes;
   int transport;               /* what crosses PCIe: 0 = dense QUANT planes,
-                                * 1 = PACK words + block index, expanded by jga_unpack_batch */
+                                * 1 = PACK words + block index, expanded by jga_unpack_batch,
+                                * 2 = the entropy-coded bytes: no host Huffman, jga_huff_* on
+                                *     the GPU (depth = lanes in flight, default 3) */
+  int batch;                   /* transport 2: images per GPU entropy batch (0 = 16); a group
+                                * must share one geometry, otherwise it is decoded one by one */
 } jga_pipeline_config;
 
 typedef struct jga_job {
@@ -349,6 +353,8 @@ int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
 long long jga_huff_upload_bytes(const jga_huff_batch *b);
 int jga_huff_last_rounds(const jga_huff_batch *b);
 const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
+/* Host threads prepare() fans out over (0 = one per image, at most 64). */
+void jga_huff_set_threads(jga_huff_batch *b, int nthreads);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -82,7 +82,7 @@ class jga_pipeline_config(C.Structure):
     _fields_ = [("device", C.c_int), ("nthreads", C.c_int), ("depth", C.c_int),
                 ("out", C.c_int), ("copy_back", C.c_int),
                 ("max_coef_shorts", C.c_longlong), ("max_out_bytes", C.c_longlong),
-                ("transport", C.c_int)]
+                ("transport", C.c_int), ("batch", C.c_int)]
 
 
 class jga_job(C.Structure):

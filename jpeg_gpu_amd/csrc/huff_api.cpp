@@ -23,7 +23,7 @@ struct jga_huff_batch {
   int max_images;
   long long max_scan;
   // host staging (pinned)
-  unsigned char *h_blob;       // images | segs | sub_seg | tables | S | scan, one upload
+  unsigned char *h_blob;       // scan | images | segs | sub_seg | tables | S, one upload
   size_t blob_cap;
   // device
   unsigned char *d_blob;
@@ -37,7 +37,8 @@ struct jga_huff_batch {
   // current batch
   int nimages;
   uint32_t total_sub, total_seg, max_nsub;
-  size_t off_images, off_segs, off_subseg, off_tables, off_S, off_scan, blob_size;
+  size_t off_images, off_segs, off_subseg, off_tables, off_S, off_scan, blob_size, scan_bytes;
+  int prepare_threads;
   jga_geom geom;
   std::vector<unsigned short> qtab;
   int last_rounds;
@@ -88,96 +89,160 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   delete b;
 }
 
+// A team of threads that runs a few phases over the images of a batch, with a barrier
+// and a short serial section (thread 0) between phases: one spawn per prepare().
+namespace {
+struct phase_barrier {
+  std::atomic<int> count{0}, gen{0};
+  int n = 1;
+  void wait() {
+    const int g = gen.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      count.store(0, std::memory_order_relaxed);
+      gen.fetch_add(1, std::memory_order_release);
+    }
+    else {
+      while (gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+    }
+  }
+};
+}  // namespace
+
 // Parse + stage a batch.  All images must share one geometry (returned in *geom).
+// Host work per image (marker parse, table build, unstuffing straight into the pinned
+// upload buffer, lane start states) is independent and fanned out over a thread team.
 JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *jpegs,
  const int *sizes, int n, jga_geom *geom, void *stream) {
   if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
   std::vector<hj_prepared> prep((size_t)n);
-  size_t total_sub = 0, total_seg = 0, total_scan = 0;
-  uint32_t max_nsub = 0;
-  {
-    // per-image host work (marker parse, table build, unstuffing) is independent: fan out
-    std::atomic<int> next(0), failed(0);
+  std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
+  std::atomic<int> next_a(0), next_b(0), next_c(0), failed(0);
+  std::atomic<int> fatal(0);       // set by the serial sections: 1 geometry, 2 capacity
+  std::atomic<int> stop(0);        // decided in a serial section, read after the next barrier
+  phase_barrier bar;
+  int nt = b->prepare_threads;
+  if (nt <= 0) {
     unsigned hw = std::thread::hardware_concurrency();
-    int nt = (int)(hw ? hw : 4);
-    if (nt > n) nt = n;
+    nt = (int)(hw ? hw : 4);
     if (nt > 64) nt = 64;
-    auto work = [&]() {
-      for (;;) {
-        const int i = next.fetch_add(1);
-        if (i >= n) break;
-        if (hj_prepare_image(jpegs[i], sizes[i], &prep[i]) != EXIT_SUCCESS) failed.fetch_add(1);
-      }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto &th : pool) th.join();
-    if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
   }
-  for (int i = 0; i < n; i++) {
-    if (i && (prep[i].geom.coef_shorts != prep[0].geom.coef_shorts
-     || prep[i].geom.width != prep[0].geom.width || prep[i].geom.height != prep[0].geom.height
-     || prep[i].geom.subsamp != prep[0].geom.subsamp)) {
-      return jga_fail("huff: images of one batch must share a geometry");
-    }
-    total_sub += prep[i].im.nsub;
-    total_seg += prep[i].segs.size();
-    total_scan += align_up(prep[i].scan_len + 16, 16);
-    if (prep[i].im.nsub > max_nsub) max_nsub = prep[i].im.nsub;
-  }
-  if (total_sub > b->sub_cap || total_seg > b->sub_cap || (long long)total_scan > b->max_scan + 64ll*n) {
-    return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
-  }
-  b->nimages = n;
-  b->total_sub = (uint32_t)total_sub;
-  b->total_seg = (uint32_t)total_seg;
-  b->max_nsub = max_nsub;
-  b->geom = prep[0].geom;
-  size_t o = 0;
-  b->off_images = o; o += align_up(sizeof(hj_image)*n, 256);
-  b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
-  b->off_subseg = o; o += align_up(4*total_sub, 256);
-  b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
-  b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
-  b->off_scan = o; o += align_up(total_scan, 256);
-  b->blob_size = o;
-  hj_image *images = (hj_image *)(b->h_blob + b->off_images);
-  hj_segment *segs = (hj_segment *)(b->h_blob + b->off_segs);
-  uint32_t *sub_seg = (uint32_t *)(b->h_blob + b->off_subseg);
-  hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
-  uint64_t *S = (uint64_t *)(b->h_blob + b->off_S);
-  unsigned char *scan = b->h_blob + b->off_scan;
+  if (nt > n) nt = n;
+  bar.n = nt;
   b->qtab.assign((size_t)n*192, 0);
-  uint32_t sub0 = 0, seg0 = 0, scan_off = 0;
-  for (int i = 0; i < n; i++) {
-    hj_prepared &p = prep[i];
-    p.im.sub0 = sub0;
-    p.im.seg0 = seg0;
-    p.im.scan_off = scan_off;
-    images[i] = p.im;
-    tables[i] = p.tabs;
-    memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
-    memcpy(scan + scan_off, p.clean.data(), p.scan_len);
-    memset(scan + scan_off + p.scan_len, 0xFF, align_up(p.scan_len + 16, 16) - p.scan_len);
-    for (size_t si = 0; si < p.segs.size(); si++) {
-      const hj_segment &sg = p.segs[si];
-      segs[seg0 + si] = sg;
-      for (uint32_t k = 0; k < sg.nsub; k++) {
-        sub_seg[sub0 + sg.sub0 + k] = (uint32_t)si;
-        const uint32_t byte = sg.start + k*HJ_SUB_BYTES; // guess: a symbol starts on this byte
-        S[sub0 + seg0 + sg.sub0 + si + k] = hj_pack((uint64_t)byte*8, 0, 0);
-      }
-      S[sub0 + seg0 + sg.sub0 + si + sg.nsub] = 0;
+  auto work = [&](int tid) {
+    // phase A: headers, tables
+    for (;;) {
+      const int i = next_a.fetch_add(1);
+      if (i >= n) break;
+      if (hj_prepare_head(jpegs[i], sizes[i], &prep[i]) != EXIT_SUCCESS) failed.fetch_add(1);
     }
-    sub0 += p.im.nsub;
-    seg0 += (uint32_t)p.segs.size();
-    scan_off += (uint32_t)align_up(p.scan_len + 16, 16);
+    bar.wait();
+    if (tid == 0 && failed.load()) stop.store(1);
+    if (tid == 0 && !failed.load()) {
+      size_t o = 0;
+      for (int i = 0; i < n; i++) {
+        if (i && (prep[i].geom.coef_shorts != prep[0].geom.coef_shorts
+         || prep[i].geom.width != prep[0].geom.width || prep[i].geom.height != prep[0].geom.height
+         || prep[i].geom.subsamp != prep[0].geom.subsamp)) {
+          fatal.store(1);
+        }
+        scan_off[i] = (uint32_t)o;
+        o += align_up((size_t)prep[i].avail + 16, 16);
+      }
+      if ((long long)o > b->max_scan + 64ll*n) fatal.store(2);
+      b->off_scan = 0;
+      b->scan_bytes = align_up(o, 256);
+      if (fatal.load()) stop.store(1);
+    }
+    bar.wait();
+    if (stop.load()) return;
+    // phase B: clean scan bytes straight into the pinned blob, restart segments
+    for (;;) {
+      const int i = next_b.fetch_add(1);
+      if (i >= n) break;
+      if (hj_prepare_scan(jpegs[i], sizes[i], &prep[i], b->h_blob + scan_off[i]) != EXIT_SUCCESS) {
+        failed.fetch_add(1);
+      }
+    }
+    bar.wait();
+    if (tid == 0 && failed.load()) stop.store(1);
+    if (tid == 0 && !failed.load()) {
+      size_t total_sub = 0, total_seg = 0;
+      uint32_t max_nsub = 0;
+      for (int i = 0; i < n; i++) {
+        sub0v[i] = (uint32_t)total_sub;
+        seg0v[i] = (uint32_t)total_seg;
+        total_sub += prep[i].im.nsub;
+        total_seg += prep[i].segs.size();
+        if (prep[i].im.nsub > max_nsub) max_nsub = prep[i].im.nsub;
+      }
+      if (total_sub > b->sub_cap || total_seg > b->sub_cap) fatal.store(2);
+      b->nimages = n;
+      b->total_sub = (uint32_t)total_sub;
+      b->total_seg = (uint32_t)total_seg;
+      b->max_nsub = max_nsub;
+      b->geom = prep[0].geom;
+      size_t o = b->scan_bytes;
+      b->off_images = o; o += align_up(sizeof(hj_image)*n, 256);
+      b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
+      b->off_subseg = o; o += align_up(4*total_sub, 256);
+      b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
+      b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
+      b->blob_size = o;
+      if (o > b->blob_cap) fatal.store(2);
+      if (fatal.load()) stop.store(1);
+    }
+    bar.wait();
+    if (stop.load()) return;
+    // phase C: descriptors, tables, lane start states of each image
+    hj_image *images = (hj_image *)(b->h_blob + b->off_images);
+    hj_segment *segs = (hj_segment *)(b->h_blob + b->off_segs);
+    uint32_t *sub_seg = (uint32_t *)(b->h_blob + b->off_subseg);
+    hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
+    uint64_t *S = (uint64_t *)(b->h_blob + b->off_S);
+    for (;;) {
+      const int i = next_c.fetch_add(1);
+      if (i >= n) break;
+      hj_prepared &p = prep[i];
+      const uint32_t sub0 = sub0v[i], seg0 = seg0v[i];
+      p.im.sub0 = sub0;
+      p.im.seg0 = seg0;
+      p.im.scan_off = scan_off[i];
+      images[i] = p.im;
+      tables[i] = p.tabs;
+      memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
+      for (size_t si = 0; si < p.segs.size(); si++) {
+        const hj_segment &sg = p.segs[si];
+        segs[seg0 + si] = sg;
+        for (uint32_t k = 0; k < sg.nsub; k++) {
+          sub_seg[sub0 + sg.sub0 + k] = (uint32_t)si;
+          const uint32_t byte = sg.start + k*HJ_SUB_BYTES; // guess: a symbol starts on this byte
+          S[sub0 + seg0 + sg.sub0 + si + k] = hj_pack((uint64_t)byte*8, 0, 0);
+        }
+        S[sub0 + seg0 + sg.sub0 + si + sg.nsub] = 0;
+      }
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
   }
+  b->nimages = 0;
+  if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
+  if (fatal.load() == 1) return jga_fail("huff: images of one batch must share a geometry");
+  if (fatal.load()) return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
+  b->nimages = n;
+  // the scan region is sized from the raw lengths; the bytes between an image's clean
+  // stream (+16 pad) and the next image's start are never read
   HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->blob_size, hipMemcpyHostToDevice, (hipStream_t)stream));
   if (geom) *geom = b->geom;
   return EXIT_SUCCESS;
 }
+
+// Host threads prepare() may use (0 = up to 64, one per image).
+JGA_EXPORT void jga_huff_set_threads(jga_huff_batch *b, int nthreads) { b->prepare_threads = nthreads; }
 
 // Bytes uploaded by the last prepare() (tables + states + compressed scan data).
 JGA_EXPORT long long jga_huff_upload_bytes(const jga_huff_batch *b) { return (long long)b->blob_size; }
@@ -226,12 +291,16 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
   HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, st));
   int round = 0;
-  static int it0 = -1, it1 = -1, group = -1;
+  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16;
   if (it0 < 0) {
     const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group" (tuning knob)
     it0 = 3; it1 = 2; group = 6;
     if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
+    e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching (tuning knob)
+    if (e) flush_lanes = atoi(e);
+    if (flush_lanes < 1) flush_lanes = 1;
   }
+  A.flush_lanes = flush_lanes;
   const int GROUP = group;
   for (;;) {
     for (int k = 0; k < GROUP && round < HJ_MAX_ROUNDS; k++, round++) {

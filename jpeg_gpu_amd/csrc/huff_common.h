@@ -252,6 +252,13 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
 //       last coefficient was decoded here, `head` = its first one was too (so the
 //       buffer holds the whole block iff complete && head); the buffer must be
 //       zero again afterwards
+//   out.any(x)                          does any lane of the wave have x? (host: x)
+//   out.flush_due(waiting, running)     wave-uniform: write the waiting lanes' blocks now?
+// Writing a block out costs far more instructions than decoding a symbol, and in a wave
+// every lane pays for every instruction any lane executes.  So a lane that completes a
+// block does not write it at once: it WAITS (decodes nothing) until the wave decides
+// that enough lanes are waiting, and then all of them write together — the write-out
+// code runs once per several symbols instead of once per symbol.
 // DC values are integrated from `pred` (predictors at the start of the run).
 template <class Src, class Out>
 HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T,
@@ -262,36 +269,43 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
   const int nslots = im.nslots;
   hj_reader<Src> br;
   int k = hj_k(start), c = hj_slot(start), error = 0;
-  bool head = k == 0;
+  bool head = k == 0, waiting = false;
   uint32_t n = 0;
   br.init(src, hj_pos(start));
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
-  while (br.tell() < stop_bit && n < max_blocks) {
-    const uint32_t w = br.window();
-    const int isdc = k == 0;
-    const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
-    const int len = (int)(e >> 8), sym = (int)(e & 255u), s = sym & 15;
-    int v = hj_value(w, len, s);
-    br.skip(len + s);
-    if (isdc) {
-      pred0 += comp == 0 ? v : 0;
-      pred1 += comp == 1 ? v : 0;
-      pred2 += comp == 2 ? v : 0;
-      v = (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);    // wraps like xjpeg.c:480
+  for (;;) {
+    const bool running = !waiting && br.tell() < stop_bit && n < max_blocks;
+    if (!out.any(running || waiting)) break;
+    if (running) {
+      const uint32_t w = br.window();
+      const int isdc = k == 0;
+      const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
+      const int len = (int)(e >> 8), sym = (int)(e & 255u), s = sym & 15;
+      int v = hj_value(w, len, s);
+      br.skip(len + s);
+      if (isdc) {
+        pred0 += comp == 0 ? v : 0;
+        pred1 += comp == 1 ? v : 0;
+        pred2 += comp == 2 ? v : 0;
+        v = (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);    // wraps like xjpeg.c:480
+      }
+      const int kk = isdc ? 0 : k + (sym >> 4);            // zig-zag index of this coefficient
+      if (kk > 63) error = 1;
+      else if (isdc || s) out.put(dezz[kk], v);
+      const int kn = isdc ? 1 : (sym ? kk + 1 : 64);
+      waiting = kn >= 64;                                  // block complete: wait for the write-out
+      k = waiting ? 0 : kn;
     }
-    const int kk = isdc ? 0 : k + (sym >> 4);              // zig-zag index of this coefficient
-    if (kk > 63) error = 1;
-    else if (isdc || s) out.put(dezz[kk], v);
-    const int kn = isdc ? 1 : (sym ? kk + 1 : 64);
-    if (kn >= 64) {
-      out.flush(n, c, true, head);
-      n++;
-      c = c + 1 == nslots ? 0 : c + 1;
-      comp = (int)((slot_comp_bits >> (2*c)) & 3u);
-      k = 0;
-      head = true;
+    if (out.flush_due(waiting, running && !waiting)) {
+      if (waiting) {
+        out.flush(n, c, true, head);
+        n++;
+        c = c + 1 == nslots ? 0 : c + 1;
+        comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+        head = true;
+        waiting = false;
+      }
     }
-    else k = kn;
   }
   if (k != 0 && n < max_blocks) out.flush(n, c, false, head);   // a later lane finishes this block
   return error;

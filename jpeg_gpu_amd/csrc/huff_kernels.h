@@ -21,6 +21,7 @@ typedef struct hj_args {
   int16_t *coef;               /* image i at coef + i*coef_stride */
   long long coef_stride;
   int nimages;
+  int flush_lanes;             /* finished blocks a wave collects before writing them out */
 } hj_args;
 
 #ifdef __cplusplus

@@ -282,6 +282,13 @@ struct hj_block_out {
   int16_t *coef;
   uint32_t *blk;                     // this lane's 32-dword LDS buffer (zero between blocks)
   uint32_t mcu0, b0;
+  int flush_lanes;
+  __device__ __forceinline__ bool any(bool x) const { return __ballot(x) != 0ull; }
+  // Write out when HJ_FLUSH_LANES lanes hold a finished block, or when nobody can decode on.
+  __device__ __forceinline__ bool flush_due(bool waiting, bool running) const {
+    const unsigned long long w = __ballot(waiting);
+    return w != 0ull && (__popcll(w) >= flush_lanes || __ballot(running) == 0ull);
+  }
   __device__ __forceinline__ void put(int idx, int v) {
     reinterpret_cast<hj_i16_alias *>(blk)[idx] = (int16_t)v;
   }
@@ -341,6 +348,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   out.coef = A.coef + (long long)blockIdx.y*A.coef_stride;
   out.blk = blk;
   out.mcu0 = L.seg_mcu0; out.b0 = b0;
+  out.flush_lanes = A.flush_lanes;
   const int err = hj_write_decode(src, im, &lds_tabs, s_dezz,
    start, stop, total - b0, A.D[3*L.g + 0], A.D[3*L.g + 1], A.D[3*L.g + 2], out);
   if (err) atomicOr(&A.errors[blockIdx.y], 2u);

@@ -40,12 +40,15 @@ static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char b
   return 0;
 }
 
-int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
-  jga_scan_desc *d = (jga_scan_desc *)malloc(sizeof(jga_scan_desc));
+hj_prepared::~hj_prepared() { free(desc); }
+
+int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
+  free(out->desc);
+  out->desc = (jga_scan_desc *)malloc(sizeof(jga_scan_desc));
+  jga_scan_desc *d = out->desc;
   if (!d) return jga_fail("Out of memory");
   if (jga_scan_describe(jpeg, size, d) != EXIT_SUCCESS
    || jga_geom_from_header(&out->geom, &d->header) != EXIT_SUCCESS) {
-    free(d);
     return EXIT_FAILURE;
   }
   const jga_geom &g = out->geom;
@@ -61,7 +64,7 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
     im.comp_coef_off[c] = g.plane[c].coef_off;
     for (int sy = 0; sy < cp.vsamp; sy++) {
       for (int sx = 0; sx < cp.hsamp; sx++) {
-        if (slot >= HJ_MAX_SLOTS) { free(d); return jga_fail("Unsupported sampling (MCU too large)"); }
+        if (slot >= HJ_MAX_SLOTS) return jga_fail("Unsupported sampling (MCU too large)");
         im.slot_comp[slot] = (uint8_t)c;
         im.slot_sbx[slot] = (uint8_t)sx;
         im.slot_sby[slot] = (uint8_t)sy;
@@ -79,7 +82,6 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
         else rc = build_table(&out->tabs, 2*c + w, &l2_used, d->dht_bits[id], d->dht_vals[id]);
       }
       if (rc) {
-        free(d);
         return jga_fail(rc == 2 ? "Huffman table too irregular for the GPU entropy stage"
          : "Error invalid DHT.");
       }
@@ -90,7 +92,15 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
   im.nslots = slot;
   im.nhmb = g.nhmb;
   im.w0_blocks = g.w0/8;
+  out->avail = (uint32_t)(size - d->scan_off);
+  return EXIT_SUCCESS;
+}
 
+int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsigned char *dst) {
+  const jga_scan_desc *d = out->desc;
+  if (!d) return jga_fail("huff: hj_prepare_head must come first");
+  const jga_geom &g = out->geom;
+  hj_image &im = out->im;
   // entropy-coded bytes: split at RSTn markers, stop at the first other marker; copy
   // them into a clean stream (stuffed zeros and markers dropped) as we go
   const unsigned char *scan = jpeg + d->scan_off;
@@ -98,22 +108,21 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
   const uint32_t total_mcus = (uint32_t)g.nhmb*(uint32_t)g.nvmb;
   const uint32_t ri = (uint32_t)d->header.restart_interval;
   out->segs.clear();
-  out->clean.clear();
-  out->clean.reserve(avail + 32);
-  uint32_t pos = 0, mcu0 = 0, nsub = 0, clean_start = 0;
-  int expect = 0;
+  uint32_t pos = 0, mcu0 = 0, nsub = 0, clean_start = 0, w = 0;
+  int expect = 0, rc = EXIT_SUCCESS;
   bool done = false;
   while (!done) {
     const unsigned char *ff = pos < avail ? (const unsigned char *)memchr(scan + pos, 0xFF, avail - pos) : NULL;
     const uint32_t at = ff ? (uint32_t)(ff - scan) : avail;
     const int marker = (ff && at + 1 < avail) ? scan[at + 1] : 0xD9;   // running off the end == EOI
-    out->clean.insert(out->clean.end(), scan + pos, scan + at);
-    if (ff && marker == 0x00) { out->clean.push_back(0xFF); pos = at + 2; continue; }   // stuffed zero
+    memcpy(dst + w, scan + pos, at - pos);
+    w += at - pos;
+    if (ff && marker == 0x00) { dst[w++] = 0xFF; pos = at + 2; continue; }   // stuffed zero
     if (ff && marker == 0xFF) { pos = at + 1; continue; }               // fill byte
     // a real marker (or the end of the buffer) closes the current segment
     hj_segment s;
     s.start = clean_start;
-    s.end = (uint32_t)out->clean.size();
+    s.end = w;
     s.sub0 = nsub;
     s.nsub = (s.end - s.start + HJ_SUB_BYTES - 1)/HJ_SUB_BYTES;
     if (s.nsub == 0) s.nsub = 1;
@@ -124,19 +133,29 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
     mcu0 += s.nmcu;
     out->raw_len = at;
     if (marker >= 0xD0 && marker <= 0xD7 && ri && mcu0 < total_mcus) {
-      if (marker != 0xD0 + (expect & 7)) { free(d); return jga_fail("Error invalid RST counter in marker."); }
+      if (marker != 0xD0 + (expect & 7)) { rc = jga_fail("Error invalid RST counter in marker."); break; }
       expect++;
       pos = at + 2;
       clean_start = s.end;
     }
     else done = true;
   }
-  out->scan_len = (uint32_t)out->clean.size();
-  out->clean.insert(out->clean.end(), 16, (unsigned char)0xFF);
-  free(d);
+  out->scan_len = w;
+  memset(dst + w, 0xFF, 16);
+  free(out->desc);
+  out->desc = nullptr;
+  if (rc != EXIT_SUCCESS) return rc;
   if (mcu0 != total_mcus) return jga_fail("Error, entropy data ended early.");
   im.nsub = nsub;
   im.nseg = (uint32_t)out->segs.size();
   im.scan_len = out->scan_len;
+  return EXIT_SUCCESS;
+}
+
+int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
+  if (hj_prepare_head(jpeg, size, out) != EXIT_SUCCESS) return EXIT_FAILURE;
+  out->clean.assign((size_t)out->avail + 16, 0);
+  if (hj_prepare_scan(jpeg, size, out, out->clean.data()) != EXIT_SUCCESS) return EXIT_FAILURE;
+  out->clean.resize((size_t)out->scan_len + 16);
   return EXIT_SUCCESS;
 }

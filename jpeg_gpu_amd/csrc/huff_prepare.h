@@ -12,12 +12,26 @@ struct hj_prepared {
   std::vector<hj_segment> segs;
   hj_tables tabs;                   // two-level LUTs, [2*comp] DC, [2*comp+1] AC
   unsigned short qtab[3*64];        // per plane, natural order
-  std::vector<unsigned char> clean; // entropy-coded bytes with FF00 -> FF and RSTn removed, + 16 pad
+  std::vector<unsigned char> clean; // (hj_prepare_image only) clean bytes + 16 pad
   uint32_t scan_len;                // clean length (without the pad)
   uint32_t raw_len;                 // entropy-coded bytes in the file incl. stuffing and RST markers
+  // between the two steps:
+  jga_scan_desc *desc;              // marker segments (owned; freed by hj_prepare_scan / _drop)
+  uint32_t avail;                   // bytes from the start of the scan to the end of the file
+  hj_prepared() : scan_len(0), raw_len(0), desc(nullptr), avail(0) {}
+  ~hj_prepared();
+  hj_prepared(const hj_prepared &) = delete;
+  hj_prepared &operator=(const hj_prepared &) = delete;
 };
 
-// Returns EXIT_SUCCESS / EXIT_FAILURE (message via jga_fail).
+// Two steps, so that a batch builder can size one pinned buffer between them:
+//   hj_prepare_head  marker segments -> geometry, slot map, tables, quantisers, `avail`
+//   hj_prepare_scan  entropy-coded bytes -> clean stream written to `dst` (capacity >=
+//                    avail + 16; 16 pad bytes of 0xFF follow the stream) + restart segments
+// Both return EXIT_SUCCESS / EXIT_FAILURE (message via jga_fail).
+int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out);
+int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsigned char *dst);
+// Both steps, clean stream kept in out->clean (emulation / tests).
 int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out);
 
 #endif

@@ -12,6 +12,11 @@
 // With cfg.transport = 1 the workers produce the reference's PACK wire format
 // (src/xjpeg.c:484-496, 513-519, 531-535) instead of dense planes; only the words and
 // the block index cross PCIe and jga_unpack_batch() expands them in HBM.
+// With cfg.transport = 2 no Huffman decoding happens on the host at all: a few
+// "lanes" (driver thread + stream + jga_huff_batch) take groups of cfg.batch jobs;
+// the host only parses markers and unstuffs the scan into pinned memory, the
+// compressed bytes cross PCIe, and the GPU entropy stage + fused kernel do the
+// rest.  While one lane waits for its GPU work the others prepare their next group.
 #include <hip/hip_runtime_api.h>
 #include <atomic>
 #include <stdlib.h>
@@ -44,11 +49,24 @@ struct worker {
   slot slots[2];
 };
 
+// transport 2: one GPU-entropy lane
+struct hlane {
+  hipStream_t stream = nullptr;
+  jga_huff_batch *hb = nullptr;
+  int hb_images = 0;
+  long long hb_scan = 0;
+  short *d_coef = nullptr;
+  unsigned short *d_q = nullptr;
+  unsigned char *d_out = nullptr, *h_out = nullptr;
+  long long cap_coef = 0, cap_q = 0, cap_out = 0, cap_hout = 0;
+};
+
 }  // namespace
 
 struct jga_pipeline {
   jga_pipeline_config cfg;
   std::vector<worker> workers;
+  std::vector<hlane> lanes;
 };
 
 namespace {
@@ -198,6 +216,112 @@ void run_worker(jga_pipeline *pl, worker *w, jga_job *jobs, int n,
   retire(w->slots[1], copy_back);
 }
 
+
+// ---- transport 2: GPU entropy lanes ------------------------------------------
+
+void free_lane(hlane &l) {
+  if (l.hb) jga_huff_destroy(l.hb);
+  if (l.d_coef) (void)hipFree(l.d_coef);
+  if (l.d_q) (void)hipFree(l.d_q);
+  if (l.d_out) (void)hipFree(l.d_out);
+  if (l.h_out) (void)hipHostFree(l.h_out);
+  if (l.stream) (void)hipStreamDestroy(l.stream);
+  l = hlane();
+}
+
+bool grow(void **p, long long *cap, long long want, bool pinned) {
+  if (want <= *cap) return true;
+  if (*p) { if (pinned) (void)hipHostFree(*p); else (void)hipFree(*p); }
+  *p = nullptr; *cap = 0;
+  if (pinned ? !HOK(hipHostMalloc(p, (size_t)want, hipHostMallocDefault)) : !HOK(hipMalloc(p, (size_t)want))) return false;
+  *cap = want;
+  return true;
+}
+
+// Decode jobs[0..m) as ONE batch of the GPU entropy stage.  Fails as a whole (mixed
+// geometry, a corrupt member, ...); the caller then retries the members one by one.
+int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
+  const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
+  const bool copy_back = pl->cfg.copy_back != 0;
+  std::vector<const unsigned char *> ptrs((size_t)m);
+  std::vector<int> sizes((size_t)m);
+  long long total = 0;
+  jga_geom g;
+  for (int i = 0; i < m; i++) {
+    ptrs[i] = jobs[i].jpeg;
+    sizes[i] = jobs[i].size;
+    total += jobs[i].size + 4096;
+  }
+  if (!l.hb || m > l.hb_images || total > l.hb_scan) {
+    if (l.hb) jga_huff_destroy(l.hb);
+    l.hb_images = m > l.hb_images ? m : l.hb_images;
+    l.hb_scan = total + total/4 > l.hb_scan ? total + total/4 : l.hb_scan;
+    l.hb = jga_huff_create(l.hb_images, l.hb_scan);
+    if (!l.hb) { l.hb_images = 0; l.hb_scan = 0; return EXIT_FAILURE; }
+  }
+  jga_huff_set_threads(l.hb, threads);
+  if (jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
+  const long long cstride = (g.coef_shorts + 127) & ~127ll;
+  const long long out_bytes = rgb ? g.rgb_bytes : g.yuv_bytes;
+  const long long ostride = (out_bytes + 255) & ~255ll;
+  if (!grow((void **)&l.d_coef, &l.cap_coef, cstride*2*m, false)
+   || !grow((void **)&l.d_q, &l.cap_q, 384ll*m, false)) {
+    return EXIT_FAILURE;
+  }
+  if (!grow((void **)&l.d_out, &l.cap_out, ostride*m, false)
+   || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*m, true))) {
+    return EXIT_FAILURE;
+  }
+  if (!HOK(hipMemcpyAsync(l.d_q, jga_huff_qtabs(l.hb), 384*(size_t)m, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
+  if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
+  bool scattered = false;
+  for (int i = 0; i < m; i++) scattered = scattered || jobs[i].dev_out != nullptr;
+  if (!scattered) {
+    if ((rgb ? jga_idct_rgb_batch(&g, m, l.d_coef, cstride, l.d_q, 1, l.d_out, ostride, l.stream)
+     : jga_idct_yuv_batch(&g, m, l.d_coef, cstride, l.d_q, 1, l.d_out, ostride, l.stream)) != EXIT_SUCCESS) {
+      return EXIT_FAILURE;
+    }
+  }
+  else {
+    for (int i = 0; i < m; i++) {
+      unsigned char *dst = jobs[i].dev_out ? jobs[i].dev_out : l.d_out + ostride*i;
+      if ((rgb ? jga_idct_rgb_batch(&g, 1, l.d_coef + cstride*i, cstride, l.d_q + 192*i, 1, dst, ostride, l.stream)
+       : jga_idct_yuv_batch(&g, 1, l.d_coef + cstride*i, cstride, l.d_q + 192*i, 1, dst, ostride, l.stream)) != EXIT_SUCCESS) {
+        return EXIT_FAILURE;
+      }
+    }
+  }
+  if (copy_back) {
+    for (int i = 0; i < m; i++) {
+      if (!jobs[i].host_out) continue;
+      const unsigned char *src = jobs[i].dev_out ? jobs[i].dev_out : l.d_out + ostride*i;
+      if (!HOK(hipMemcpyAsync(l.h_out + ostride*i, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return EXIT_FAILURE;
+    }
+  }
+  if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;
+  const long long up = jga_huff_upload_bytes(l.hb)/m;
+  for (int i = 0; i < m; i++) {
+    if (copy_back && jobs[i].host_out) memcpy(jobs[i].host_out, l.h_out + ostride*i, (size_t)out_bytes);
+    jobs[i].width = g.width; jobs[i].height = g.height; jobs[i].nplanes = g.nplanes;
+    jobs[i].h2d_bytes = up;
+    jobs[i].status = EXIT_SUCCESS;
+  }
+  return EXIT_SUCCESS;
+}
+
+void run_lane(jga_pipeline *pl, hlane *l, jga_job *jobs, int n, std::atomic<int> *next,
+ int batch, int threads) {
+  if (!HOK(hipSetDevice(pl->cfg.device))) return;
+  for (;;) {
+    const int i0 = next->fetch_add(batch);
+    if (i0 >= n) break;
+    const int m = n - i0 < batch ? n - i0 : batch;
+    if (lane_group(pl, *l, jobs + i0, m, threads) == EXIT_SUCCESS) continue;
+    if (m == 1) continue;
+    for (int i = 0; i < m; i++) (void)lane_group(pl, *l, jobs + i0 + i, 1, 1);   // isolate the bad one(s)
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -205,8 +329,8 @@ extern "C" {
 JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
   jga_pipeline *pl = new jga_pipeline();
   pl->cfg = *cfg;
-  if (pl->cfg.transport != 0 && pl->cfg.transport != 1) {
-    jga_fail("pipeline: transport must be 0 (planes) or 1 (PACK)");
+  if (pl->cfg.transport < 0 || pl->cfg.transport > 2) {
+    jga_fail("pipeline: transport must be 0 (planes), 1 (PACK) or 2 (GPU entropy stage)");
     delete pl;
     return nullptr;
   }
@@ -223,6 +347,16 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     delete pl;
     return nullptr;
   }
+  if (pl->cfg.transport == 2) {
+    pl->lanes.resize(pl->cfg.depth > 0 ? pl->cfg.depth : 3);
+    for (auto &l : pl->lanes) {
+      if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        jga_pipeline_destroy(pl);
+        return nullptr;
+      }
+    }
+    return pl;
+  }
   pl->workers.resize(pl->cfg.nthreads);
   for (auto &w : pl->workers) {
     if (!hip_ok(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking), "hipStreamCreate")) {
@@ -237,8 +371,20 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
   std::atomic<int> next(0);
   std::vector<std::thread> threads;
   int failed = 0;
-  const int nt = n < (int)pl->workers.size() ? n : (int)pl->workers.size();
   for (int i = 0; i < n; i++) jobs[i].status = EXIT_FAILURE;
+  if (pl->cfg.transport == 2) {
+    const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 16;
+    const int nl = (int)pl->lanes.size();
+    int per = pl->cfg.nthreads/nl;
+    if (per < 1) per = 1;
+    for (int t = 0; t < nl; t++) {
+      threads.emplace_back(run_lane, pl, &pl->lanes[t], jobs, n, &next, batch, per);
+    }
+    for (auto &th : threads) th.join();
+    for (int i = 0; i < n; i++) failed += jobs[i].status != EXIT_SUCCESS;
+    return failed ? EXIT_FAILURE : EXIT_SUCCESS;
+  }
+  const int nt = n < (int)pl->workers.size() ? n : (int)pl->workers.size();
   for (int t = 0; t < nt; t++) {
     threads.emplace_back(run_worker, pl, &pl->workers[t], jobs, n, &next);
   }
@@ -250,6 +396,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
 JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {
   if (!pl) return;
   (void)hipSetDevice(pl->cfg.device);
+  for (auto &l : pl->lanes) free_lane(l);
   for (auto &w : pl->workers) {
     free_slot(w.slots[0]);
     free_slot(w.slots[1]);

@@ -23,6 +23,7 @@ EXPORTED = [
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
     "jga_huff_decode", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_qtabs",
+    "jga_huff_set_threads",
 ]
 
 
@@ -102,6 +103,8 @@ L.jga_huff_decode.argtypes = [_vp, _vp, _ll, _vp]
 L.jga_huff_upload_bytes.argtypes = [_vp]
 L.jga_huff_upload_bytes.restype = _ll
 L.jga_huff_last_rounds.argtypes = [_vp]
+L.jga_huff_set_threads.argtypes = [_vp, _i]
+L.jga_huff_set_threads.restype = None
 L.jga_huff_qtabs.argtypes = [_vp]
 L.jga_huff_qtabs.restype = C.POINTER(C.c_ushort)
 
@@ -334,9 +337,9 @@ class Decoder:
 
 class Pipeline:
     def __init__(self, device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
-                 max_coef_shorts=0, max_out_bytes=0, transport=0):
-        cfg = abi.jga_pipeline_config(device, nthreads, 0, out, int(copy_back),
-                                      max_coef_shorts, max_out_bytes, int(transport))
+                 max_coef_shorts=0, max_out_bytes=0, transport=0, batch=0, depth=0):
+        cfg = abi.jga_pipeline_config(device, nthreads, depth, out, int(copy_back),
+                                      max_coef_shorts, max_out_bytes, int(transport), int(batch))
         self.ptr = L.jga_pipeline_create(C.byref(cfg))
         if not self.ptr:
             raise JgaError((L.jga_last_error() or b"pipeline_create failed").decode())

@@ -245,10 +245,11 @@ def test_plugin_gpu_stages(gpu, orc, synth):
         assert np.array_equal(d.pixels(), planes[0][:33, :77])
 
 
-@pytest.mark.parametrize("transport", [0, 1])
+@pytest.mark.parametrize("transport", [0, 1, 2])
 def test_pipeline(gpu, orc, synth, transport):
     """Pipelined batch decoder: mixed geometries, copy-back to host, results equal
-    the oracle's whole-path decode — with dense planes (0) or the PACK wire format (1)
+    the oracle's whole-path decode — with dense planes (0), the PACK wire format (1) or only
+    the entropy-coded bytes (2: GPU entropy stage, groups of 4 with mixed geometries inside)
     crossing PCIe."""
     from jpeg_gpu_amd import abi
     specs = [(320, 200, "420"), (128, 64, "444"), (200, 100, "422"), (64, 64, "grey"),
@@ -257,14 +258,14 @@ def test_pipeline(gpu, orc, synth, transport):
              for i, (w, h, s) in enumerate(specs)]
     outs = [np.zeros(w * h * (1 if s == "grey" else 3), np.uint8) for (w, h, s) in specs]
     pl = gpu.Pipeline(device=0, nthreads=3, out=abi.JPEG_DECODE_RGB, copy_back=True,
-                      transport=transport)
+                      transport=transport, batch=4)
     try:
         rc, jobs = pl.run(datas, host_outs=outs)
         assert rc == 0
         for i, d in enumerate(datas):
             assert jobs[i].status == 0
             assert np.array_equal(outs[i], orc.decode_rgb(d)[1].reshape(-1)), i
-        if transport == 1:      # the compact form is what crossed PCIe
+        if transport >= 1:      # the compact form is what crossed PCIe
             _, g = gpu.geom_of(datas[0])
             assert 0 < jobs[0].h2d_bytes < g.coef_shorts * 2
         # a corrupt job fails alone
@@ -274,6 +275,34 @@ def test_pipeline(gpu, orc, synth, transport):
         assert rc == 1 and [jobs[i].status for i in range(4)] == [0, 1, 0, 0]
     finally:
         pl.close()
+
+
+def test_pipeline_gpu_entropy_batches(gpu, orc, synth):
+    """transport 2 on a stream of same-geometry images: full groups, a ragged last group,
+    results left in HBM at caller-given addresses and in internal buffers."""
+    from jpeg_gpu_amd import abi
+    datas = [synth.synthetic_jpeg(640, 360, "420", quality=50 + i, seed=i, restart_interval=(i % 2) * 40)
+             for i in range(37)]
+    _, g = gpu.geom_of(datas[0])
+    want = [orc.decode_rgb(d)[1].reshape(-1) for d in datas]
+    outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in datas]
+    pl = gpu.Pipeline(device=0, nthreads=6, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2,
+                      batch=8, depth=2)
+    dbuf = gpu.DeviceBuffer(gpu._align(g.rgb_bytes) * len(datas))
+    try:
+        rc, jobs = pl.run(datas, host_outs=outs)
+        assert rc == 0
+        for i in range(len(datas)):
+            assert np.array_equal(outs[i], want[i]), i
+        devs = [dbuf.ptr + gpu._align(g.rgb_bytes) * i for i in range(len(datas))]
+        rc, jobs = pl.run(datas, dev_outs=devs)
+        assert rc == 0
+        got = dbuf.download().reshape(len(datas), -1)
+        for i in range(len(datas)):
+            assert np.array_equal(got[i, :g.rgb_bytes], want[i]), i
+    finally:
+        pl.close()
+        dbuf.free()
 
 
 # ---- PACK wire format expanded on the GPU (SURVEY.md §8f-2) ---------------------------

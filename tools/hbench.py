@@ -16,10 +16,15 @@ distinct = [synth.synthetic_jpeg(w, h, samp, quality=90, restart_interval=ri, se
             for i in range(min(n, 6))]
 jpegs = [distinct[i % len(distinct)] for i in range(n)]
 hb = lib.HuffBatch(n, sum(map(len, jpegs)) + 4096 * n)
-t0 = time.perf_counter()
-g = hb.prepare(jpegs)
-lib.check(lib.L.jga_stream_sync(None))
-t_prep = time.perf_counter() - t0
+preps = []
+for _ in range(4):
+    t0 = time.perf_counter()
+    g = hb.prepare(jpegs)
+    t1 = time.perf_counter()
+    lib.check(lib.L.jga_stream_sync(None))
+    preps.append((t1 - t0, time.perf_counter() - t0))
+t_prep = preps[-1][1]
+print("prepare host / host+H2D ms:", ["%.1f/%.1f" % (a * 1e3, b * 1e3) for a, b in preps])
 stride = (g.coef_shorts * 2 + 255) // 256 * 128
 ostride = (g.rgb_bytes + 255) // 256 * 256
 d_coef = lib.DeviceBuffer(stride * 2 * n)

@@ -22,6 +22,8 @@ static void init_dezz() {
 struct block_out {
   const hj_image *im; const hj_segment *seg; short *coef; uint32_t b0; short blk[64];
   void put(int idx, int v) { blk[idx] = (short)v; }
+  bool any(bool x) const { return x; }
+  bool flush_due(bool waiting, bool) const { return waiting; }
   void flush(uint32_t n, int slot, bool complete, bool head) {
     const uint32_t b = b0 + n;
     short *dst = coef + hj_block_offset(*im, seg->mcu0 + b/(uint32_t)im->nslots, slot);
