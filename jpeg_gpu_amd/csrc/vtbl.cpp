@@ -13,6 +13,12 @@
 // computes YUV on the CPU and rejects RGB, jpeg_wrap.c:335-339), and malformed
 // input is rejected instead of read out of bounds.  There is NO CPU fallback
 // for the GPU stages: without a HIP device they fail loudly.
+//
+// For the YUV and RGB stages the scan itself is decoded on the GPU too
+// (jga_huff_*): the host only parses the markers and unstuffs the
+// scan into pinned memory.  JGA_PLUGIN_ENTROPY=host selects the host entropy
+// stage (csrc/entropy.c) instead; it is also what a file whose Huffman tables do
+// not fit the device lookup format ("too irregular") is decoded with.
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,9 +44,22 @@ struct hipjpeg_ctx {
   unsigned short *d_qtab;
   unsigned char *d_out;
   long long cap_coef, cap_out;
+  jga_huff_batch *hb;         // GPU entropy stage, one image
+  long long hb_scan;
 };
 
+int gpu_entropy_wanted(void) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("JGA_PLUGIN_ENTROPY");
+    mode = (e && strcmp(e, "host") == 0) ? 0 : 1;
+  }
+  return mode;
+}
+
 void release_device(hipjpeg_ctx *c) {
+  if (c->hb) jga_huff_destroy(c->hb);
+  c->hb = NULL; c->hb_scan = 0;
   if (c->h_coef) (void)hipHostFree(c->h_coef);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_coef) (void)hipFree(c->d_coef);
@@ -162,7 +181,25 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     if (ensure_device(c, g->coef_shorts, (out_bytes + 15) & ~15ll) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
     }
-    if (jga_entropy_decode(c->buf, c->size, g, c->h_coef, 0) != EXIT_SUCCESS) {
+    int on_gpu = gpu_entropy_wanted();
+    if (on_gpu) {
+      jga_geom g2;
+      if (!c->hb || c->size + 4096ll > c->hb_scan) {
+        if (c->hb) jga_huff_destroy(c->hb);
+        c->hb_scan = c->size + c->size/4 + 4096ll;
+        c->hb = jga_huff_create(1, c->hb_scan);
+        if (!c->hb) { c->hb_scan = 0; return EXIT_FAILURE; }
+        jga_huff_set_threads(c->hb, 1);
+      }
+      if (jga_huff_prepare(c->hb, &c->buf, &c->size, 1, &g2, c->stream) != EXIT_SUCCESS) {
+        if (!strstr(jga_last_error(), "too irregular")) return EXIT_FAILURE;
+        on_gpu = 0;                        // tables outside the device lookup format
+      }
+      else if (jga_huff_decode(c->hb, c->d_coef, g->coef_shorts, c->stream) != EXIT_SUCCESS) {
+        return EXIT_FAILURE;
+      }
+    }
+    if (!on_gpu && jga_entropy_decode(c->buf, c->size, g, c->h_coef, 0) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
     }
     memset(qtab, 0, sizeof(qtab));
@@ -170,8 +207,10 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       memcpy(qtab + 64*i, c->header.comp[i].quant->tbl, 64*sizeof(unsigned short));
     }
     HIP_OK(hipMemcpyAsync(c->d_qtab, qtab, sizeof(qtab), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpyAsync(c->d_coef, c->h_coef, g->coef_shorts*sizeof(short),
-     hipMemcpyHostToDevice, c->stream));
+    if (!on_gpu) {
+      HIP_OK(hipMemcpyAsync(c->d_coef, c->h_coef, g->coef_shorts*sizeof(short),
+       hipMemcpyHostToDevice, c->stream));
+    }
     if ((rgb ? jga_idct_rgb_batch(g, 1, c->d_coef, g->coef_shorts, c->d_qtab, 1,
      c->d_out, c->cap_out, c->stream)
      : jga_idct_yuv_batch(g, 1, c->d_coef, g->coef_shorts, c->d_qtab, 1,

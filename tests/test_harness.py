@@ -14,9 +14,9 @@ EXE = os.path.join(ROOT, "jpeg_gpu_amd", "jpeg_gpu_hip")
 SUBSAMP = ["Unknown", "4:4:4", "4:2:2", "4:2:0", "4:4:0", "4:1:1", "Mono"]
 
 
-def run(*args, ok=True):
+def run(*args, ok=True, env=None):
     r = subprocess.run([EXE] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, timeout=300, env=dict(os.environ, JGA_QUIET="0"))
+                       text=True, timeout=300, env=dict(os.environ, JGA_QUIET="0", **(env or {})))
     if ok:
         assert r.returncode == 0, r.stderr
     return r
@@ -135,4 +135,20 @@ def test_main_loop_finishes_every_stage_on_the_device(gpu, orc, jpg, stage, samp
     assert out[-1] == "RGB 333x211x%d adler32 %08x" % (nc, zlib.adler32(rgb.tobytes())), out
     # --no-cpu: the first decode is kept and the device still finishes it
     out = run("-o", stage, "--no-cpu", "--frames", "2", "--check", path).stdout.strip().split("\n")
+    assert out[-1].endswith("%08x" % zlib.adler32(rgb.tobytes()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entropy", ["gpu", "host"])
+def test_plugin_entropy_stage_choice(gpu, orc, jpg, entropy):
+    """decode_image(YUV|RGB) decodes the scan on the GPU by default and on the host with
+    JGA_PLUGIN_ENTROPY=host: identical planes and pixels either way."""
+    import oracle
+    path, data = jpg(517, 389, "420", quality=92, restart_interval=7)
+    env = {"JGA_PLUGIN_ENTROPY": entropy}
+    _, planes = orc.decode(data, oracle.YUV)
+    for a, b in zip(numbers(run("--dump", "-o", "yuv", path, env=env).stdout), planes):
+        assert np.array_equal(a, b)
+    _, rgb = orc.decode_rgb(data)
+    out = run("-o", "rgb", "--frames", "4", "--check", path, env=env).stdout.strip().split("\n")
     assert out[-1].endswith("%08x" % zlib.adler32(rgb.tobytes()))
