@@ -176,7 +176,8 @@ DEV void row_pass_ldsq(const uint4 (&rows)[8], const uint4 *qp, float (&z)[64]) 
 // its first entry (dct.c:112-115), floor (118).  On return t[k*8+i] =
 // floor(idct)(row k, col i) as an integer-valued float, already passed through
 // the (short) wrap of dct.c:118 when it can matter.
-DEV void col_pass(const float (&z)[64], float (&t)[64]) {
+// Returns max |t| over the block.
+DEV float col_pass(const float (&z)[64], float (&t)[64]) {
   float m = 0.0f;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -201,7 +202,9 @@ DEV void col_pass(const float (&z)[64], float (&t)[64]) {
   if (__builtin_expect(!(m < 32000.0f), 0)) {
 #pragma unroll
     for (int n = 0; n < 64; n++) t[n] = (float)(short)(int)t[n];
+    m = 32768.0f;
   }
+  return m;
 }
 
 template <bool DEQUANT>
@@ -258,12 +261,13 @@ struct chroma_row {
 };
 
 // One output row (8 pixels) of a luma block -> 24 RGB bytes in 6 dwords.
-template <int XDEC, int CW>
+// CLAMP = false when no sample of the wave leaves [-128,127] (the clamp is the identity).
+template <int XDEC, int CW, bool CLAMP>
 DEV void rgb_row(const float *t8, const chroma_row<CW> &cr, uint4 &a, uint2 &b2) {
   float rgb[24];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const float yc = __builtin_amdgcn_fmed3f(t8[i], -128.0f, 127.0f);
+    const float yc = CLAMP ? __builtin_amdgcn_fmed3f(t8[i], -128.0f, 127.0f) : t8[i];
     const int c = i >> XDEC;
     rgb[3*i + 0] = yc + cr.r[c];
     rgb[3*i + 1] = __builtin_floorf((yc + cr.g1[c]) + cr.g2[c]);
@@ -408,6 +412,30 @@ struct rgb_cfg {
   static constexpr int LDS_FLOATS = CHROMA_FLOATS + 3*32;
 };
 
+// Upsample + convert + store the 8 pixel rows of one luma block.
+template <int XDEC, int YDEC, bool CLAMP>
+DEV void colour_rows(const float (&t)[64], const float *ub, const float *vb, uint8_t *obase,
+ long long pitch, bool fast, int x0, int y0, int width, int height) {
+  typedef rgb_cfg<XDEC, YDEC> cfg;
+  chroma_row<cfg::CW> cr;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if ((k & (cfg::LH - 1)) == 0) {
+      float u[cfg::CW], v[cfg::CW];
+#pragma unroll
+      for (int c = 0; c < cfg::CW; c++) {
+        u[c] = ub[(k >> YDEC)*(cfg::TILE*8) + c];
+        v[c] = vb[(k >> YDEC)*(cfg::TILE*8) + c];
+      }
+      cr.set(u, v);
+    }
+    uint4 a;
+    uint2 b;
+    rgb_row<XDEC, cfg::CW, CLAMP>(t + k*8, cr, a, b);
+    if (y0 + k < height) store_rgb_row(obase + k*pitch, a, b, fast, x0, width);
+  }
+}
+
 template <int XDEC, int YDEC, bool DEQUANT>
 __global__ __launch_bounds__((rgb_cfg<XDEC, YDEC>::THREADS))
 void jga_idct_rgb_kernel(const jga_kparams P) {
@@ -458,19 +486,32 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
   }
   float z[64], t[64];
   row_pass_ldsq<DEQUANT>(rows, qlds + pl*8, z);
-  col_pass(z, t);
+  const float tmax = col_pass(z, t);
+  // Clamping to [-128,127] is the identity unless some sample overshoots; decide once per
+  // wave (64 blocks) and drop the 64 v_med3 per lane when nobody does — the usual case.
+  const bool clip = __builtin_amdgcn_ballot_w64(tmax > 127.0f) != 0ull;
 
   if (!is_luma) {
     // publish (sample-128) clamped to [-128,127] == clamp255(s+128)-128
     float *dst = chroma + ((comp*8)*cfg::TILE + cb)*8;
+    if (clip) {
 #pragma unroll
-    for (int n = 0; n < 64; n += 4) {
-      v4f v;
-      v.x = __builtin_amdgcn_fmed3f(t[n + 0], -128.0f, 127.0f);
-      v.y = __builtin_amdgcn_fmed3f(t[n + 1], -128.0f, 127.0f);
-      v.z = __builtin_amdgcn_fmed3f(t[n + 2], -128.0f, 127.0f);
-      v.w = __builtin_amdgcn_fmed3f(t[n + 3], -128.0f, 127.0f);
-      *reinterpret_cast<v4f *>(dst + (n >> 3)*(cfg::TILE*8) + (n & 4)) = v;
+      for (int n = 0; n < 64; n += 4) {
+        v4f v;
+        v.x = __builtin_amdgcn_fmed3f(t[n + 0], -128.0f, 127.0f);
+        v.y = __builtin_amdgcn_fmed3f(t[n + 1], -128.0f, 127.0f);
+        v.z = __builtin_amdgcn_fmed3f(t[n + 2], -128.0f, 127.0f);
+        v.w = __builtin_amdgcn_fmed3f(t[n + 3], -128.0f, 127.0f);
+        *reinterpret_cast<v4f *>(dst + (n >> 3)*(cfg::TILE*8) + (n & 4)) = v;
+      }
+    }
+    else {
+#pragma unroll
+      for (int n = 0; n < 64; n += 4) {
+        v4f v;
+        v.x = t[n + 0]; v.y = t[n + 1]; v.z = t[n + 2]; v.w = t[n + 3];
+        *reinterpret_cast<v4f *>(dst + (n >> 3)*(cfg::TILE*8) + (n & 4)) = v;
+      }
     }
   }
   __syncthreads();
@@ -484,23 +525,8 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
   uint8_t *obase = P.out + (long long)img*P.out_stride + (long long)y0*pitch
    + (long long)x0*3;
   const bool fast = P.out_aligned && x0 + 8 <= P.width;
-  chroma_row<cfg::CW> cr;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if ((k & (cfg::LH - 1)) == 0) {
-      float u[cfg::CW], v[cfg::CW];
-#pragma unroll
-      for (int c = 0; c < cfg::CW; c++) {
-        u[c] = ub[(k >> YDEC)*(cfg::TILE*8) + c];
-        v[c] = vb[(k >> YDEC)*(cfg::TILE*8) + c];
-      }
-      cr.set(u, v);
-    }
-    uint4 a;
-    uint2 b;
-    rgb_row<XDEC, cfg::CW>(t + k*8, cr, a, b);
-    if (y0 + k < P.height) store_rgb_row(obase + k*pitch, a, b, fast, x0, P.width);
-  }
+  if (clip) colour_rows<XDEC, YDEC, true>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
+  else colour_rows<XDEC, YDEC, false>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
 }
 
 // Grey: one plane, img->pixels is 1 B/px at the true size (ungrey.fs.glsl:18;
