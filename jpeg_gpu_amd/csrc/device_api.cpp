@@ -217,6 +217,33 @@ JGA_EXPORT int jga_unpack_batch(const jga_geom *g, int nimages,
     index0 += (long long)(g->plane[p].hblocks << g->plane[p].xdec)*g->plane[p].cstride;
   }
   P.plane_first[g->nplanes] = first;
+  P.nhmb = g->nhmb;
+  P.nvmb = g->nvmb;
+  {
+    int slot = 0, hmax = 1, vmax = 1;
+    for (p = 0; p < g->nplanes; p++) {
+      if ((1 << g->plane[p].xdec) > hmax) hmax = 1 << g->plane[p].xdec;
+      if ((1 << g->plane[p].ydec) > vmax) vmax = 1 << g->plane[p].ydec;
+    }
+    for (p = 0; p < g->nplanes; p++) {
+      const int hs = hmax >> g->plane[p].xdec, vs = vmax >> g->plane[p].ydec;
+      P.plane_hs[p] = hs;
+      P.plane_vs[p] = vs;
+      for (int sy = 0; sy < vs; sy++) {
+        for (int sx = 0; sx < hs; sx++) {
+          if (slot >= 10 || sx > 3 || sy > 3) return jga_fail("Unsupported sampling (MCU too large)");
+          P.slot_desc |= (unsigned long long)(p | (sx << 2) | (sy << 4)) << (6*slot);
+          slot++;
+        }
+      }
+    }
+    P.nslots = slot;
+    {
+      const jga_divisor a = make_divisor((uint32_t)slot), b = make_divisor((uint32_t)g->nhmb);
+      P.div_nslots.mul = a.mul; P.div_nslots.shift = a.shift;
+      P.div_nhmb.mul = b.mul; P.div_nhmb.shift = b.shift;
+    }
+  }
   rc = jga_launch_unpack(&P, stream);
   if (rc) return jga_fail("PACK kernel launch failed (HIP error %d)", rc);
   return EXIT_SUCCESS;

@@ -19,6 +19,12 @@ typedef struct jga_pack_params {
   int plane_first[4];         /* flat number of each plane's first real block; [nplanes] = total */
   int plane_index0[3];        /* first index entry of each plane (src/image.c:93-94) */
   long long plane_coef_off[3];
+  /* scan order (MCU-interleaved), the order the words are stored in */
+  int nhmb, nvmb;             /* MCUs per row / rows */
+  int nslots;                 /* blocks per MCU */
+  struct { uint32_t mul, shift; } div_nslots, div_nhmb;   /* n/d == (n*mul) >> shift, n < 2^31 */
+  unsigned long long slot_desc; /* 6 bits per slot: plane | sbx << 2 | sby << 4 (<= 10 slots) */
+  int plane_hs[3], plane_vs[3];
 } jga_pack_params;
 
 #ifdef __cplusplus
