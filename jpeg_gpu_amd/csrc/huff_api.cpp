@@ -116,7 +116,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
-  std::atomic<int> next_a(0), next_b(0), next_c(0), failed(0);
+  std::atomic<int> next_a(0), next_b(0), next_c(0), failed(0), irregular(0);
   std::atomic<int> fatal(0);       // set by the serial sections: 1 geometry, 2 capacity
   std::atomic<int> stop(0);        // decided in a serial section, read after the next barrier
   phase_barrier bar;
@@ -134,7 +134,9 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
     for (;;) {
       const int i = next_a.fetch_add(1);
       if (i >= n) break;
-      if (hj_prepare_head(jpegs[i], sizes[i], &prep[i]) != EXIT_SUCCESS) failed.fetch_add(1);
+      const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
+      if (rc != EXIT_SUCCESS) failed.fetch_add(1);
+      if (rc == HJ_PREPARE_IRREGULAR) irregular.fetch_add(1);
     }
     bar.wait();
     if (tid == 0 && failed.load()) stop.store(1);
@@ -230,6 +232,10 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
     for (auto &th : pool) th.join();
   }
   b->nimages = 0;
+  if (irregular.load()) {
+    return jga_fail("huff: %d image(s) of the batch have Huffman tables too irregular for the GPU "
+     "entropy stage", irregular.load());
+  }
   if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
   if (fatal.load() == 1) return jga_fail("huff: images of one batch must share a geometry");
   if (fatal.load()) return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");

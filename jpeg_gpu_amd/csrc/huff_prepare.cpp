@@ -82,8 +82,9 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
         else rc = build_table(&out->tabs, 2*c + w, &l2_used, d->dht_bits[id], d->dht_vals[id]);
       }
       if (rc) {
-        return jga_fail(rc == 2 ? "Huffman table too irregular for the GPU entropy stage"
+        jga_fail(rc == 2 ? "Huffman table too irregular for the GPU entropy stage"
          : "Error invalid DHT.");
+        return rc == 2 ? HJ_PREPARE_IRREGULAR : EXIT_FAILURE;
       }
     }
     memcpy(out->qtab + 64*c, cp.quant->tbl, 64*sizeof(unsigned short));

@@ -58,7 +58,8 @@ struct hlane {
   short *d_coef = nullptr;
   unsigned short *d_q = nullptr;
   unsigned char *d_out = nullptr, *h_out = nullptr;
-  long long cap_coef = 0, cap_q = 0, cap_out = 0, cap_hout = 0;
+  short *h_coef = nullptr;          // pinned, host-entropy fallback only
+  long long cap_coef = 0, cap_q = 0, cap_out = 0, cap_hout = 0, cap_hcoef = 0;
 };
 
 }  // namespace
@@ -225,6 +226,7 @@ void free_lane(hlane &l) {
   if (l.d_q) (void)hipFree(l.d_q);
   if (l.d_out) (void)hipFree(l.d_out);
   if (l.h_out) (void)hipHostFree(l.h_out);
+  if (l.h_coef) (void)hipHostFree(l.h_coef);
   if (l.stream) (void)hipStreamDestroy(l.stream);
   l = hlane();
 }
@@ -260,7 +262,18 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
     if (!l.hb) { l.hb_images = 0; l.hb_scan = 0; return EXIT_FAILURE; }
   }
   jga_huff_set_threads(l.hb, threads);
-  if (jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
+  // A lone image whose Huffman tables do not fit the device lookup format takes the host
+  // entropy stage (csrc/entropy.c) instead; everything after it is the same.
+  bool host_entropy = false;
+  jpeg_header hdr;
+  if (jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream) != EXIT_SUCCESS) {
+    if (m != 1 || !strstr(jga_last_error(), "too irregular")) return EXIT_FAILURE;
+    if (jga_parse_header(jobs[0].jpeg, jobs[0].size, &hdr) != EXIT_SUCCESS
+     || jga_geom_from_header(&g, &hdr) != EXIT_SUCCESS) {
+      return EXIT_FAILURE;
+    }
+    host_entropy = true;
+  }
   const long long cstride = (g.coef_shorts + 127) & ~127ll;
   const long long out_bytes = rgb ? g.rgb_bytes : g.yuv_bytes;
   const long long ostride = (out_bytes + 255) & ~255ll;
@@ -272,8 +285,20 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
    || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*m, true))) {
     return EXIT_FAILURE;
   }
-  if (!HOK(hipMemcpyAsync(l.d_q, jga_huff_qtabs(l.hb), 384*(size_t)m, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
-  if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
+  if (host_entropy) {
+    unsigned short q[192];
+    memset(q, 0, sizeof(q));
+    for (int p = 0; p < g.nplanes; p++) memcpy(q + 64*p, hdr.comp[p].quant->tbl, 128);
+    if (!grow((void **)&l.h_coef, &l.cap_hcoef, cstride*2, true)) return EXIT_FAILURE;
+    if (jga_entropy_decode(jobs[0].jpeg, jobs[0].size, &g, l.h_coef, 0) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (!HOK(hipMemcpyAsync(l.d_q, q, sizeof(q), hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
+    if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;       // q is on this stack frame
+    if (!HOK(hipMemcpyAsync(l.d_coef, l.h_coef, (size_t)g.coef_shorts*2, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
+  }
+  else {
+    if (!HOK(hipMemcpyAsync(l.d_q, jga_huff_qtabs(l.hb), 384*(size_t)m, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
+    if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
+  }
   bool scattered = false;
   for (int i = 0; i < m; i++) scattered = scattered || jobs[i].dev_out != nullptr;
   if (!scattered) {
@@ -299,7 +324,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
     }
   }
   if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;
-  const long long up = jga_huff_upload_bytes(l.hb)/m;
+  const long long up = host_entropy ? g.coef_shorts*2 : jga_huff_upload_bytes(l.hb)/m;
   for (int i = 0; i < m; i++) {
     if (copy_back && jobs[i].host_out) memcpy(jobs[i].host_out, l.h_out + ostride*i, (size_t)out_bytes);
     jobs[i].width = g.width; jobs[i].height = g.height; jobs[i].nplanes = g.nplanes;

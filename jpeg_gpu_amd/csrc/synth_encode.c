@@ -226,6 +226,11 @@ static long long block_off(const frame *f, int p, int bx, int by) {
 #define JGS_DQT16      1   /* write 16-bit (Pq=1) quantisation tables */
 #define JGS_NO_JFIF    2   /* omit the APP0 segment */
 #define JGS_SPLIT_DHT  4   /* one DHT segment per table instead of one for all */
+#define JGS_FLAT_AC    8   /* AC tables with all 162 symbols on 10-bit codes: valid, wasteful, and
+                            * 81 distinct 9-bit prefixes of long codes (the Annex K tables have 5) */
+static const unsigned char FLAT_AC_BITS[16] = {0,0,0,0,0,0,0,0,0,162,0,0,0,0,0,0};
+#define AC_LUMA_BITS(flags) (((flags) & JGS_FLAT_AC) ? FLAT_AC_BITS : K5_AC_LUMA_BITS)
+#define AC_CHROMA_BITS(flags) (((flags) & JGS_FLAT_AC) ? FLAT_AC_BITS : K6_AC_CHROMA_BITS)
 
 static void put_headers(writer *w, const frame *f,
  const unsigned short q[3][64], int nq, int restart_interval, int flags) {
@@ -262,10 +267,10 @@ static void put_headers(writer *w, const frame *f,
   }
   if (flags & JGS_SPLIT_DHT) {
     put_dht(w, 0x00, K3_DC_LUMA_BITS, K_DC_VALS);
-    put_dht(w, 0x10, K5_AC_LUMA_BITS, K5_AC_LUMA_VALS);
+    put_dht(w, 0x10, AC_LUMA_BITS(flags), K5_AC_LUMA_VALS);
     if (f->ncomps == 3) {
       put_dht(w, 0x01, K4_DC_CHROMA_BITS, K_DC_VALS);
-      put_dht(w, 0x11, K6_AC_CHROMA_BITS, K6_AC_CHROMA_VALS);
+      put_dht(w, 0x11, AC_CHROMA_BITS(flags), K6_AC_CHROMA_VALS);
     }
   }
   else {
@@ -277,14 +282,14 @@ static void put_headers(writer *w, const frame *f,
     for (i = 0; i < 16; i++) put8(w, K3_DC_LUMA_BITS[i]);
     for (i = 0; i < 12; i++) put8(w, K_DC_VALS[i]);
     put8(w, 0x10);
-    for (i = 0; i < 16; i++) put8(w, K5_AC_LUMA_BITS[i]);
+    for (i = 0; i < 16; i++) put8(w, AC_LUMA_BITS(flags)[i]);
     for (i = 0; i < 162; i++) put8(w, K5_AC_LUMA_VALS[i]);
     if (f->ncomps == 3) {
       put8(w, 0x01);
       for (i = 0; i < 16; i++) put8(w, K4_DC_CHROMA_BITS[i]);
       for (i = 0; i < 12; i++) put8(w, K_DC_VALS[i]);
       put8(w, 0x11);
-      for (i = 0; i < 16; i++) put8(w, K6_AC_CHROMA_BITS[i]);
+      for (i = 0; i < 16; i++) put8(w, AC_CHROMA_BITS(flags)[i]);
       for (i = 0; i < 162; i++) put8(w, K6_AC_CHROMA_VALS[i]);
     }
   }
@@ -318,9 +323,9 @@ static long encode_levels(const frame *f, const short *levels,
   w.out = out;
   w.cap = cap;
   build_huff(&dcl, K3_DC_LUMA_BITS, K_DC_VALS);
-  build_huff(&acl, K5_AC_LUMA_BITS, K5_AC_LUMA_VALS);
+  build_huff(&acl, AC_LUMA_BITS(flags), K5_AC_LUMA_VALS);
   build_huff(&dcc, K4_DC_CHROMA_BITS, K_DC_VALS);
-  build_huff(&acc, K6_AC_CHROMA_BITS, K6_AC_CHROMA_VALS);
+  build_huff(&acc, AC_CHROMA_BITS(flags), K6_AC_CHROMA_VALS);
   put_headers(&w, f, q, nq, restart_interval, flags);
   for (mby = 0; mby < f->nvmb; mby++) {
     for (mbx = 0; mbx < f->nhmb; mbx++) {

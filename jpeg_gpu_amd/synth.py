@@ -14,7 +14,7 @@ if not os.path.exists(_PATH):
     raise ImportError("%s missing: run `python -m jpeg_gpu_amd.build`" % _PATH)
 S = C.CDLL(_PATH)
 
-DQT16, NO_JFIF, SPLIT_DHT = 1, 2, 4
+DQT16, NO_JFIF, SPLIT_DHT, FLAT_AC = 1, 2, 4, 8
 # luma sampling factors (hs, vs) by name
 SAMPLING = {"444": (1, 1), "422": (2, 1), "420": (2, 2), "440": (1, 2), "411": (4, 1),
             "grey": (1, 1)}
@@ -43,7 +43,7 @@ def synthetic_jpeg(width, height, sampling="420", quality=90, restart_interval=0
     """SURVEY.md §8(d) recipe.  restart_interval: MCUs, 0 = none, -1 = one MCU row."""
     ncomps = 1 if sampling == "grey" else 3
     hs, vs = _samp(sampling, ncomps)
-    buf = np.empty(width * height * ncomps + (1 << 16), np.uint8)
+    buf = np.empty(width * height * ncomps * (3 if flags & FLAT_AC else 1) + (1 << 16), np.uint8)
     n = S.jgs_encode_synthetic(width, height, ncomps, hs, vs, quality, restart_interval,
                                seed, flags, buf.ctypes.data, buf.size)
     if n <= 0:

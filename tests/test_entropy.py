@@ -145,3 +145,17 @@ def test_plugin_host_stages(lib, orc, synth):
         assert d.img.packed == sum(d.img.plane[i].packed for i in range(3)) > 0
         with pytest.raises(lib.JgaError):
             d.decode(7)
+
+
+def test_irregular_huffman_tables(lib, orc, synth):
+    """A valid file whose AC tables put all 162 symbols on 10-bit codes (81 long-code
+    prefixes; the GPU entropy stage's lookup format holds 16): the host stage decodes it
+    like any other."""
+    import oracle
+    data = synth.synthetic_jpeg(200, 120, "420", quality=85, restart_interval=5,
+                                flags=synth.FLAT_AC)
+    _, g = lib.geom_of(data)
+    assert np.array_equal(lib.entropy_decode(data, g), orc.decode(data, oracle.QUANT)[1])
+    if oracle.Reference.available():
+        assert np.array_equal(oracle.Reference().decode(data, oracle.QUANT)[1],
+                              lib.entropy_decode(data, g))
