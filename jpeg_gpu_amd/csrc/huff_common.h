@@ -248,12 +248,14 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
 
 // Final pass, lean like hj_sync_decode: every coefficient goes through `out`:
 //   out.put(natural_index, value)       into the lane's block buffer
-//   out.flush(n, slot, complete, head)  the run's n-th block is over: `complete` = its
-//       last coefficient was decoded here, `head` = its first one was too (so the
-//       buffer holds the whole block iff complete && head); the buffer must be
-//       zero again afterwards
+//   out.flush_complete(waiting, slot, head)   called by EVERY lane of the wave at a write-out
+//       point: the lanes with `waiting` hold a block whose last coefficient was decoded
+//       here (`head`: its first one was too, so the buffer holds the whole block) and the
+//       wave writes those blocks out together; buffers must be zero again afterwards
+//   out.flush_partial(slot, head)       end of the run, block unfinished: its coefficients
+//       so far (a later lane holds the rest)
 //   out.any(x)                          does any lane of the wave have x? (host: x)
-//   out.flush_due(waiting, running)     wave-uniform: write the waiting lanes' blocks now?
+//   out.flush_due(waiting, running)     wave-uniform: is this a write-out point?
 // Writing a block out costs far more instructions than decoding a symbol, and in a wave
 // every lane pays for every instruction any lane executes.  So a lane that completes a
 // block does not write it at once: it WAITS (decodes nothing) until the wave decides
@@ -297,8 +299,8 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
       k = waiting ? 0 : kn;
     }
     if (out.flush_due(waiting, running && !waiting)) {
+      out.flush_complete(waiting, c, head);
       if (waiting) {
-        out.flush(n, c, true, head);
         n++;
         c = c + 1 == nslots ? 0 : c + 1;
         comp = (int)((slot_comp_bits >> (2*c)) & 3u);
@@ -307,7 +309,7 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
       }
     }
   }
-  if (k != 0 && n < max_blocks) out.flush(n, c, false, head);   // a later lane finishes this block
+  if (k != 0 && n < max_blocks) out.flush_partial(c, head);     // a later lane finishes this block
   return error;
 }
 

@@ -272,19 +272,28 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_scan(const hj_args A) {
 }
 
 // Output side of hj_write_decode.  Every coefficient lands in the lane's LDS block
-// buffer first.  A block decoded here from its first to its last coefficient leaves as
-// one 128-byte line; a piece of a block shared with a neighbouring lane is scattered
-// as 2-byte stores onto the pre-zeroed planes (disjoint positions, so the lanes need
-// no ordering between them).
+// buffer first.  At a write-out point the WAVE writes the finished blocks of its waiting
+// lanes together: the k-th waiting lane's block is handled by lanes 8k..8k+7 of a pass,
+// 16 bytes each, so every store instruction writes whole 128-byte lines (16-byte pieces
+// at a 128-byte stride per lane cost 2-4x more in the memory pipeline).  A piece of a
+// block shared with a neighbouring lane is scattered as 2-byte stores onto the pre-zeroed
+// planes (disjoint positions, so the lanes need no ordering between them).
 typedef int16_t __attribute__((may_alias)) hj_i16_alias;    // 16-bit view of the dword buffer
+typedef uint32_t hj_v4u __attribute__((ext_vector_type(4)));
 struct hj_block_out {
   const hj_image *im;
-  int16_t *coef;
-  uint32_t *blk;                     // this lane's 32-dword LDS buffer (zero between blocks)
-  uint32_t mcu0, b0;
+  int16_t *coef;                     // this image's planes
+  uint32_t *blk;                     // this lane's LDS buffer: 32 dwords + 1 (its block's byte offset)
+  uint32_t *wave_blk;                // buffer of lane 0 of this wave
+  uint8_t *rank_lane;                // per wave: lane number of the k-th waiting lane
+  uint32_t mbx, mby;                 // MCU of the block being decoded
   int flush_lanes;
+  __device__ __forceinline__ void init(uint32_t mcu) {
+    mby = mcu/(uint32_t)im->nhmb;
+    mbx = mcu - mby*(uint32_t)im->nhmb;
+  }
   __device__ __forceinline__ bool any(bool x) const { return __ballot(x) != 0ull; }
-  // Write out when HJ_FLUSH_LANES lanes hold a finished block, or when nobody can decode on.
+  // Write out when `flush_lanes` lanes hold a finished block, or when nobody can decode on.
   __device__ __forceinline__ bool flush_due(bool waiting, bool running) const {
     const unsigned long long w = __ballot(waiting);
     return w != 0ull && (__popcll(w) >= flush_lanes || __ballot(running) == 0ull);
@@ -292,27 +301,59 @@ struct hj_block_out {
   __device__ __forceinline__ void put(int idx, int v) {
     reinterpret_cast<hj_i16_alias *>(blk)[idx] = (int16_t)v;
   }
-  __device__ __forceinline__ void flush(uint32_t n, int slot, bool complete, bool head) {
-    const uint32_t b = b0 + n;
-    int16_t *dst = coef + hj_block_offset(*im, mcu0 + b/(uint32_t)im->nslots, slot);
-    if (complete && head) {
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        uint4 v;
-        v.x = blk[4*q]; v.y = blk[4*q + 1]; v.z = blk[4*q + 2]; v.w = blk[4*q + 3];
-        reinterpret_cast<uint4 *>(dst)[q] = v;
-        blk[4*q] = 0; blk[4*q + 1] = 0; blk[4*q + 2] = 0; blk[4*q + 3] = 0;
-      }
-    }
-    else {
-      for (int q = 0; q < 32; q++) {
-        const uint32_t two = blk[q];
-        if (two & 0xffffu) dst[2*q] = (int16_t)(two & 0xffffu);
-        if (two >> 16) dst[2*q + 1] = (int16_t)(two >> 16);
-        blk[q] = 0;
-      }
+  // offset (shorts) of the current MCU's block `slot` in the image's planes
+  // (inverse of the MCU loop nest + block placement of src/xjpeg.c:461-472, 556-561)
+  __device__ __forceinline__ uint32_t offset(int slot) const {
+    const int comp = im->slot_comp[slot];
+    const uint32_t bx = mbx*im->comp_hs[comp] + im->slot_sbx[slot];
+    const uint32_t by = mby*im->comp_vs[comp] + im->slot_sby[slot];
+    const uint32_t xd = im->comp_xdec[comp];
+    const uint32_t rs = (uint32_t)im->w0_blocks*64u;
+    return (uint32_t)im->comp_coef_off[comp] + rs*(by >> xd) + (rs >> xd)*(by & ((1u << xd) - 1u))
+     + (bx << 6);
+  }
+  __device__ __forceinline__ void scatter(int slot) {
+    int16_t *dst = coef + offset(slot);
+    for (int q = 0; q < 32; q++) {
+      const uint32_t two = blk[q];
+      if (two & 0xffffu) dst[2*q] = (int16_t)(two & 0xffffu);
+      if (two >> 16) dst[2*q + 1] = (int16_t)(two >> 16);
+      blk[q] = 0;
     }
   }
+  __device__ __forceinline__ void next_block(int slot) {
+    if (slot + 1 == im->nslots) {
+      mbx++;
+      if (mbx == (uint32_t)im->nhmb) { mbx = 0; mby++; }
+    }
+  }
+  // every lane of the wave calls this together
+  __device__ __forceinline__ void flush_complete(bool waiting, int slot, bool head) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (waiting && !head) scatter(slot);                     // tail of a block begun by an earlier lane
+    const bool full = waiting && head;
+    const unsigned long long mask = __ballot(full);
+    if (mask) {
+      if (full) {
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        rank_lane[r] = (uint8_t)lane;
+        blk[32] = offset(slot)*2u;
+      }
+      const uint32_t cnt = (uint32_t)__popcll(mask), part = lane & 7u;
+      for (uint32_t k = lane >> 3; k < cnt; k += 8) {        // (uniform trip count up to a partial last pass)
+        uint32_t *src = wave_blk + (uint32_t)rank_lane[k]*HJ_BLK_STRIDE;
+        const uint32_t off = src[32];
+        hj_v4u v;
+        v.x = src[4*part]; v.y = src[4*part + 1]; v.z = src[4*part + 2]; v.w = src[4*part + 3];
+        src[4*part] = 0; src[4*part + 1] = 0; src[4*part + 2] = 0; src[4*part + 3] = 0;
+        typedef __attribute__((address_space(1))) hj_v4u global_v4u;
+        __builtin_nontemporal_store(v, (global_v4u *)((uintptr_t)coef + off) + part);
+      }
+    }
+    if (waiting) next_block(slot);
+  }
+  __device__ __forceinline__ void flush_partial(int slot, bool) { scatter(slot); }
 };
 
 __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
@@ -321,6 +362,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   __shared__ uint32_t lds_blk[HJ_BLOCK*HJ_BLK_STRIDE];
   __shared__ hj_image s_im;
   __shared__ uint8_t s_dezz[64];
+  __shared__ uint8_t s_rank[HJ_BLOCK];
   const hj_image im0 = A.images[blockIdx.y];
   if (blockIdx.x*HJ_BLOCK >= im0.nsub) return;              // grid.x covers the largest image
   hj_stage_image(&s_im, A.images + blockIdx.y);
@@ -335,22 +377,26 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   uint32_t *blk = lds_blk + threadIdx.x*HJ_BLK_STRIDE;
 #pragma unroll
   for (int k = 0; k < 32; k++) blk[k] = 0;                  // own buffer only: no barrier needed
-  if (!on) return;
+  // Lanes with nothing to decode stay in the wave with an empty run: the write-out is
+  // wave-collective and counts on all 64 lanes being there.
   const hj_image &im = s_im;
   const uint32_t total = L.seg_nmcu*(uint32_t)im.nslots;
-  const uint32_t b0 = A.B[L.g];
-  if (b0 >= total) return;
+  const uint32_t b0 = on ? A.B[L.g] : 0u;
+  const bool live = on && b0 < total;
   const uint32_t sidx = L.g + im.seg0 + L.si;
-  const uint64_t start = A.S[sidx];
-  const uint64_t stop = L.i + 1 < L.seg_nsub ? hj_pos(A.S[sidx + 1]) : (uint64_t)L.seg_end*8;
+  const uint64_t start = live ? A.S[sidx] : 0ull;
+  const uint64_t stop = !live ? 0ull
+   : L.i + 1 < L.seg_nsub ? hj_pos(A.S[sidx + 1]) : (uint64_t)L.seg_end*8;
   hj_block_out out;
   out.im = &im;
   out.coef = A.coef + (long long)blockIdx.y*A.coef_stride;
   out.blk = blk;
-  out.mcu0 = L.seg_mcu0; out.b0 = b0;
+  out.wave_blk = lds_blk + (threadIdx.x & ~63u)*HJ_BLK_STRIDE;
+  out.rank_lane = s_rank + (threadIdx.x & ~63u);
+  out.init(L.seg_mcu0 + b0/(uint32_t)im.nslots);
   out.flush_lanes = A.flush_lanes;
-  const int err = hj_write_decode(src, im, &lds_tabs, s_dezz,
-   start, stop, total - b0, A.D[3*L.g + 0], A.D[3*L.g + 1], A.D[3*L.g + 2], out);
+  const int err = hj_write_decode(src, im, &lds_tabs, s_dezz, start, stop, live ? total - b0 : 0u,
+   live ? A.D[3*L.g + 0] : 0, live ? A.D[3*L.g + 1] : 0, live ? A.D[3*L.g + 2] : 0, out);
   if (err) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 

@@ -21,6 +21,11 @@ static void init_dezz() {
 
 struct block_out {
   const hj_image *im; const hj_segment *seg; short *coef; uint32_t b0; short blk[64];
+  uint32_t n = 0;                    // complete blocks written so far
+  void flush_complete(bool waiting, int slot, bool head) {
+    if (waiting) { flush(n, slot, true, head); n++; }
+  }
+  void flush_partial(int slot, bool head) { flush(n, slot, false, head); }
   void put(int idx, int v) { blk[idx] = (short)v; }
   bool any(bool x) const { return x; }
   bool flush_due(bool waiting, bool) const { return waiting; }
