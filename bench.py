@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the supplementary e2e leg")
     ap.add_argument("--no-pack", action="store_true", help="skip the PACK expansion leg")
+    ap.add_argument("--no-other", action="store_true", help="skip the other-kernels leg")
     ap.add_argument("--e2e-images", type=int, default=96)
     ap.add_argument("--e2e-threads", type=int, default=0, help="0 = min(cores, 48)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -233,6 +234,54 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_seconds)
+
+    if rank == 0 and world == 1 and not args.no_other:
+        # Supplementary: the other device stages, each against its own algorithmic bytes
+        # (128 B per coded block in, output bytes out), HIP-event timed.
+        others = {}
+
+        def time_stage(gg, n, dc, cs, dq, do, os_, rgb, reps=10):
+            ms = C.c_float()
+            for r in (2, reps):
+                lib.check(lib.L.jga_time_idct_batch(C.byref(gg), n, dc, cs, dq, 1, do, os_, rgb, r,
+                                                    stream, C.byref(ms)))
+            return ms.value
+
+        ys = (g.yuv_bytes + 255) // 256 * 256
+        d_yuv = lib.DeviceBuffer(ys * B)
+        t = time_stage(g, B, d_coef.ptr, cstride, d_q.ptr, d_yuv.ptr, ys, 0)
+        ab = B * (g.coef_blocks * 128 + g.yuv_bytes)
+        others["yuv_stage_420"] = {"kernel": "jga_idct_yuv_kernel", "ms": round(t, 4),
+                                   "GBps": round(ab / t / 1e6, 1), "images": B}
+        # pass 3 alone on those planes (wall-clock over 10 launches)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                lib.check(lib.L.jga_yuv_rgb_batch(C.byref(g), B, d_yuv.ptr, ys, d_out.ptr, ostride,
+                                                  stream))
+            lib.check(lib.L.jga_stream_sync(stream))
+            t = (time.perf_counter() - t0) / 10 * 1e3
+        ab = B * (g.yuv_bytes + g.rgb_bytes)
+        others["yuv_to_rgb_420"] = {"kernel": "jga_yuv_rgb_kernel", "ms": round(t, 4),
+                                    "GBps": round(ab / t / 1e6, 1), "images": B}
+        d_yuv.free()
+        for name, samp, n in (("rgb_444", "444", 24), ("grey", "grey", 48)):
+            data = synth.synthetic_jpeg(W, H, samp, quality=90, seed=1234)
+            h2, g2 = lib.geom_of(data)
+            cs2 = (g2.coef_shorts * 2 + 255) // 256 * 128
+            os2 = (g2.rgb_bytes + 255) // 256 * 256
+            dc2, do2 = lib.DeviceBuffer(cs2 * 2 * n), lib.DeviceBuffer(os2 * n)
+            c2 = lib.entropy_decode(data, g2)
+            for i in range(n):
+                dc2.upload(c2, offset=i * cs2 * 2)
+            dq2 = lib.DeviceBuffer(384 * n)
+            dq2.upload(np.tile(lib.qtab_of(h2).reshape(-1), n))
+            t = time_stage(g2, n, dc2.ptr, cs2, dq2.ptr, do2.ptr, os2, 1)
+            ab = n * (g2.coef_blocks * 128 + g2.rgb_bytes)
+            others[name] = {"kernel": lib.L.jga_kernel_name(C.byref(g2), 1).decode(),
+                            "ms": round(t, 4), "GBps": round(ab / t / 1e6, 1), "images": n}
+            dc2.free(); do2.free(); dq2.free()
+        out["other_kernels"] = others
 
     if rank == 0 and world == 1 and not args.no_e2e:
         n = args.e2e_images

@@ -256,15 +256,6 @@ JGA_EXPORT int jga_huff_last_rounds(const jga_huff_batch *b) { return b->last_ro
 // Quantisation tables of the prepared batch: nimages*3*64 uint16 (host memory).
 JGA_EXPORT const unsigned short *jga_huff_qtabs(const jga_huff_batch *b) { return b->qtab.data(); }
 
-// Debug/test hook: copy the lane start states (nsub + nseg entries per image) to the host.
-JGA_EXPORT long long jga_huff_debug_states(jga_huff_batch *b, unsigned long long *out, long long cap) {
-  const long long n = (long long)b->total_sub + b->total_seg;
-  if (out && cap >= n) {
-    if (hipMemcpy(out, b->d_blob + b->off_S, 8*(size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  }
-  return n;
-}
-
 // Decode the prepared batch into d_coef (image i at d_coef + i*coef_stride shorts).
 // May be called repeatedly on the same prepared batch (state is reset each time).
 JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,

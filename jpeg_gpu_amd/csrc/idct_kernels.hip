@@ -584,48 +584,67 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
 // matrix of res/unyuv.fs.glsl:12-16, 48 on u8 planes): Y/Cb/Cr planes resident in HBM
 // (YUV-stage layout: planes at plane_data_off, padded, pitch = plane width) ->
 // img->pixels.  Used when a caller stops the decode at the YUV stage (the harness's
-// `-o yuv`).  SURVEY.md A.5 arithmetic, evaluated literally.  One thread = 4 pixels
+// `-o yuv`).  SURVEY.md A.5 arithmetic, evaluated literally.  One thread = 8 pixels
 // of one row; HBM-bound: reads 1 + 2/(LW*LH) bytes, writes 3 bytes per pixel.
-DEV uint32_t unorm8(float c) {
-  const float m = __builtin_fminf(__builtin_fmaxf(c, 0.0f), 255.0f);
-  return (uint32_t)(int)(m + 0.5f);
-}
-
 __global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, int xdec, int ydec) {
-  const int x0 = (blockIdx.x*256 + threadIdx.x)*4;
+  // 8 pixels per thread: Y as one 8-byte load, chroma as 8 >> xdec bytes, 24 output bytes
+  const int x0 = (blockIdx.x*256 + threadIdx.x)*8;
   const int y = blockIdx.y, img = blockIdx.z;
   if (x0 >= P.width) return;
-  const uint8_t *base = P.coef ? reinterpret_cast<const uint8_t *>(P.coef) + (long long)img*P.coef_stride : nullptr;
+  const uint8_t *base = reinterpret_cast<const uint8_t *>(P.coef) + (long long)img*P.coef_stride;
   const uint8_t *py = base + P.plane_data_off[0] + (long long)y*(P.plane_hblocks[0]*8) + x0;
-  const int n = P.width - x0 < 4 ? P.width - x0 : 4;
+  const int n = P.width - x0 < 8 ? P.width - x0 : 8;
+  const uint2 yy = *reinterpret_cast<const uint2 *>(py);          // plane rows are whole blocks
   if (P.nplanes == 1) {
     uint8_t *o = P.out + (long long)img*P.out_stride + (long long)y*P.width + x0;
-    for (int i = 0; i < n; i++) o[i] = py[i];
+    if (n == 8 && ((P.width | (int)(P.out_stride & 7)) & 7) == 0 && ((uintptr_t)P.out & 7) == 0) {
+      st_nt(reinterpret_cast<uint2 *>(o), yy);
+    }
+    else {
+      for (int i = 0; i < n; i++) o[i] = (uint8_t)(((i < 4 ? yy.x : yy.y) >> (8*(i & 3))) & 255u);
+    }
     return;
   }
-  const uint8_t *pu = base + P.plane_data_off[1] + (long long)(y >> ydec)*(P.plane_hblocks[1]*8);
-  const uint8_t *pv = base + P.plane_data_off[2] + (long long)(y >> ydec)*(P.plane_hblocks[2]*8);
-  uint32_t px[12];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    // plane rows are padded to whole blocks, so x0+i stays inside the row
-    const float Y = (float)py[i];
-    const float u = (float)pu[(x0 + i) >> xdec] - 128.0f;
-    const float v = (float)pv[(x0 + i) >> xdec] - 128.0f;
-    px[3*i + 0] = unorm8(Y + 1.402f*v);
-    px[3*i + 1] = unorm8((Y + (-0.34414f)*u) + (-0.71414f)*v);
-    px[3*i + 2] = unorm8(Y + 1.772f*u);
+  const uint8_t *pu = base + P.plane_data_off[1] + (long long)(y >> ydec)*(P.plane_hblocks[1]*8)
+   + (x0 >> xdec);
+  const uint8_t *pv = base + P.plane_data_off[2] + (long long)(y >> ydec)*(P.plane_hblocks[2]*8)
+   + (x0 >> xdec);
+  uint32_t ub[2] = {0, 0}, vb[2] = {0, 0};                         // 8 >> xdec chroma bytes
+  if (xdec == 0) {
+    const uint2 a = *reinterpret_cast<const uint2 *>(pu), b = *reinterpret_cast<const uint2 *>(pv);
+    ub[0] = a.x; ub[1] = a.y; vb[0] = b.x; vb[1] = b.y;
   }
-  uint8_t *o = P.out + (long long)img*P.out_stride + ((long long)y*P.width + x0)*3;
-  if (n == 4 && P.out_aligned) {
-    uint32_t *o4 = reinterpret_cast<uint32_t *>(o);
-    o4[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
-    o4[1] = px[4] | (px[5] << 8) | (px[6] << 16) | (px[7] << 24);
-    o4[2] = px[8] | (px[9] << 8) | (px[10] << 16) | (px[11] << 24);
+  else if (xdec == 1) {
+    ub[0] = *reinterpret_cast<const uint32_t *>(pu);
+    vb[0] = *reinterpret_cast<const uint32_t *>(pv);
   }
   else {
-    for (int i = 0; i < 3*n; i++) o[i] = (uint8_t)px[i];
+    ub[0] = *reinterpret_cast<const uint16_t *>(pu);
+    vb[0] = *reinterpret_cast<const uint16_t *>(pv);
   }
+  float rgb[24];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int c = i >> xdec;
+    const float Y = (float)(((i < 4 ? yy.x : yy.y) >> (8*(i & 3))) & 255u);
+    const float u = (float)((ub[c >> 2] >> (8*(c & 3))) & 255u) - 128.0f;
+    const float v = (float)((vb[c >> 2] >> (8*(c & 3))) & 255u) - 128.0f;
+    // clamp + 0.5 + truncation of SURVEY.md A.5; v_cvt_pk_u8_f32 then converts an
+    // integer-valued float in [0,255]
+    rgb[3*i + 0] = __builtin_floorf(__builtin_fminf(__builtin_fmaxf(Y + 1.402f*v, 0.0f), 255.0f) + 0.5f);
+    rgb[3*i + 1] = __builtin_floorf(__builtin_fminf(__builtin_fmaxf((Y + (-0.34414f)*u) + (-0.71414f)*v, 0.0f), 255.0f) + 0.5f);
+    rgb[3*i + 2] = __builtin_floorf(__builtin_fminf(__builtin_fmaxf(Y + 1.772f*u, 0.0f), 255.0f) + 0.5f);
+  }
+  uint4 a;
+  uint2 b2;
+  a.x = pack_u8x4(rgb[0], rgb[1], rgb[2], rgb[3]);
+  a.y = pack_u8x4(rgb[4], rgb[5], rgb[6], rgb[7]);
+  a.z = pack_u8x4(rgb[8], rgb[9], rgb[10], rgb[11]);
+  a.w = pack_u8x4(rgb[12], rgb[13], rgb[14], rgb[15]);
+  b2.x = pack_u8x4(rgb[16], rgb[17], rgb[18], rgb[19]);
+  b2.y = pack_u8x4(rgb[20], rgb[21], rgb[22], rgb[23]);
+  uint8_t *o = P.out + (long long)img*P.out_stride + ((long long)y*P.width + x0)*3;
+  store_rgb_row(o, a, b2, P.out_aligned && n == 8, x0, P.width);
 }
 
 // ---------------------------------------------------------------------------
@@ -675,7 +694,7 @@ extern "C" int jga_launch_yuv(const jga_kparams *P, int staged, void *stream) {
 }
 
 extern "C" int jga_launch_yuv_rgb(const jga_kparams *P, int xdec, int ydec, void *stream) {
-  dim3 grid((P->width + 1023)/1024, P->height, P->nimages), block(256);
+  dim3 grid((P->width + 2047)/2048, P->height, P->nimages), block(256);
   hipLaunchKernelGGL(jga_yuv_rgb_kernel, grid, block, 0, (hipStream_t)stream, *P, xdec, ydec);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

@@ -450,3 +450,27 @@ def test_irregular_huffman_tables_take_the_host_entropy_stage(gpu, orc, synth):
             assert np.array_equal(o, orc.decode_rgb(dd)[1].reshape(-1))
     finally:
         pl.close()
+
+
+@pytest.mark.parametrize("sampling", SAMPLINGS)
+@pytest.mark.parametrize("size", [(17, 9), (100, 75), (642, 363)])
+def test_pass3_alone_matches_oracle(gpu, orc, synth, sampling, size):
+    """jga_yuv_rgb_batch (res/yuv.fs.glsl:16-24 / unyuv.fs.glsl on u8 planes): planes in HBM
+    -> pixels, for every sampling and ragged sizes, two images per launch."""
+    import oracle
+    datas = [synth.synthetic_jpeg(size[0], size[1], sampling, quality=q, seed=q) for q in (90, 40)]
+    _, g = gpu.geom_of(datas[0])
+    ys, os_ = gpu._align(g.yuv_bytes), gpu._align(g.rgb_bytes)
+    d_yuv, d_rgb = gpu.DeviceBuffer(ys * 2), gpu.DeviceBuffer(os_ * 2)
+    try:
+        for i, d in enumerate(datas):
+            _, planes = orc.decode(d, oracle.YUV)
+            d_yuv.upload(np.concatenate([p.reshape(-1) for p in planes]), offset=i * ys)
+        gpu.check(gpu.L.jga_yuv_rgb_batch(C.byref(g), 2, d_yuv.ptr, ys, d_rgb.ptr, os_, None))
+        gpu.check(gpu.L.jga_stream_sync(None))
+        for i, d in enumerate(datas):
+            got = d_rgb.download(g.rgb_bytes, offset=i * os_)
+            assert np.array_equal(got, orc.decode_rgb(d)[1].reshape(-1)), (sampling, size, i)
+    finally:
+        d_yuv.free()
+        d_rgb.free()
