@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 #include "jga_internal.h"
 
@@ -242,7 +243,7 @@ bool grow(void **p, long long *cap, long long want, bool pinned) {
 
 // Decode jobs[0..m) as ONE batch of the GPU entropy stage.  Fails as a whole (mixed
 // geometry, a corrupt member, ...); the caller then retries the members one by one.
-int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
+int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads) {
   const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
   const bool copy_back = pl->cfg.copy_back != 0;
   std::vector<const unsigned char *> ptrs((size_t)m);
@@ -250,9 +251,9 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
   long long total = 0;
   jga_geom g;
   for (int i = 0; i < m; i++) {
-    ptrs[i] = jobs[i].jpeg;
-    sizes[i] = jobs[i].size;
-    total += jobs[i].size + 4096;
+    ptrs[i] = jobv[i]->jpeg;
+    sizes[i] = jobv[i]->size;
+    total += jobv[i]->size + 4096;
   }
   if (!l.hb || m > l.hb_images || total > l.hb_scan) {
     if (l.hb) jga_huff_destroy(l.hb);
@@ -268,7 +269,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
   jpeg_header hdr;
   if (jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream) != EXIT_SUCCESS) {
     if (m != 1 || !strstr(jga_last_error(), "too irregular")) return EXIT_FAILURE;
-    if (jga_parse_header(jobs[0].jpeg, jobs[0].size, &hdr) != EXIT_SUCCESS
+    if (jga_parse_header(jobv[0]->jpeg, jobv[0]->size, &hdr) != EXIT_SUCCESS
      || jga_geom_from_header(&g, &hdr) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
     }
@@ -290,7 +291,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
     memset(q, 0, sizeof(q));
     for (int p = 0; p < g.nplanes; p++) memcpy(q + 64*p, hdr.comp[p].quant->tbl, 128);
     if (!grow((void **)&l.h_coef, &l.cap_hcoef, cstride*2, true)) return EXIT_FAILURE;
-    if (jga_entropy_decode(jobs[0].jpeg, jobs[0].size, &g, l.h_coef, 0) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (jga_entropy_decode(jobv[0]->jpeg, jobv[0]->size, &g, l.h_coef, 0) != EXIT_SUCCESS) return EXIT_FAILURE;
     if (!HOK(hipMemcpyAsync(l.d_q, q, sizeof(q), hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
     if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;       // q is on this stack frame
     if (!HOK(hipMemcpyAsync(l.d_coef, l.h_coef, (size_t)g.coef_shorts*2, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
@@ -300,7 +301,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
     if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
   }
   bool scattered = false;
-  for (int i = 0; i < m; i++) scattered = scattered || jobs[i].dev_out != nullptr;
+  for (int i = 0; i < m; i++) scattered = scattered || jobv[i]->dev_out != nullptr;
   if (!scattered) {
     if ((rgb ? jga_idct_rgb_batch(&g, m, l.d_coef, cstride, l.d_q, 1, l.d_out, ostride, l.stream)
      : jga_idct_yuv_batch(&g, m, l.d_coef, cstride, l.d_q, 1, l.d_out, ostride, l.stream)) != EXIT_SUCCESS) {
@@ -309,7 +310,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
   }
   else {
     for (int i = 0; i < m; i++) {
-      unsigned char *dst = jobs[i].dev_out ? jobs[i].dev_out : l.d_out + ostride*i;
+      unsigned char *dst = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
       if ((rgb ? jga_idct_rgb_batch(&g, 1, l.d_coef + cstride*i, cstride, l.d_q + 192*i, 1, dst, ostride, l.stream)
        : jga_idct_yuv_batch(&g, 1, l.d_coef + cstride*i, cstride, l.d_q + 192*i, 1, dst, ostride, l.stream)) != EXIT_SUCCESS) {
         return EXIT_FAILURE;
@@ -318,32 +319,58 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *jobs, int m, int threads) {
   }
   if (copy_back) {
     for (int i = 0; i < m; i++) {
-      if (!jobs[i].host_out) continue;
-      const unsigned char *src = jobs[i].dev_out ? jobs[i].dev_out : l.d_out + ostride*i;
+      if (!jobv[i]->host_out) continue;
+      const unsigned char *src = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
       if (!HOK(hipMemcpyAsync(l.h_out + ostride*i, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return EXIT_FAILURE;
     }
   }
   if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;
   const long long up = host_entropy ? g.coef_shorts*2 : jga_huff_upload_bytes(l.hb)/m;
   for (int i = 0; i < m; i++) {
-    if (copy_back && jobs[i].host_out) memcpy(jobs[i].host_out, l.h_out + ostride*i, (size_t)out_bytes);
-    jobs[i].width = g.width; jobs[i].height = g.height; jobs[i].nplanes = g.nplanes;
-    jobs[i].h2d_bytes = up;
-    jobs[i].status = EXIT_SUCCESS;
+    if (copy_back && jobv[i]->host_out) memcpy(jobv[i]->host_out, l.h_out + ostride*i, (size_t)out_bytes);
+    jobv[i]->width = g.width; jobv[i]->height = g.height; jobv[i]->nplanes = g.nplanes;
+    jobv[i]->h2d_bytes = up;
+    jobv[i]->status = EXIT_SUCCESS;
   }
   return EXIT_SUCCESS;
 }
 
-void run_lane(jga_pipeline *pl, hlane *l, jga_job *jobs, int n, std::atomic<int> *next,
- int batch, int threads) {
+// Frame size + sampling of a JPEG without a full parse: (Y<<48 | X<<32 | Nf<<24 | sampling
+// bytes), 0 if no SOF0 is found.  Jobs are bucketed by it so that one batch of the GPU
+// entropy stage holds one geometry even when the stream of jobs mixes sizes.
+uint64_t geometry_key(const unsigned char *p, int size) {
+  int i = 2;
+  if (size < 4 || p[0] != 0xFF || p[1] != 0xD8) return 0;
+  while (i + 4 <= size) {
+    if (p[i] != 0xFF) return 0;
+    const int m = p[i + 1];
+    if (m == 0xFF) { i++; continue; }
+    const int len = (p[i + 2] << 8) | p[i + 3];
+    if (m == 0xC0) {
+      if (i + 2 + len > size || len < 11) return 0;
+      const unsigned char *f = p + i + 4;           // P, Y, X, Nf, then (C, HV, Tq) per component
+      uint64_t k = ((uint64_t)((f[1] << 8) | f[2]) << 48) | ((uint64_t)((f[3] << 8) | f[4]) << 32)
+       | ((uint64_t)f[5] << 24);
+      for (int c = 0; c < f[5] && c < 3 && 8 + 3*c < len - 2; c++) k |= (uint64_t)f[7 + 3*c] << (8*c);
+      return k | 1ull << 63;
+    }
+    if (m == 0xDA || m == 0xD9) return 0;
+    i += 2 + len;
+  }
+  return 0;
+}
+
+void run_lane(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *groups,
+ std::atomic<int> *next, int threads) {
   if (!HOK(hipSetDevice(pl->cfg.device))) return;
   for (;;) {
-    const int i0 = next->fetch_add(batch);
-    if (i0 >= n) break;
-    const int m = n - i0 < batch ? n - i0 : batch;
-    if (lane_group(pl, *l, jobs + i0, m, threads) == EXIT_SUCCESS) continue;
+    const int gi = next->fetch_add(1);
+    if (gi >= (int)groups->size()) break;
+    std::vector<jga_job *> &grp = (*groups)[gi];
+    const int m = (int)grp.size();
+    if (lane_group(pl, *l, grp.data(), m, threads) == EXIT_SUCCESS) continue;
     if (m == 1) continue;
-    for (int i = 0; i < m; i++) (void)lane_group(pl, *l, jobs + i0 + i, 1, 1);   // isolate the bad one(s)
+    for (int i = 0; i < m; i++) (void)lane_group(pl, *l, &grp[i], 1, 1);   // isolate the bad one(s)
   }
 }
 
@@ -402,8 +429,25 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     const int nl = (int)pl->lanes.size();
     int per = pl->cfg.nthreads/nl;
     if (per < 1) per = 1;
+    // bucket the jobs by geometry, in arrival order, `batch` to a group
+    std::vector<std::vector<jga_job *>> groups;
+    {
+      std::unordered_map<uint64_t, size_t> open;      // geometry -> its group still filling up
+      for (int i = 0; i < n; i++) {
+        const uint64_t key = geometry_key(jobs[i].jpeg, jobs[i].size);
+        auto it = key ? open.find(key) : open.end();
+        if (it == open.end()) {
+          groups.emplace_back();
+          groups.back().reserve(key ? batch : 1);
+          if (key) it = open.emplace(key, groups.size() - 1).first;
+          else { groups.back().push_back(&jobs[i]); continue; }      // unparsable: fails on its own
+        }
+        groups[it->second].push_back(&jobs[i]);
+        if ((int)groups[it->second].size() >= batch) open.erase(it);
+      }
+    }
     for (int t = 0; t < nl; t++) {
-      threads.emplace_back(run_lane, pl, &pl->lanes[t], jobs, n, &next, batch, per);
+      threads.emplace_back(run_lane, pl, &pl->lanes[t], &groups, &next, per);
     }
     for (auto &th : threads) th.join();
     for (int i = 0; i < n; i++) failed += jobs[i].status != EXIT_SUCCESS;
