@@ -38,11 +38,20 @@
 #define HJ_MAX_SLOTS 10           /* blocks per MCU (4:1:1 / 4:2:0 = 6) */
 
 // The Huffman tables of one image in device form: a two-level lookup that never
-// leaves LDS.  Level 1 is indexed by the next 9 bits: (len << 8) | symbol for codes
-// of up to 9 bits, or 0x8000 | n for a longer code whose remaining bits select an
-// entry of level-2 block n (128 entries, indexed by bits 9..15): (len << 8) | symbol
-// again, 0 for bit patterns that are no code.  With SIMT divergence a rarely taken
-// slow path is taken by every wave, so it has to be as cheap as the fast one.
+// leaves LDS.  Level 1 is indexed by the next 9 bits and holds, for codes of up to 9
+// bits, a 16-bit ENTRY
+//     len << 10 | s << 6 | adv1        len  = code length (1..16)
+//                                      s    = magnitude bits that follow (symbol & 15)
+//                                      adv1 = how far the zig-zag index moves, minus one:
+//                                             0 for a DC code, the run for an AC code,
+//                                             63 for EOB (k + 64 always ends the block)
+// so that the decode loops need no per-symbol case analysis: k' = k + adv1 + 1 and the
+// block is complete iff k' >= 64.  For a longer code level 1 holds 0x8000 | n and the
+// code's bits 9..15 select an entry of level-2 block n (128 entries).  Bit patterns that
+// are no code decode as a 16-bit EOB (AC) / zero difference (DC): they only occur on
+// trajectories that started out of step, or in corrupt data, which the block-count
+// checks of hj_scan catch.  With SIMT divergence a rarely taken slow path is taken by
+// every wave, so it has to be as cheap as the fast one.
 #define HJ_L2_BLOCKS 16
 struct hj_tables {
   uint16_t l1[6][1 << HJ_FAST_BITS];   // [2*comp] = DC, [2*comp + 1] = AC of that component
@@ -120,13 +129,16 @@ struct hj_reader {
   HJ_HD uint64_t tell() const { return p; }
 };
 
-// Look up the symbol at the top of window `w` in table `ti`: returns (len << 8) | symbol
-// (len = 16, symbol = 0 for a bit pattern that is no code).
+// Look up the code at the top of window `w` in table `ti`: returns its entry.
 HJ_HD uint32_t hj_lookup(const hj_tables *T, int ti, uint32_t w) {
   uint32_t e = T->l1[ti][w >> (32 - HJ_FAST_BITS)];
   if (e & 0x8000u) e = T->l2[((e & 0x7fffu) << 7) | ((w >> 16) & 127u)];
-  return e ? e : (16u << 8);
+  return e;
 }
+#define HJ_ENTRY(len, s, adv1) ((uint16_t)(((len) << 10) | ((s) << 6) | (adv1)))
+#define HJ_E_LEN(e) ((int)((e) >> 10))
+#define HJ_E_S(e) ((int)(((e) >> 6) & 15u))
+#define HJ_E_ADV1(e) ((int)((e) & 63u))
 
 // The `s` magnitude bits that follow a `len`-bit code in window `w`, extended (T.81 F.2.2.1).
 HJ_HD int hj_value(uint32_t w, int len, int s) {
@@ -135,75 +147,11 @@ HJ_HD int hj_value(uint32_t w, int len, int s) {
   return v - ((v >> (s - 1)) ? 0 : (1 << s) - 1);
 }
 
-// A sink receives decoded values; the sync/count passes use hj_null_sink.
-struct hj_null_sink {
-  HJ_HD void block_begin(uint32_t, int, int) {}
-  HJ_HD void dc(int, int) {}
-  HJ_HD void ac(int, int) {}
-  HJ_HD void finish(int) {}
-};
-
-// Decode from `start` until the first symbol boundary whose raw bit position is
-// >= stop_bit (or until max_blocks blocks are complete).  `tabs[2*comp]`/`[2*comp+1]`
-// and the matching `fast` arrays (possibly LDS copies) are the DC/AC tables.
-// Sink protocol: block_begin(n, slot, k) when the run's n-th block becomes current
-// (k != 0 only for n == 0: a block some earlier lane began), dc()/ac() for its
-// values, finish(k) at the end of the run (k != 0: the current block is incomplete).
-// `T` = the image's tables (an LDS copy on the GPU); `slot_comp_bits` = component of
-// MCU slot c in bits [2c, 2c+1] (keeps the per-symbol lookups free of indexed
-// private arrays, which would live in scratch).
-template <class Src, class Sink>
-HJ_HD hj_run hj_decode(const Src &src, const hj_image &im, const hj_tables *T,
- uint64_t start, uint64_t stop_bit, uint32_t max_blocks, Sink &sink) {
-  uint32_t slot_comp_bits = 0;
-  for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
-  const int nslots = im.nslots;
-  hj_reader<Src> br;
-  hj_run r;
-  int k = hj_k(start), c = hj_slot(start);
-  int dc0 = 0, dc1 = 0, dc2 = 0;     // scalars, not an indexed array (would live in scratch)
-  r.nblocks = 0;
-  r.error = 0;
-  br.init(src, hj_pos(start));
-  sink.block_begin(0, c, k);         // block 0 of this run may be one a previous lane began
-  int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
-  while (br.tell() < stop_bit && r.nblocks < max_blocks) {
-    const uint32_t w = br.window();
-    const uint32_t e = hj_lookup(T, 2*comp + (k != 0), w);  // DC table for k == 0, else AC
-    const int len = (int)(e >> 8), rs = (int)(e & 255u), s = rs & 15;
-    const int v = hj_value(w, len, s);
-    br.skip(len + s);
-    if (k == 0) {
-      dc0 += comp == 0 ? v : 0;
-      dc1 += comp == 1 ? v : 0;
-      dc2 += comp == 2 ? v : 0;
-      sink.dc(comp, v);
-      k = 1;
-    }
-    else if (rs == 0) k = 64;                               // EOB
-    else {
-      k += rs >> 4;
-      if (k > 63) { r.error = 1; k = 63; }
-      else if (s) sink.ac(k, v);
-      k++;
-    }
-    if (k >= 64) {
-      r.nblocks++;
-      c = c + 1 == nslots ? 0 : c + 1;
-      comp = (int)((slot_comp_bits >> (2*c)) & 3u);
-      k = 0;
-      sink.block_begin(r.nblocks, c, 0);
-    }
-  }
-  sink.finish(k);
-  r.dcsum[0] = (int16_t)dc0; r.dcsum[1] = (int16_t)dc1; r.dcsum[2] = (int16_t)dc2;
-  r.end_state = hj_pack(br.tell(), c, k);
-  return r;
-}
-
-// Lean, branch-light variant of hj_decode for the synchronisation rounds: same
-// trajectory and the same hj_run (end state, block count, DC sums), no sink, no
-// coefficient values except the DC differences.  Every lane of a wave executes
+// Decode from `start` until the first symbol boundary whose bit position is >= stop_bit:
+// the synchronisation rounds' run.  Produces the hj_run (end state, blocks completed, DC
+// difference sums), no coefficient values except the DC differences.  `T` = the image's
+// tables (an LDS copy on the GPU); the component of MCU slot c sits in bits [2c, 2c+1]
+// of a register (an indexed private array would live in scratch).  Every lane of a wave executes
 // every instruction of a divergent loop, so the per-symbol instruction count is
 // what the rounds cost.
 template <class Src>
@@ -223,7 +171,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
     const uint32_t w = br.window();
     const int isdc = k == 0;
     const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
-    const int len = (int)(e >> 8), sym = (int)(e & 255u), s = sym & 15;
+    const int len = HJ_E_LEN(e), s = HJ_E_S(e);
     br.skip(len + s);
     if (isdc) {                                            // DC difference, extended
       const int v = hj_value(w, len, s);
@@ -231,8 +179,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
       dc1 += comp == 1 ? v : 0;
       dc2 += comp == 2 ? v : 0;
     }
-    int kn = sym ? k + (sym >> 4) + 1 : 64;                // AC: run, then the coefficient; EOB
-    kn = isdc ? 1 : kn;
+    const int kn = k + HJ_E_ADV1(e) + 1;                   // DC: 1; AC: past the run; EOB: >= 64
     const int done = kn >= 64;
     nblocks += (uint32_t)done;
     c = done ? (c + 1 == nslots ? 0 : c + 1) : c;
@@ -282,7 +229,7 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
       const uint32_t w = br.window();
       const int isdc = k == 0;
       const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
-      const int len = (int)(e >> 8), sym = (int)(e & 255u), s = sym & 15;
+      const int len = HJ_E_LEN(e), s = HJ_E_S(e), adv1 = HJ_E_ADV1(e);
       int v = hj_value(w, len, s);
       br.skip(len + s);
       if (isdc) {
@@ -291,10 +238,9 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
         pred2 += comp == 2 ? v : 0;
         v = (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);    // wraps like xjpeg.c:480
       }
-      const int kk = isdc ? 0 : k + (sym >> 4);            // zig-zag index of this coefficient
-      if (kk > 63) error = 1;
-      else if (isdc || s) out.put(dezz[kk], v);
-      const int kn = isdc ? 1 : (sym ? kk + 1 : 64);
+      const int kn = k + adv1 + 1;                         // one past this coefficient's zig-zag index
+      if (kn > 64 && adv1 != 63) error = 1;                // an AC run past coefficient 63
+      else if (isdc || s) out.put(dezz[kn - 1], v);
       waiting = kn >= 64;                                  // block complete: wait for the write-out
       k = waiting ? 0 : kn;
     }

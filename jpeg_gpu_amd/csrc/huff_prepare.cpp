@@ -12,12 +12,17 @@ static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char b
  const unsigned char *vals) {
   unsigned code = 0;
   int k = 0;
+  const bool is_dc = (ti & 1) == 0;
+  // what a bit pattern that is no code decodes as (see hj_tables)
+  const uint16_t nocode = HJ_ENTRY(16, 0, is_dc ? 0 : 63);
+  const int l2_first = *l2_used;
   uint16_t *l1 = T->l1[ti];
   memset(l1, 0, sizeof(T->l1[ti]));
   for (int len = 1; len <= 16; len++) {
     for (int i = 0; i < bits[len - 1]; i++, k++, code++) {
       if (k >= 256 || code >= (1u << len)) return 1;
-      const uint16_t entry = (uint16_t)((len << 8) | vals[k]);
+      const int sym = vals[k];
+      const uint16_t entry = HJ_ENTRY(len, sym & 15, is_dc ? 0 : (sym == 0 ? 63 : sym >> 4));
       if (len <= HJ_FAST_BITS) {
         const unsigned c = code << (HJ_FAST_BITS - len);
         for (unsigned j = 0; j < (1u << (HJ_FAST_BITS - len)); j++) l1[c + j] = entry;
@@ -37,6 +42,8 @@ static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char b
     }
     code <<= 1;
   }
+  for (int j = 0; j < (1 << HJ_FAST_BITS); j++) if (!l1[j]) l1[j] = nocode;
+  for (int j = 128*l2_first; j < 128*(*l2_used); j++) if (!T->l2[j]) T->l2[j] = nocode;
   return 0;
 }
 
