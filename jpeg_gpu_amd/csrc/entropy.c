@@ -465,7 +465,7 @@ static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
   if (s < 0 || s > 15) return jga_fail("Error invalid DC code.");
   if (s) *pred = (short)(*pred + receive_extend(br, s));
   if (stage == JGA_STAGE_PACK) {
-    if (so->nwords + 66 > so->pack_cap) return jga_fail("Error PACK buffer too small.");
+    if (so->nwords + 64 > so->pack_cap) return jga_fail("Error PACK buffer too small.");   /* a block is at most 1 + 63 words */
     so->pack[so->nwords++] = (short)(*pred & 0xfff);
   }
   else {

@@ -89,6 +89,39 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   delete b;
 }
 
+// Streams cut into very many restart intervals (one MCU per interval, a 9 x 65528 frame...)
+// need more subsequence / segment slots than the byte count suggests: grow the per-lane
+// arrays and the upload blob in place.  Called between two barriers of prepare(), by one
+// thread, with the scan region of h_blob already written (it is carried over).
+static bool grow_batch(jga_huff_batch *b, size_t need_sub, size_t need_blob) {
+  if (need_sub > b->sub_cap) {
+    const size_t cap = need_sub + need_sub/4 + 1024;
+    if (b->d_last_in) (void)hipFree(b->d_last_in);
+    if (b->d_R) (void)hipFree(b->d_R);
+    if (b->d_B) (void)hipFree(b->d_B);
+    if (b->d_D) (void)hipFree(b->d_D);
+    b->d_last_in = NULL; b->d_R = NULL; b->d_B = NULL; b->d_D = NULL; b->sub_cap = 0;
+    if (hipMalloc((void **)&b->d_last_in, 8*cap) != hipSuccess
+     || hipMalloc((void **)&b->d_R, sizeof(hj_run)*cap) != hipSuccess
+     || hipMalloc((void **)&b->d_B, 4*cap) != hipSuccess
+     || hipMalloc((void **)&b->d_D, 6*cap) != hipSuccess) {
+      return false;
+    }
+    b->sub_cap = cap;
+  }
+  if (need_blob > b->blob_cap) {
+    const size_t cap = need_blob + need_blob/4;
+    unsigned char *h = NULL, *d = NULL;
+    if (hipHostMalloc((void **)&h, cap, hipHostMallocDefault) != hipSuccess) return false;
+    if (hipMalloc((void **)&d, cap) != hipSuccess) { (void)hipHostFree(h); return false; }
+    memcpy(h, b->h_blob, b->scan_bytes);
+    (void)hipHostFree(b->h_blob);
+    (void)hipFree(b->d_blob);
+    b->h_blob = h; b->d_blob = d; b->blob_cap = cap;
+  }
+  return true;
+}
+
 // A team of threads that runs a few phases over the images of a batch, with a barrier
 // and a short serial section (thread 0) between phases: one spawn per prepare().
 namespace {
@@ -178,7 +211,6 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
         total_seg += prep[i].segs.size();
         if (prep[i].im.nsub > max_nsub) max_nsub = prep[i].im.nsub;
       }
-      if (total_sub > b->sub_cap || total_seg > b->sub_cap) fatal.store(2);
       b->nimages = n;
       b->total_sub = (uint32_t)total_sub;
       b->total_seg = (uint32_t)total_seg;
@@ -191,7 +223,8 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
       b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
       b->blob_size = o;
-      if (o > b->blob_cap) fatal.store(2);
+      const size_t need_sub = total_sub > total_seg ? total_sub : total_seg;
+      if ((need_sub > b->sub_cap || o > b->blob_cap) && !grow_batch(b, need_sub, o)) fatal.store(2);
       if (fatal.load()) stop.store(1);
     }
     bar.wait();

@@ -109,9 +109,9 @@ bool ensure_slot(slot &s, long long coef_shorts, long long out_bytes, bool copy_
     if (s.d_pack) (void)hipFree(s.d_pack);
     s.h_coef = nullptr; s.d_coef = nullptr; s.h_pack = nullptr; s.d_pack = nullptr; s.cap_coef = 0;
     if (index_count) {   // PACK transport: the dense planes exist on the device only
-      // a block is at most 1 + 63 words, so the dense size (+ slack for the producer's per-block check) holds any stream
-      if (!HOK(hipHostMalloc((void **)&s.h_pack, (coef_shorts + 128)*sizeof(short), hipHostMallocDefault))) return false;
-      if (!HOK(hipMalloc((void **)&s.d_pack, (coef_shorts + 128)*sizeof(short)))) return false;
+      // a block is at most 1 + 63 words, so the dense size holds any stream
+      if (!HOK(hipHostMalloc((void **)&s.h_pack, coef_shorts*sizeof(short), hipHostMallocDefault))) return false;
+      if (!HOK(hipMalloc((void **)&s.d_pack, coef_shorts*sizeof(short)))) return false;
     }
     else if (!HOK(hipHostMalloc((void **)&s.h_coef, coef_shorts*sizeof(short), hipHostMallocDefault))) return false;
     if (!HOK(hipMalloc((void **)&s.d_coef, coef_shorts*sizeof(short)))) return false;
@@ -172,7 +172,7 @@ void run_worker(jga_pipeline *pl, worker *w, jga_job *jobs, int n,
     // host entropy stage, straight into pinned memory
     long long nwords = 0;
     if (packed) {
-      if (jga_entropy_decode_pack(job->jpeg, job->size, &g, s.h_pack, s.cap_coef + 128, s.h_index,
+      if (jga_entropy_decode_pack(job->jpeg, job->size, &g, s.h_pack, s.cap_coef, s.h_index,
        &nwords, nullptr) != EXIT_SUCCESS) {
         continue;
       }

@@ -474,3 +474,31 @@ def test_pass3_alone_matches_oracle(gpu, orc, synth, sampling, size):
     finally:
         d_yuv.free()
         d_rgb.free()
+
+
+@pytest.mark.parametrize("sampling", ["420", "grey", "411"])
+@pytest.mark.parametrize("size", [(1, 1), ("max", 9), (9, "max")])
+def test_extreme_dimensions_every_path(gpu, orc, synth, sampling, size):
+    """The smallest frame and the largest ones whose MCU-padded planes still fit image.h's
+    unsigned-short plane dimensions (src/image.h:31-32): plugin with the GPU entropy stage,
+    PACK expansion + fused kernel, and the host-entropy pipeline all give the oracle's pixels."""
+    from jpeg_gpu_amd import abi
+    mcu = {"420": (16, 16), "grey": (8, 8), "411": (32, 8)}[sampling]
+    w, h = [(65535 // mcu[i]) * mcu[i] if v == "max" else v for i, v in enumerate(size)]
+    data = synth.synthetic_jpeg(w, h, sampling, quality=75, seed=7, restart_interval=-1)
+    want = orc.decode_rgb(data)[1].reshape(-1)
+    with gpu.Decoder(data) as d:                      # GPU entropy stage + fused kernel
+        d.read_header()
+        d.init_image()
+        d.decode(abi.JPEG_DECODE_RGB)
+        assert np.array_equal(d.pixels().reshape(-1), want)
+    _, g = gpu.geom_of(data)
+    pack, index, _ = gpu.entropy_decode_pack(data, g)  # PACK words expanded on the GPU
+    assert np.array_equal(gpu.gpu_unpack(g, [pack], [index])[0], gpu.entropy_decode(data, g))
+    out = np.zeros(want.size, np.uint8)
+    pl = gpu.Pipeline(device=0, nthreads=1, out=abi.JPEG_DECODE_RGB, copy_back=True)
+    try:
+        rc, _ = pl.run([data], host_outs=[out])
+        assert rc == 0 and np.array_equal(out, want)
+    finally:
+        pl.close()

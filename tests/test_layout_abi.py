@@ -119,3 +119,17 @@ def test_product_never_touches_oracle():
                                  if not l.strip().startswith(("#", "//", "*", "/*")))
                 assert "import oracle" not in code and "liboracle" not in code \
                     and "libjpeggpu_ref" not in code, f
+
+
+def test_frames_whose_padded_planes_overflow_image_h_are_refused(lib, synth):
+    """image_plane.width/height are unsigned shorts (src/image.h:31-32): a 65535-wide 4:2:0 frame
+    pads to 65536 and cannot be described; the reference wraps silently, this build refuses."""
+    import pytest
+    with lib.Decoder(synth.synthetic_jpeg(65535, 8, "420", quality=50)) as d:
+        d.read_header()
+        with pytest.raises(lib.JgaError, match="too large"):
+            d.init_image()
+    with lib.Decoder(synth.synthetic_jpeg(65520, 8, "420", quality=50)) as d:
+        d.read_header()
+        d.init_image()
+        assert d.img.plane[0].width == 65520 and d.img.plane[1].width == 32760
