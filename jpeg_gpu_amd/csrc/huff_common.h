@@ -48,9 +48,9 @@
 // so that the decode loops need no per-symbol case analysis: k' = k + adv1 + 1 and the
 // block is complete iff k' >= 64.  For a longer code level 1 holds 0x8000 | n and the
 // code's bits 9..15 select an entry of level-2 block n (128 entries).  Bit patterns that
-// are no code decode as a 16-bit EOB (AC) / zero difference (DC): they only occur on
-// trajectories that started out of step, or in corrupt data, which the block-count
-// checks of hj_scan catch.  With SIMT divergence a rarely taken slow path is taken by
+// are no code decode as a 17-bit EOB (AC) / zero difference (DC): they occur on
+// trajectories that started out of step (harmless) or in corrupt data, where the final
+// pass reports them (len > 16), like the host stage's "invalid code" errors.  With SIMT divergence a rarely taken slow path is taken by
 // every wave, so it has to be as cheap as the fast one.
 #define HJ_L2_BLOCKS 16
 struct hj_tables {
@@ -239,6 +239,7 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
         v = (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);    // wraps like xjpeg.c:480
       }
       const int kn = k + adv1 + 1;                         // one past this coefficient's zig-zag index
+      if (len > 16) error = 1;                             // a bit pattern that is no code
       if (kn > 64 && adv1 != 63) error = 1;                // an AC run past coefficient 63
       else if (isdc || s) out.put(dezz[kn - 1], v);
       waiting = kn >= 64;                                  // block complete: wait for the write-out

@@ -14,7 +14,7 @@ static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char b
   int k = 0;
   const bool is_dc = (ti & 1) == 0;
   // what a bit pattern that is no code decodes as (see hj_tables)
-  const uint16_t nocode = HJ_ENTRY(16, 0, is_dc ? 0 : 63);
+  const uint16_t nocode = HJ_ENTRY(17, 0, is_dc ? 0 : 63);
   const int l2_first = *l2_used;
   uint16_t *l1 = T->l1[ti];
   memset(l1, 0, sizeof(T->l1[ti]));

@@ -502,3 +502,45 @@ def test_extreme_dimensions_every_path(gpu, orc, synth, sampling, size):
         assert rc == 0 and np.array_equal(out, want)
     finally:
         pl.close()
+
+
+def test_gpu_huffman_on_corrupted_scans_agrees_with_the_host_stage(gpu, synth):
+    """Random byte edits, bit flips and deletions inside the entropy-coded data: the GPU
+    entropy stage always returns (no hang, no crash), rejects exactly the files the host stage
+    rejects, and produces the same coefficients for the ones both accept."""
+    rng = np.random.default_rng(5)
+    accepted = rejected = 0
+    for it in range(160):
+        samp = ["420", "444", "grey", "422"][it % 4]
+        d = bytearray(synth.synthetic_jpeg(200 + it % 37, 120 + it % 23, samp, quality=70,
+                                           restart_interval=[0, 3, -1][it % 3], seed=it))
+        lo = d.find(b"\xff\xda") + 14
+        for _ in range(int(rng.integers(1, 6))):
+            pos = int(rng.integers(lo, len(d) - 2))
+            mode = int(rng.integers(0, 3))
+            if mode == 0:
+                d[pos] = int(rng.integers(0, 256))
+            elif mode == 1:
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+            else:
+                del d[pos]
+        d = bytes(d)
+        try:
+            _, g = gpu.geom_of(d)
+        except gpu.JgaError:
+            continue
+        try:
+            want = gpu.entropy_decode(d, g)
+        except gpu.JgaError:
+            want = None
+        try:
+            got = gpu.gpu_entropy_decode([d])[1][0]
+        except gpu.JgaError:
+            got = None
+        assert (got is None) == (want is None), it
+        if got is not None:
+            assert np.array_equal(got, want), it
+            accepted += 1
+        else:
+            rejected += 1
+    assert accepted > 20 and rejected > 20
