@@ -67,6 +67,13 @@ def make_inputs(synth, n, rank):
                            seeds))
 
 
+def device_facts(torch, dev):
+    p = torch.cuda.get_device_properties(dev)
+    return {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": p.multi_processor_count,
+            "hbm_GB": round(p.total_memory / 2**30, 1),
+            "clock_MHz": getattr(p, "clock_rate", 0) // 1000 or None}
+
+
 def cpu_baseline(jpegs, seconds):
     """The CPU port of the whole path (oracle.orc_decode_rgb: Huffman + float IDCT
     + clamp + upsample + RGB), one image per thread on the host cores; bounded."""
@@ -230,6 +237,7 @@ def main():
             "parallelism": "image-sharded x%d, no collectives" % world,
             "kernel": lib.L.jga_kernel_name(C.byref(g), 1).decode(),
             "bit_exact_vs_oracle": ok,
+            "device": device_facts(torch, local_rank),
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
