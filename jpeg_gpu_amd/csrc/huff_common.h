@@ -122,12 +122,22 @@ struct hj_mem_src {
 template <class Src>
 struct hj_reader {
   Src src;
-  uint32_t p;                        // bit position in the image's clean scan
-  HJ_HD void init(const Src &source, uint64_t pos) { src = source; p = (uint32_t)pos; }
+  uint32_t p, stop;                  // bit positions in the image's clean scan
+  HJ_HD void init(const Src &source, uint64_t pos, uint64_t stop_bit) {
+    src = source; p = (uint32_t)pos; stop = (uint32_t)stop_bit;
+  }
+  HJ_HD bool before_stop() const { return p < stop; }
   HJ_HD uint32_t window() const { return src.window32(p); }
   HJ_HD void skip(int n) { p += (uint32_t)n; }
   HJ_HD uint64_t tell() const { return p; }
 };
+
+// Which reader a bit source is read with: the one above unless the source brings its own
+// (the LDS source of the kernels does: huff_kernels.hip).
+template <class Src, class = void>
+struct hj_reader_of { typedef hj_reader<Src> type; };
+template <class Src>
+struct hj_reader_of<Src, typename Src::has_reader> { typedef typename Src::reader type; };
 
 // Look up the code at the top of window `w` in table `ti`: returns its entry.
 HJ_HD uint32_t hj_lookup(const hj_tables *T, int ti, uint32_t w) {
@@ -160,14 +170,14 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
   uint32_t slot_comp_bits = 0;
   for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
   const int nslots = im.nslots;
-  hj_reader<Src> br;
+  typename hj_reader_of<Src>::type br;
   hj_run r;
   int k = hj_k(start), c = hj_slot(start);
   int dc0 = 0, dc1 = 0, dc2 = 0;
   uint32_t nblocks = 0;
-  br.init(src, hj_pos(start));
+  br.init(src, hj_pos(start), stop_bit);
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
-  while (br.tell() < stop_bit) {
+  while (br.before_stop()) {
     const uint32_t w = br.window();
     const int isdc = k == 0;
     const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
@@ -216,14 +226,14 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
   uint32_t slot_comp_bits = 0;
   for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
   const int nslots = im.nslots;
-  hj_reader<Src> br;
+  typename hj_reader_of<Src>::type br;
   int k = hj_k(start), c = hj_slot(start), error = 0;
   bool head = k == 0, waiting = false;
   uint32_t n = 0;
-  br.init(src, hj_pos(start));
+  br.init(src, hj_pos(start), stop_bit);
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
   for (;;) {
-    const bool running = !waiting && br.tell() < stop_bit && n < max_blocks;
+    const bool running = !waiting && br.before_stop() && n < max_blocks;
     if (!out.any(running || waiting)) break;
     if (running) {
       const uint32_t w = br.window();

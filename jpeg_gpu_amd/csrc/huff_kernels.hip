@@ -35,12 +35,29 @@ __device__ const uint8_t HJ_DEZZ[64] = {     // T.81 Figure A.6: zig-zag index -
 struct hj_lds_src {
   const uint32_t *base;              // first dword of this subsequence's copy
   uint32_t bit0;                     // clean-scan bit position of that dword
-  __device__ __forceinline__ uint32_t window32(uint32_t p) const {
-    const uint32_t r = p - bit0;
-    const uint32_t *q = base + (r >> 5);
-    const uint64_t v = ((uint64_t)q[0] << 32) | q[1];
-    return (uint32_t)(v >> (32 - (r & 31)));
-  }
+  // Reader in the copy's own coordinates: r1 = (position - bit0) - 1.  With q = the dword
+  // holding bit r1, the 32 bits that start at bit r1 + 1 are ({q[0], q[1]} >> (31 - r1 % 32)),
+  // one v_alignbit_b32 whose shift operand is simply ~r1 (the instruction reads 5 bits) —
+  // a shift of 0..31 in every case, including the dword-aligned one that a plain
+  // "shift by 32 - offset" formulation cannot express.
+  typedef void has_reader;
+  struct reader {
+    const uint32_t *base;
+    uint32_t bit0;
+    int32_t r1, stop1;
+    __device__ __forceinline__ void init(const hj_lds_src &src, uint64_t pos, uint64_t stop_bit) {
+      base = src.base; bit0 = src.bit0;
+      r1 = (int32_t)((uint32_t)pos - bit0) - 1;
+      stop1 = (int32_t)((uint32_t)stop_bit - bit0) - 1;
+    }
+    __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
+    __device__ __forceinline__ uint32_t window() const {
+      const uint32_t *q = base + (r1 >> 5);                  // r1 = -1: the dword before (unused bits)
+      return __builtin_amdgcn_alignbit(q[0], q[1], ~(uint32_t)r1);
+    }
+    __device__ __forceinline__ void skip(int n) { r1 += n; }
+    __device__ __forceinline__ uint64_t tell() const { return (uint64_t)((uint32_t)(r1 + 1) + bit0); }
+  };
 };
 
 struct hj_lane_ctx {                 // what a lane knows about its subsequence
@@ -118,7 +135,8 @@ struct hj_run16 {                    // (the end state lives in lds_S / S)
 
 __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int round, int max_iters) {
   __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
-  __shared__ uint32_t lds_win[HJ_WIN_DWORDS];
+  __shared__ uint32_t lds_win_mem[1 + HJ_WIN_DWORDS];      // [0]: the dword "before" row 0 (hj_lds_src::reader)
+  uint32_t *lds_win = lds_win_mem + 1;
   __shared__ uint64_t lds_S[HJ_BLOCK + 1];       // start state of each subsequence of the group
   __shared__ hj_run16 lds_R[HJ_BLOCK];           // result of its latest run
   __shared__ uint32_t lds_stop[HJ_BLOCK];        // stop byte | bit 31: has a successor in its segment
@@ -358,7 +376,8 @@ struct hj_block_out {
 
 __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
-  __shared__ uint32_t lds_win[HJ_WIN_DWORDS];
+  __shared__ uint32_t lds_win_mem[1 + HJ_WIN_DWORDS];      // [0]: the dword "before" row 0 (hj_lds_src::reader)
+  uint32_t *lds_win = lds_win_mem + 1;
   __shared__ uint32_t lds_blk[HJ_BLOCK*HJ_BLK_STRIDE];
   __shared__ hj_image s_im;
   __shared__ uint8_t s_dezz[64];
