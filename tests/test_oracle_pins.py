@@ -192,3 +192,24 @@ def test_pack_consumer_restatement_against_reference_goldens(orc, lib, golden_jp
             blocks = orc.unpack_blocks(pack, index[ipos])
             got[off[:, None] + np.arange(64)] = blocks
         assert np.array_equal(got, quant), name
+
+
+@pytest.mark.parametrize("sampling", ["444", "422", "420"])
+def test_rgb_stage_definition_is_sane_against_libjpeg_turbo(orc, synth, sampling):
+    """The reference has no CPU code for upsample + YCbCr->RGB, so oracle.c's
+    restatement of res/unyuv.fs.glsl IS the definition of that stage.  Cross-check, with a
+    tolerance and not for equality: libjpeg-turbo (through Pillow, when it is installed) decodes
+    the same files with a different IDCT (ISLOW integer), fancy upsampling off, to pixels that
+    differ by rounding only."""
+    PIL = pytest.importorskip("PIL.Image")
+    import io
+    data = synth.synthetic_jpeg(320, 200, sampling, quality=92, seed=9)
+    _, rgb = orc.decode_rgb(data)
+    im = PIL.open(io.BytesIO(data))
+    im.draft("RGB", im.size)
+    ref = np.asarray(im.convert("RGB"), dtype=np.int16)
+    diff = np.abs(rgb.reshape(200, 320, 3).astype(np.int16) - ref)
+    # 4:4:4: rounding only.  Subsampled: nearest-neighbour replication here vs libjpeg's
+    # triangle filter, on chroma that carries per-pixel noise — a few levels, no pixel far off.
+    mean_max, p99_max = (1.0, 4) if sampling == "444" else (3.0, 16)
+    assert diff.mean() < mean_max and np.percentile(diff, 99) <= p99_max, (diff.mean(), diff.max())
