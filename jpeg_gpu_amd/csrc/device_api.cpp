@@ -274,8 +274,8 @@ JGA_EXPORT int jga_time_idct_batch(const jga_geom *g, int nimages,
   HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
   HIP_TRY(hipEventSynchronize(e1));
   HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   if (ms) *ms = t/(float)reps;
   return rc;
 }

@@ -172,7 +172,8 @@ static int dump_image(const image *img, jpeg_decode_out out) {
         break;
       }
       default : {
-        fprintf(stderr, "Unsupported output '%s'.\n", OUT_NAMES[out]);
+        fprintf(stderr, "Unsupported output '%s'.\n",
+         (unsigned)out < JPEG_DECODE_OUT_MAX ? OUT_NAMES[out] : "?");
         return EXIT_FAILURE;
       }
     }

@@ -314,7 +314,7 @@ struct hj_block_out {
   // Write out when `flush_lanes` lanes hold a finished block, or when nobody can decode on.
   __device__ __forceinline__ bool flush_due(bool waiting, bool running) const {
     const unsigned long long w = __ballot(waiting);
-    return w != 0ull && (__popcll(w) >= flush_lanes || __ballot(running) == 0ull);
+    return w != 0ull && ((int)__popcll(w) >= flush_lanes || __ballot(running) == 0ull);
   }
   __device__ __forceinline__ void put(int idx, int v) {
     reinterpret_cast<hj_i16_alias *>(blk)[idx] = (int16_t)v;

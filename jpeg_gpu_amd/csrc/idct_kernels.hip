@@ -43,15 +43,12 @@ typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 // Output pixels are written once and never re-read by the kernel: nontemporal
 // (streaming) stores keep them from thrashing L2 — on MI355X a read+write stream
 // runs 5.7 TB/s with nt stores vs 3.6-4.8 TB/s with plain ones (tools/membench2,
-// profiles/r1_membench2.txt).  Coefficients are read once: nt loads too.
+// profiles/r1_membench2.txt).  (Loads stay plain: the 8 row loads of a lane share L1 lines.)
 DEV void st_nt(uint4 *p, const uint4 v) {
   __builtin_nontemporal_store(__builtin_bit_cast(v4u, v), reinterpret_cast<v4u *>(p));
 }
 DEV void st_nt(uint2 *p, const uint2 v) {
   __builtin_nontemporal_store(__builtin_bit_cast(v2u, v), reinterpret_cast<v2u *>(p));
-}
-DEV uint4 ld_nt(const uint4 *p) {
-  return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p)));
 }
 
 // n / d for n < 2^31 with a host-precomputed reciprocal (kernel_params.h):
