@@ -284,6 +284,9 @@ int main(int argc, char *argv[]) {
   jpeg_decode_ctx *dec;
   int c, loi;
   memset(&info, 0, sizeof(info));
+  /* this program keeps one image for the life of each decoder context, so the plugin may
+   * register its buffers and copy results straight into them */
+  setenv("JGA_PLUGIN_REGISTER", "1", 0);
   while ((c = getopt_long(argc, argv, OPTSTRING, OPTIONS, &loi)) != EOF) {
     switch (c) {
       case 0 : {

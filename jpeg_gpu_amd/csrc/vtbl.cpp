@@ -46,6 +46,9 @@ struct hipjpeg_ctx {
   long long cap_coef, cap_out;
   jga_huff_batch *hb;         // GPU entropy stage, one image
   long long hb_scan;
+  // caller buffers (img->pixels, plane data) registered with HIP so that the D2H copy
+  // lands in them directly; the harness decodes into the same image every frame
+  struct { void *ptr; size_t bytes; } reg[4];
 };
 
 int gpu_entropy_wanted(void) {
@@ -57,7 +60,41 @@ int gpu_entropy_wanted(void) {
   return mode;
 }
 
+// True if [p, p+bytes) is (now) registered.  OPT-IN (JGA_PLUGIN_REGISTER=1): it is only
+// safe for a caller that keeps the image's buffers alive and in place for as long as the
+// decoder context lives (the harness does; a caller that frees and re-allocates its image
+// between frames would leave a stale registration behind).  Default: the staged copy.
+bool registered(hipjpeg_ctx *c, void *p, size_t bytes) {
+  static int want = -1;
+  if (want < 0) {
+    const char *e = getenv("JGA_PLUGIN_REGISTER");
+    want = (e && strcmp(e, "1") == 0) ? 1 : 0;
+  }
+  if (!want || !p || !bytes) return false;
+  int free_slot = -1;
+  for (int i = 0; i < 4; i++) {
+    if (c->reg[i].ptr == p && c->reg[i].bytes >= bytes) return true;
+    if (c->reg[i].ptr == p) { (void)hipHostUnregister(p); c->reg[i].ptr = NULL; }
+    if (!c->reg[i].ptr && free_slot < 0) free_slot = i;
+  }
+  if (free_slot < 0) {                     // a different image: start over
+    for (int i = 0; i < 4; i++) { (void)hipHostUnregister(c->reg[i].ptr); c->reg[i].ptr = NULL; }
+    free_slot = 0;
+  }
+  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  c->reg[free_slot].ptr = p;
+  c->reg[free_slot].bytes = bytes;
+  return true;
+}
+
 void release_device(hipjpeg_ctx *c) {
+  for (int i = 0; i < 4; i++) {
+    if (c->reg[i].ptr) (void)hipHostUnregister(c->reg[i].ptr);
+    c->reg[i].ptr = NULL;
+  }
   if (c->hb) jga_huff_destroy(c->hb);
   c->hb = NULL; c->hb_scan = 0;
   if (c->h_coef) (void)hipHostFree(c->h_coef);
@@ -217,13 +254,39 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
      c->d_out, c->cap_out, c->stream)) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
     }
-    HIP_OK(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
-    if (rgb) memcpy(img->pixels, c->h_out, out_bytes);
+    // D2H straight into the caller's buffers when they can be registered, else through
+    // the pinned staging buffer
+    if (rgb) {
+      if (registered(c, img->pixels, (size_t)out_bytes)) {
+        HIP_OK(hipMemcpyAsync(img->pixels, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+      }
+      else {
+        HIP_OK(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        memcpy(img->pixels, c->h_out, out_bytes);
+      }
+    }
     else {
+      bool direct = true;
       for (i = 0; i < img->nplanes; i++) {
-        memcpy(img->plane[i].data, c->h_out + g->plane[i].data_off,
+        direct = direct && registered(c, img->plane[i].data,
          (size_t)img->plane[i].ystride*img->plane[i].height);
+      }
+      if (direct) {
+        for (i = 0; i < img->nplanes; i++) {
+          HIP_OK(hipMemcpyAsync(img->plane[i].data, c->d_out + g->plane[i].data_off,
+           (size_t)img->plane[i].ystride*img->plane[i].height, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_OK(hipStreamSynchronize(c->stream));
+      }
+      else {
+        HIP_OK(hipMemcpyAsync(c->h_out, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipStreamSynchronize(c->stream));
+        for (i = 0; i < img->nplanes; i++) {
+          memcpy(img->plane[i].data, c->h_out + g->plane[i].data_off,
+           (size_t)img->plane[i].ystride*img->plane[i].height);
+        }
       }
     }
   }

@@ -319,12 +319,12 @@ class Decoder:
         return a.copy()
 
     def close(self):
+        if self.ctx:                       # the reference's order: decode_free, then image_clear
+            VTBL.decode_free(self.ctx)
+            self.ctx = None
         if self.img is not None:
             L.jga_image_clear(C.byref(self.img))
             self.img = None
-        if self.ctx:
-            VTBL.decode_free(self.ctx)
-            self.ctx = None
 
     def __enter__(self):
         return self
