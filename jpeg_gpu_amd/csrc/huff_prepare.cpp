@@ -5,6 +5,43 @@
 #include <stdlib.h>
 #include <string.h>
 #include "huff_prepare.h"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+// Copy src[0..n) to dst until the first 0xFF byte (not copied); returns the number of bytes
+// before it (n if there is none).  May write up to 31 bytes of junk past the returned count
+// (the callers' buffers have that room and overwrite it next).  The scan is mostly FF-free
+// runs of a few hundred bytes: a fused compare+copy beats memchr + memcpy per run.
+#if defined(__x86_64__)
+__attribute__((target("avx2")))
+static uint32_t copy_until_ff_avx2(unsigned char *dst, const unsigned char *src, uint32_t n) {
+  uint32_t i = 0;
+  const __m256i ff = _mm256_set1_epi8((char)0xFF);
+  while (i + 32 <= n) {
+    const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+    const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, ff));
+    _mm256_storeu_si256((__m256i *)(dst + i), v);
+    if (m) return i + (uint32_t)__builtin_ctz(m);
+    i += 32;
+  }
+  while (i < n && src[i] != 0xFF) { dst[i] = src[i]; i++; }
+  return i;
+}
+#endif
+static uint32_t copy_until_ff_plain(unsigned char *dst, const unsigned char *src, uint32_t n) {
+  const unsigned char *ff = n ? (const unsigned char *)memchr(src, 0xFF, n) : NULL;
+  const uint32_t k = ff ? (uint32_t)(ff - src) : n;
+  memcpy(dst, src, k);
+  return k;
+}
+static uint32_t copy_until_ff(unsigned char *dst, const unsigned char *src, uint32_t n) {
+#if defined(__x86_64__)
+  static const int have_avx2 = __builtin_cpu_supports("avx2");
+  if (have_avx2) return copy_until_ff_avx2(dst, src, n);
+#endif
+  return copy_until_ff_plain(dst, src, n);
+}
 
 // Build the two-level lookup of one table into T->l1[ti] (+ level-2 blocks taken
 // from *l2_used).  Returns 0, 1 = malformed DHT, 2 = out of level-2 blocks.
@@ -120,11 +157,11 @@ int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsig
   int expect = 0, rc = EXIT_SUCCESS;
   bool done = false;
   while (!done) {
-    const unsigned char *ff = pos < avail ? (const unsigned char *)memchr(scan + pos, 0xFF, avail - pos) : NULL;
-    const uint32_t at = ff ? (uint32_t)(ff - scan) : avail;
+    const uint32_t run = pos < avail ? copy_until_ff(dst + w, scan + pos, avail - pos) : 0;
+    const uint32_t at = pos + run;
+    const bool ff = at < avail;                                 // scan[at] == 0xFF
     const int marker = (ff && at + 1 < avail) ? scan[at + 1] : 0xD9;   // running off the end == EOI
-    memcpy(dst + w, scan + pos, at - pos);
-    w += at - pos;
+    w += run;
     if (ff && marker == 0x00) { dst[w++] = 0xFF; pos = at + 2; continue; }   // stuffed zero
     if (ff && marker == 0xFF) { pos = at + 1; continue; }               // fill byte
     // a real marker (or the end of the buffer) closes the current segment
