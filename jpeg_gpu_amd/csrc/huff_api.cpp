@@ -33,6 +33,8 @@ struct jga_huff_batch {
   int16_t *d_D;
   uint32_t *d_ran, *d_errors;
   uint32_t *h_ran;             // pinned readback
+  hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
+  hipEvent_t ev_begin, ev_zeroed;
   size_t sub_cap;
   // current batch
   int nimages;
@@ -66,7 +68,10 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipMalloc((void **)&b->d_D, 6*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS) == hipSuccess
    && hipMalloc((void **)&b->d_errors, 4*(size_t)max_images) == hipSuccess
-   && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess;
+   && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess
+   && hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) == hipSuccess
+   && hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming) == hipSuccess
+   && hipEventCreateWithFlags(&b->ev_zeroed, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     jga_fail("huff: allocation failed (%d images, %lld scan bytes)", max_images, max_scan_bytes);
     jga_huff_destroy(b);
@@ -86,6 +91,9 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_D) (void)hipFree(b->d_D);
   if (b->d_ran) (void)hipFree(b->d_ran);
   if (b->d_errors) (void)hipFree(b->d_errors);
+  if (b->side) (void)hipStreamDestroy(b->side);
+  if (b->ev_begin) (void)hipEventDestroy(b->ev_begin);
+  if (b->ev_zeroed) (void)hipEventDestroy(b->ev_zeroed);
   delete b;
 }
 
@@ -319,7 +327,12 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipMemsetAsync(b->d_last_in, 0xFF, 8*(size_t)b->total_sub, st));
   HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));
   HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
-  HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, st));
+  // the planes are only touched by the write pass: zero them on the side stream, behind
+  // whatever the caller's stream has queued so far, while the rounds run
+  HOK(hipEventRecord(b->ev_begin, st));
+  HOK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
+  HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
+  HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
   static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16;
   if (it0 < 0) {
@@ -344,6 +357,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   b->last_rounds = 0;
   while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;
   if (hj_launch_scan(&A, (int)b->total_seg, st)) return jga_fail("huff: launch failed");
+  HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
   if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
   HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
   HOK(hipStreamSynchronize(st));
