@@ -306,10 +306,12 @@ def main():
             nt = max(1, min(os.cpu_count() or 1, 96)) if transport == 2 else nthr
             pl = lib.Pipeline(device=local_rank, nthreads=nt, out=abi.JPEG_DECODE_RGB,
                               copy_back=copy_back, transport=transport, batch=24, depth=4)
-            n = args.e2e_images*2 if transport == 2 else args.e2e_images   # the fast path needs more to ramp
+            # enough images for every worker to reach steady state (its two slots allocated in the
+            # warm-up, then several images each); the fast path needs more to ramp
+            n = args.e2e_images*2 if transport == 2 else max(args.e2e_images, 4*nthr)
             jobs = [jpegs[i % len(jpegs)] for i in range(n)]
             outs = [np.empty(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
-            nw = 96 if transport == 2 else 16                          # warm: slots/lanes, pages
+            nw = 96 if transport == 2 else 2*nthr                      # warm: slots/lanes, pages
             pl.run(jobs[:nw], host_outs=outs[:nw] if outs else None)
             t0 = time.perf_counter()
             rc, done = pl.run(jobs, host_outs=outs)
