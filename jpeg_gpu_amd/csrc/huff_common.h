@@ -2,11 +2,11 @@
 //
 // SURVEY.md §8(f)-1 / BASELINE config 5: the reference decodes the scan serially
 // on the host (src/xjpeg.c:449-632; restart handling 593-629).  Here the scan is
-// cut into fixed-size SUBSEQUENCES of raw bytes; one GPU lane decodes one
+// unstuffed on the host and cut into fixed-size SUBSEQUENCES; one GPU lane decodes one
 // subsequence.  Huffman streams self-synchronise, so a lane that starts at an
 // arbitrary bit soon falls into step with the true symbol sequence:
 //
-//   state  = (raw bit position p, next coefficient index k, block slot c in MCU)
+//   state  = (bit position p in the clean scan, next coefficient index k, block slot c in MCU)
 //   S[0]   = known (segment start, k = 0, c = 0); restart markers make more
 //            segments, each with a known S[0] (xjpeg.c:612-618)
 //   round 0: lane i decodes from a GUESS at the start of subsequence i to the
@@ -34,7 +34,7 @@
 #endif
 
 #define HJ_FAST_BITS 9
-#define HJ_SUB_BYTES 128          /* subsequence length in raw scan bytes */
+#define HJ_SUB_BYTES 128          /* subsequence length in clean scan bytes */
 #define HJ_MAX_SLOTS 10           /* blocks per MCU (4:1:1 / 4:2:0 = 6) */
 
 // The Huffman tables of one image in device form: a two-level lookup that never

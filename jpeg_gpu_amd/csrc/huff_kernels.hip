@@ -6,13 +6,15 @@
 //                  propagation needs no extra launch.
 //   hj_scan        one workgroup per restart segment: exclusive prefix sums of
 //                  block counts and DC-difference sums over the segment's lanes
-//   hj_write       one lane per subsequence: final decode.  Blocks a lane decodes
-//                  completely are assembled in LDS and leave as one 128-byte line;
-//                  only the pieces of blocks that straddle lanes are scattered.
-// Integer/byte work.  The scan bytes a workgroup needs (its 256 consecutive
-// subsequences, ~33 KB) are staged into LDS with coalesced 16-byte loads, padded
-// by one dword per 128 bytes so that lanes reading at a 128-byte stride hit
-// different banks; the two-level Huffman lookup of the image (14 KB) sits next to them.
+//   hj_write       one lane per subsequence: final decode.  Blocks are assembled in LDS;
+//                  a lane that finishes one waits until enough lanes of its wave have,
+//                  then the wave writes them out together as full 128-byte lines.  Only
+//                  the pieces of blocks that straddle lanes are scattered.
+// Integer/byte work.  Every subsequence of a workgroup gets its own LDS copy — 35
+// big-endian dwords (alignment + 128 bytes + look-ahead) at an odd stride, so lanes
+// walking their own copies hit different banks — next to the image's two-level Huffman
+// lookup (10 KB).  LDS is what bounds occupancy: 53.7 KB per sync workgroup (3 per CU),
+// 80.3 KB per write workgroup (2 per CU).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "huff_common.h"
