@@ -102,6 +102,7 @@ def build(force=False, verbose=False):
                "-c", os.path.join(CSRC, s), "-o", o]
         if s.endswith(".hip"):
             cmd.insert(1, "-save-temps=obj")
+        cmd[1:1] = os.environ.get("JGA_EXTRA_HIPFLAGS", "").split()      # tuning experiments
         _run(cmd)
         objs.append(o)
         if s == "idct_kernels.hip":      # the float path; huff_kernels is integer/byte code

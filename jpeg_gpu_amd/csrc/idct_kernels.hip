@@ -404,19 +404,34 @@ struct rgb_cfg {
   static constexpr int NCW = 2*TILE/64;                    // chroma waves
   static constexpr int THREADS = (NLW + NCW)*64;
   static constexpr int CW = 8 >> XDEC, CH = 8 >> YDEC;     // chroma patch per luma block
-  // LDS floats: hand-off [comp][row][chroma block][8] + the image's 3 q tables
+  // Work balance: a luma lane would run IDCT + 8 rows of colour conversion, a chroma lane
+  // IDCT + publish only, and the chroma waves would idle through the conversion.  So the luma
+  // lanes convert their first OWN rows from registers and hand the last SHARE rows to the
+  // chroma lanes through LDS ([row][luma block][8] floats).
+  static constexpr int NLB = LW*LH*TILE;                   // luma blocks per tile
+  // (measured, tools/ab_variants.sh: 4:2:0 best at 1 shared row, -1.4 %; 4:4:4 at 3, -4 %: the
+  // hardware back-fills most of the idle slots by itself)
+#ifndef JGA_SHARE_1
+#define JGA_SHARE_1 3                /* 4:4:4: 1 luma block per MCU */
+#define JGA_SHARE_2 4                /* 4:2:2, 4:4:0 */
+#define JGA_SHARE_4 1                /* 4:2:0, 4:1:1 */
+#endif
+  static constexpr int SHARE = (LW*LH == 1) ? JGA_SHARE_1 : (LW*LH == 2) ? JGA_SHARE_2 : JGA_SHARE_4;
+  static constexpr int OWN = 8 - SHARE;
+  // LDS floats: hand-off [comp][row][chroma block][8] + the image's 3 q tables + shared rows
   static constexpr int CHROMA_FLOATS = 2*8*TILE*8;
-  static constexpr int LDS_FLOATS = CHROMA_FLOATS + 3*32;
+  static constexpr int YSHARE_FLOATS = SHARE*NLB*8;
+  static constexpr int LDS_FLOATS = CHROMA_FLOATS + 3*32 + YSHARE_FLOATS;
 };
 
-// Upsample + convert + store the 8 pixel rows of one luma block.
-template <int XDEC, int YDEC, bool CLAMP>
+// Upsample + convert + store pixel rows [0, NROWS) of one luma block.
+template <int XDEC, int YDEC, bool CLAMP, int NROWS>
 DEV void colour_rows(const float (&t)[64], const float *ub, const float *vb, uint8_t *obase,
  long long pitch, bool fast, int x0, int y0, int width, int height) {
   typedef rgb_cfg<XDEC, YDEC> cfg;
   chroma_row<cfg::CW> cr;
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < NROWS; k++) {
     if ((k & (cfg::LH - 1)) == 0) {
       float u[cfg::CW], v[cfg::CW];
 #pragma unroll
@@ -440,6 +455,7 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
   __shared__ float lds[cfg::LDS_FLOATS];
   float *chroma = lds;
   uint4 *qlds = reinterpret_cast<uint4 *>(lds + cfg::CHROMA_FLOATS);
+  float *yshare = lds + cfg::CHROMA_FLOATS + 3*32;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tx = blockIdx.x, mrow = blockIdx.y, img = blockIdx.z;
@@ -511,19 +527,77 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
       }
     }
   }
+  else {
+    // hand the last SHARE rows of this luma block (clamped) to the chroma lanes
+    const int idx = wave*64 + lane;
+#pragma unroll
+    for (int r = cfg::OWN; r < 8; r++) {
+      float *dst = yshare + ((r - cfg::OWN)*cfg::NLB + idx)*8;
+#pragma unroll
+      for (int h = 0; h < 8; h += 4) {
+        v4f v;
+        v.x = t[r*8 + h]; v.y = t[r*8 + h + 1]; v.z = t[r*8 + h + 2]; v.w = t[r*8 + h + 3];
+        if (clip) {
+          v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
+          v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
+          v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
+          v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
+        }
+        *reinterpret_cast<v4f *>(dst + h) = v;
+      }
+    }
+  }
   __syncthreads();
-  if (!is_luma || !valid) return;
-
-  // chroma patch of this luma block: rows suby*CH.., cols subx*CW..
-  const float *ub = chroma + ((suby*cfg::CH)*cfg::TILE + cb)*8 + subx*cfg::CW;
-  const float *vb = ub + 8*cfg::TILE*8;
-  const int x0 = bx*8, y0 = by*8;
   const long long pitch = (long long)P.width*3;
-  uint8_t *obase = P.out + (long long)img*P.out_stride + (long long)y0*pitch
-   + (long long)x0*3;
-  const bool fast = P.out_aligned && x0 + 8 <= P.width;
-  if (clip) colour_rows<XDEC, YDEC, true>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
-  else colour_rows<XDEC, YDEC, false>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
+  uint8_t *img_out = P.out + (long long)img*P.out_stride;
+
+  if (is_luma) {
+    if (!valid) return;
+    // chroma patch of this luma block: rows suby*CH.., cols subx*CW..
+    const float *ub = chroma + ((suby*cfg::CH)*cfg::TILE + cb)*8 + subx*cfg::CW;
+    const float *vb = ub + 8*cfg::TILE*8;
+    const int x0 = bx*8, y0 = by*8;
+    uint8_t *obase = img_out + (long long)y0*pitch + (long long)x0*3;
+    const bool fast = P.out_aligned && x0 + 8 <= P.width;
+    if (clip) colour_rows<XDEC, YDEC, true, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
+    else colour_rows<XDEC, YDEC, false, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
+    return;
+  }
+
+  // chroma lanes: the shared rows, one (luma block, row) unit at a time
+  const int cl = (wave - cfg::NLW)*64 + lane;                // 0 .. NCW*64-1
+#pragma unroll
+  for (int u0 = 0; u0 < cfg::SHARE*cfg::NLB; u0 += cfg::NCW*64) {
+    const int unit = u0 + cl;
+    const int rs = unit/cfg::NLB, idx = unit - rs*cfg::NLB;  // NLB is a power of two
+    const int k = cfg::OWN + rs;                             // pixel row inside the block
+    const int sy = idx/cfg::ROWLEN, lx = idx - sy*cfg::ROWLEN;
+    const int ubx = cbx0*cfg::LW + lx, uby = mrow*cfg::LH + sy;
+    const bool live = unit < cfg::SHARE*cfg::NLB && ubx < P.plane_hblocks[0];
+    const int ucb = lx >> XDEC, usubx = lx & (cfg::LW - 1);
+    const float *ub = chroma + (live ? ((sy*cfg::CH + (k >> YDEC))*cfg::TILE + ucb)*8 + usubx*cfg::CW : 0);
+    const float *vb = ub + 8*cfg::TILE*8;
+    float u[cfg::CW], v[cfg::CW];
+#pragma unroll
+    for (int c = 0; c < cfg::CW; c++) { u[c] = ub[c]; v[c] = vb[c]; }
+    chroma_row<cfg::CW> cr;
+    cr.set(u, v);
+    float y8[8];
+    {
+      const v4f *ys = reinterpret_cast<const v4f *>(yshare + (live ? (rs*cfg::NLB + idx)*8 : 0));
+      const v4f a = ys[0], b = ys[1];
+      y8[0] = a.x; y8[1] = a.y; y8[2] = a.z; y8[3] = a.w;
+      y8[4] = b.x; y8[5] = b.y; y8[6] = b.z; y8[7] = b.w;
+    }
+    uint4 a;
+    uint2 b;
+    rgb_row<XDEC, cfg::CW, false>(y8, cr, a, b);             // already clamped by its luma lane
+    const int x0 = ubx*8, yy = uby*8 + k;
+    if (live && yy < P.height) {
+      store_rgb_row(img_out + (long long)yy*pitch + (long long)x0*3, a, b,
+       P.out_aligned && x0 + 8 <= P.width, x0, P.width);
+    }
+  }
 }
 
 // Grey: one plane, img->pixels is 1 B/px at the true size (ungrey.fs.glsl:18;

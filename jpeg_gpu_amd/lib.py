@@ -8,7 +8,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjpeg_gpu_amd.so")
+LIB_PATH = os.environ.get("JGA_LIB_PATH") or os.path.join(_HERE, "libjpeg_gpu_amd.so")   # (override: A/B builds)
 
 # Symbols include/jpeg_gpu_amd.h declares (checked by tests/test_abi.py).
 EXPORTED = [
