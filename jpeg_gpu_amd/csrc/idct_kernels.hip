@@ -295,6 +295,25 @@ DEV void store_rgb_row(uint8_t *o, const uint4 a, const uint2 b2, bool fast,
   }
 }
 
+// The same row for a whole wave whose 64 lanes own 64 horizontally adjacent blocks, all
+// inside the image: the wave's 1536 bytes are contiguous, so they go through a per-wave LDS
+// line and leave as 16 bytes per lane, back to back (1 KB + 512 B bursts) instead of
+// 16 + 8 bytes at a 24-byte stride.  `row0` = address of lane 0's first pixel (16-byte aligned).
+DEV void store_rgb_row_wave(uint32_t *wstage, int lane, uint8_t *row0, const uint4 a, const uint2 b2) {
+  uint2 *w2 = reinterpret_cast<uint2 *>(wstage) + lane*3;
+  w2[0] = make_uint2(a.x, a.y);
+  w2[1] = make_uint2(a.z, a.w);
+  w2[2] = b2;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint4 *r4 = reinterpret_cast<const uint4 *>(wstage);
+  st_nt(reinterpret_cast<uint4 *>(row0) + lane, r4[lane]);
+  if (lane < 32) st_nt(reinterpret_cast<uint4 *>(row0) + 64 + lane, r4[64 + lane]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // Fetch the 8 coefficient rows of the block at `src` (128 contiguous bytes).
 DEV void load_block_direct(const int16_t *__restrict__ src, uint4 (&rows)[8]) {
   const uint4 *p = reinterpret_cast<const uint4 *>(src);
@@ -422,12 +441,17 @@ struct rgb_cfg {
   static constexpr int CHROMA_FLOATS = 2*8*TILE*8;
   static constexpr int YSHARE_FLOATS = SHARE*NLB*8;
   static constexpr int LDS_FLOATS = CHROMA_FLOATS + 3*32 + YSHARE_FLOATS;
+  // Wave-staged pixel stores (store_rgb_row_wave): when a wave's 64 lanes are 64 adjacent
+  // blocks of one row.  -6 % time at 4:2:0; not at 4:4:4, whose larger LDS footprint already
+  // limits it to few workgroups per CU (+12 % there).
+  static constexpr bool STAGE_STORES = (ROWLEN % 64 == 0) && (LW*LH >= 2);
 };
 
 // Upsample + convert + store pixel rows [0, NROWS) of one luma block.
 template <int XDEC, int YDEC, bool CLAMP, int NROWS>
 DEV void colour_rows(const float (&t)[64], const float *ub, const float *vb, uint8_t *obase,
- long long pitch, bool fast, int x0, int y0, int width, int height) {
+ long long pitch, bool fast, int x0, int y0, int width, int height, bool wfast, uint32_t *wstage,
+ int lane) {
   typedef rgb_cfg<XDEC, YDEC> cfg;
   chroma_row<cfg::CW> cr;
 #pragma unroll
@@ -444,7 +468,10 @@ DEV void colour_rows(const float (&t)[64], const float *ub, const float *vb, uin
     uint4 a;
     uint2 b;
     rgb_row<XDEC, cfg::CW, CLAMP>(t + k*8, cr, a, b);
-    if (y0 + k < height) store_rgb_row(obase + k*pitch, a, b, fast, x0, width);
+    if (wfast) {                       // wave-uniform (as is y0 when wfast)
+      if (y0 + k < height) store_rgb_row_wave(wstage, lane, obase - lane*24 + k*pitch, a, b);
+    }
+    else if (y0 + k < height) store_rgb_row(obase + k*pitch, a, b, fast, x0, width);
   }
 }
 
@@ -456,8 +483,10 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
   float *chroma = lds;
   uint4 *qlds = reinterpret_cast<uint4 *>(lds + cfg::CHROMA_FLOATS);
   float *yshare = lds + cfg::CHROMA_FLOATS + 3*32;
+  __shared__ __attribute__((aligned(16))) uint32_t stage_mem[cfg::STAGE_STORES ? cfg::NLW + cfg::NCW : 1][384];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t *wstage = stage_mem[cfg::STAGE_STORES ? wave : 0];
   const int tx = blockIdx.x, mrow = blockIdx.y, img = blockIdx.z;
   const int cbx0 = tx*cfg::TILE;               // first MCU / chroma block of the tile
   const long long rs = (long long)P.w0_blocks*64;
@@ -552,15 +581,19 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
   uint8_t *img_out = P.out + (long long)img*P.out_stride;
 
   if (is_luma) {
+    const int x0 = bx*8, y0 = by*8;
+    // all 64 lanes of the wave inside the image and the run 16-byte aligned: staged stores
+    const bool wfast = cfg::STAGE_STORES && P.out_aligned && (pitch & 15) == 0
+     && __builtin_amdgcn_ballot_w64(valid && x0 + 8 <= P.width) == ~0ull
+     && (((uintptr_t)img_out + (unsigned long long)__builtin_amdgcn_readfirstlane(x0)*3u) & 15u) == 0;
     if (!valid) return;
     // chroma patch of this luma block: rows suby*CH.., cols subx*CW..
     const float *ub = chroma + ((suby*cfg::CH)*cfg::TILE + cb)*8 + subx*cfg::CW;
     const float *vb = ub + 8*cfg::TILE*8;
-    const int x0 = bx*8, y0 = by*8;
     uint8_t *obase = img_out + (long long)y0*pitch + (long long)x0*3;
     const bool fast = P.out_aligned && x0 + 8 <= P.width;
-    if (clip) colour_rows<XDEC, YDEC, true, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
-    else colour_rows<XDEC, YDEC, false, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height);
+    if (clip) colour_rows<XDEC, YDEC, true, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height, wfast, wstage, lane);
+    else colour_rows<XDEC, YDEC, false, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height, wfast, wstage, lane);
     return;
   }
 
@@ -593,9 +626,15 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
     uint2 b;
     rgb_row<XDEC, cfg::CW, false>(y8, cr, a, b);             // already clamped by its luma lane
     const int x0 = ubx*8, yy = uby*8 + k;
-    if (live && yy < P.height) {
-      store_rgb_row(img_out + (long long)yy*pitch + (long long)x0*3, a, b,
-       P.out_aligned && x0 + 8 <= P.width, x0, P.width);
+    const bool wfast = cfg::STAGE_STORES && P.out_aligned && (pitch & 15) == 0
+     && __builtin_amdgcn_ballot_w64(live && x0 + 8 <= P.width) == ~0ull
+     && (((uintptr_t)img_out + (unsigned long long)__builtin_amdgcn_readfirstlane(x0)*3u) & 15u) == 0;
+    uint8_t *o = img_out + (long long)yy*pitch + (long long)x0*3;
+    if (wfast) {                       // (yy is wave-uniform then)
+      if (yy < P.height) store_rgb_row_wave(wstage, lane, o - lane*24, a, b);
+    }
+    else if (live && yy < P.height) {
+      store_rgb_row(o, a, b, P.out_aligned && x0 + 8 <= P.width, x0, P.width);
     }
   }
 }
