@@ -24,9 +24,8 @@
 //   * zig-zag position of word l = inclusive prefix sum of (run+1) over the lanes: six
 //     DPP adds (row_shr 1/2/4/8, row_bcast 15/31), no LDS;
 //   * each valid lane drops its sign-extended level at its natural position in a
-//     128-byte LDS line of the wave, and lane n then reads coefficient n back (zeroing
-//     the line for the next block) and stores it: the wave writes the block as ONE
-//     full 128-byte line.
+//     128-byte LDS line of the wave; the lines of the blocks in flight then leave 16 bytes
+//     per lane, eight whole blocks per store instruction (and are zeroed for the next ones).
 // Sixteen blocks are in flight per wave so that the vector load -> LDS -> store
 // chain of one overlaps the others (0.68 ms with 4 in flight, 0.54 ms with 16).  Blocks
 // are taken in scan order (the order the producer emits the words), so consecutive reads
@@ -50,6 +49,7 @@ __device__ const uint8_t PK_DEZZ[64] = {     // T.81 Figure A.6: zig-zag index -
   52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 typedef int16_t __attribute__((may_alias)) pk_i16_alias;
+typedef uint32_t __attribute__((may_alias)) pk_v4u __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ int pk_sext12(uint32_t w) {
   return (int)(w << 20) >> 20;       // horz_pack_yuv.fs.glsl:112, 123
@@ -71,7 +71,7 @@ static __device__ __forceinline__ int pk_wave_scan(int x) {
 }
 
 __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_params P) {
-  __shared__ uint16_t lds_line[PK_BLOCK/64][PK_INFLIGHT][64];   // one 128-byte line per block in flight
+  __shared__ __attribute__((aligned(16))) uint16_t lds_line[PK_BLOCK/64][PK_INFLIGHT][64];   // one 128-byte line per block in flight
   __shared__ uint8_t s_dezz[64];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -150,15 +150,29 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
       }
     }
     // (a wave's LDS accesses execute in order: the writes above are visible to the reads below)
+    // Write-out: the PK_INFLIGHT lines leave 16 bytes per lane — lanes 8j..8j+7 carry block j of
+    // a pass — so one store instruction moves eight whole blocks instead of one.
+    static_assert(PK_INFLIGHT % 8 == 0, "eight blocks per store pass");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int u = 0; u < PK_INFLIGHT; u++) {
-      const uint16_t c = lds_line[wv][u][lane];
-      lds_line[wv][u][lane] = 0;
-      if (dst[u]) {
-        typedef __attribute__((address_space(1))) uint16_t global_u16;     // global_store, not flat
-        __builtin_nontemporal_store(c, (global_u16 *)(uintptr_t)dst[u] + lane);
+    for (int pass = 0; pass < PK_INFLIGHT/8; pass++) {
+      const int u = pass*8 + (int)(lane >> 3), part = (int)(lane & 7u);
+      pk_v4u *line = reinterpret_cast<pk_v4u *>(&lds_line[wv][u][0]) + part;
+      const pk_v4u v = *line;
+      const pk_v4u zero = {0u, 0u, 0u, 0u};
+      *line = zero;
+      const int owner = (int)b0 + u;                        // lane that described this block
+      const uint32_t lo = (uint32_t)__shfl((int)dst_lo, owner), hi = (uint32_t)__shfl((int)dst_hi, owner);
+      const unsigned long long a = ((unsigned long long)hi << 32) | lo;
+      if (a && owner < PK_PER_WAVE) {
+        typedef __attribute__((address_space(1))) pk_v4u global_v4u;     // global_store, not flat
+        __builtin_nontemporal_store(v, (global_v4u *)(uintptr_t)a + part);
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
