@@ -334,11 +334,13 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
   HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
-  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16;
+  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16, sparse_from = 1;
   if (it0 < 0) {
     const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group" (tuning knob)
-    it0 = 3; it1 = 2; group = 6;
+    it0 = 3; it1 = 3; group = 6;
     if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
+    e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (tuning knob)
+    if (e) sparse_from = atoi(e);
     e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching (tuning knob)
     if (e) flush_lanes = atoi(e);
     if (flush_lanes < 1) flush_lanes = 1;
@@ -347,7 +349,9 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   const int GROUP = group;
   for (;;) {
     for (int k = 0; k < GROUP && round < HJ_MAX_ROUNDS; k++, round++) {
-      if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, st)) return jga_fail("huff: launch failed");
+      if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, round >= sparse_from, st)) {
+        return jga_fail("huff: launch failed");
+      }
     }
     HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
     HOK(hipStreamSynchronize(st));

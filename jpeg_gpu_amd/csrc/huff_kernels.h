@@ -27,7 +27,8 @@ typedef struct hj_args {
 #ifdef __cplusplus
 extern "C" {
 #endif
-int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, void *stream);
+/* sparse != 0: the one-wave-per-group variant for rounds in which few lanes still move */
+int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, void *stream);
 int hj_launch_write(const hj_args *A, int max_nsub, void *stream);
 #ifdef __cplusplus

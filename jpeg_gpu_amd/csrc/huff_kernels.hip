@@ -235,6 +235,152 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
   if (__syncthreads_or(on && lds_ran[t]) && t == 0) atomicOr(&A.ran[round], 1u);
 }
 
+// The same round for the LATER launches, when only a minority of the lanes still moves.
+// A launch then costs (groups with a moving lane) x (latency of one run) / (workgroups
+// in flight), whatever the groups hold — so this variant trades lanes for residency: ONE
+// wave per group of 256 subsequences, the scan rows of the (at most 64) lanes it runs at a
+// time staged on demand into a 9 KB pool instead of all 256 rows up front.  26 KB of LDS
+// instead of 54: six groups in flight per CU instead of three.  Same indexing, same
+// hand-over protocol and same results as hj_sync_round.
+#define HJ_POOL 64
+__global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round, int max_iters) {
+  __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
+  __shared__ uint32_t pool_mem[1 + HJ_POOL*HJ_SUB_STRIDE + 8];
+  uint32_t *pool = pool_mem + 1;
+  __shared__ uint64_t lds_S[HJ_BLOCK + 1];
+  __shared__ hj_run16 lds_R[HJ_BLOCK];
+  __shared__ uint32_t lds_stop[HJ_BLOCK], lds_start[HJ_BLOCK];
+  __shared__ uint8_t lds_dirty[HJ_BLOCK], lds_ran[HJ_BLOCK];
+  __shared__ uint16_t lds_act[HJ_BLOCK];
+  __shared__ uint32_t lds_sidx_last;
+  __shared__ hj_image s_im;
+  const hj_image im = A.images[blockIdx.y];
+  const uint32_t lane = threadIdx.x;
+  {
+    // cheap exit before anything else: did any lane's start state move since its last run?
+    bool need = false;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t li = blockIdx.x*HJ_BLOCK + (uint32_t)q*64u + lane;
+      if (li < im.nsub) {
+        const uint32_t gg = im.sub0 + li;
+        need = need || A.S[gg + im.seg0 + A.sub_seg[gg]] != A.last_in[gg];
+      }
+    }
+    if (!__syncthreads_or(need)) return;
+  }
+  // lane l describes subsequences l, l+64, l+128, l+192 of the group
+  uint32_t g[4], sidx[4];
+  bool on[4], any = false;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t t = (uint32_t)q*64u + lane, li = blockIdx.x*HJ_BLOCK + t;
+    on[q] = li < im.nsub;
+    g[q] = 0; sidx[q] = 0;
+    uint64_t st = 0;
+    uint32_t start = 0, stop = 0;
+    bool dirty = false;
+    if (on[q]) {
+      g[q] = im.sub0 + li;
+      const uint32_t si = A.sub_seg[g[q]];
+      const hj_segment sg = A.segs[im.seg0 + si];
+      const uint32_t i = li - sg.sub0;
+      sidx[q] = g[q] + im.seg0 + si;
+      st = A.S[sidx[q]];
+      dirty = st != A.last_in[g[q]];
+      start = sg.start + i*HJ_SUB_BYTES;
+      stop = start + HJ_SUB_BYTES;
+      if (stop > sg.end) stop = sg.end;
+      if (i + 1 < sg.nsub) stop |= 0x80000000u;
+    }
+    lds_S[t] = st;
+    lds_dirty[t] = dirty;
+    lds_ran[t] = 0;
+    lds_start[t] = start;
+    lds_stop[t] = stop;
+    if (t == HJ_BLOCK - 1) lds_sidx_last = sidx[q];
+    any = any || dirty;
+  }
+  if (!__syncthreads_or(any)) return;
+  hj_stage_image(&s_im, A.images + blockIdx.y);
+  {
+    const uint4 *tsrc = reinterpret_cast<const uint4 *>(A.tables + blockIdx.y);
+    uint4 *tdst = reinterpret_cast<uint4 *>(&lds_tabs);
+    for (int k = (int)lane; k < (int)(sizeof(hj_tables)/16); k += 64) tdst[k] = tsrc[k];
+  }
+  __syncthreads();
+  const uint8_t *scan = A.scan + im.scan_off;
+  const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;
+  for (int it = 0; it < max_iters; it++) {
+    // the lanes that moved, in order
+    uint32_t total = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t t = (uint32_t)q*64u + lane;
+      const bool need = lds_dirty[t] != 0;
+      const unsigned long long m = __ballot(need);
+      if (need) {
+        lds_act[total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
+        lds_dirty[t] = 0;
+      }
+      total += (uint32_t)__popcll(m);
+    }
+    if (total == 0) break;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < total; c0 += HJ_POOL) {
+      const uint32_t nact = total - c0 < HJ_POOL ? total - c0 : HJ_POOL;
+      // their scan rows -> the pool (row r = the r-th lane of this batch)
+      for (uint32_t c = lane; c < nact*HJ_SUB_DWORDS; c += 64) {
+        const uint32_t r = c/HJ_SUB_DWORDS, d = c - r*HJ_SUB_DWORDS;
+        uint32_t a = (lds_start[lds_act[c0 + r]] & ~3u) + 4*d;
+        if (a + 4 > padded) a = padded - 4;
+        pool[r*HJ_SUB_STRIDE + d] = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(scan + a));
+      }
+      __syncthreads();
+      if (lane < nact) {
+        const uint32_t sub = lds_act[c0 + lane];
+        const uint64_t start = lds_S[sub];
+        const uint32_t sb = lds_stop[sub];
+        hj_lds_src src;
+        src.base = pool + lane*HJ_SUB_STRIDE;
+        src.bit0 = (lds_start[sub] & ~3u) << 3;
+        const hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)(sb & 0x7fffffffu)*8);
+        hj_run16 r16;
+        r16.nblocks = (uint16_t)r.nblocks;
+        r16.dcsum[0] = r.dcsum[0]; r16.dcsum[1] = r.dcsum[1]; r16.dcsum[2] = r.dcsum[2];
+        lds_R[sub] = r16;
+        lds_ran[sub] = 1;
+        if (sb & 0x80000000u) {
+          if (sub + 1 < HJ_BLOCK) {
+            if (lds_S[sub + 1] != r.end_state) { lds_S[sub + 1] = r.end_state; lds_dirty[sub + 1] = 1; }
+          }
+          else A.S[lds_sidx_last + 1] = r.end_state;       // first subsequence of the next group
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // publish (as hj_sync_round)
+  bool ran_any = false;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t t = (uint32_t)q*64u + lane;
+    if (!on[q]) continue;
+    const uint64_t st = lds_S[t];
+    if (t > 0 && st != A.S[sidx[q]]) A.S[sidx[q]] = st;
+    if (lds_ran[t]) {
+      const hj_run16 r16 = lds_R[t];
+      hj_run r;
+      r.end_state = 0; r.nblocks = r16.nblocks; r.error = 0;
+      r.dcsum[0] = r16.dcsum[0]; r.dcsum[1] = r16.dcsum[1]; r.dcsum[2] = r16.dcsum[2];
+      A.R[g[q]] = r;
+      A.last_in[g[q]] = lds_dirty[t] ? ~0ull : st;
+      ran_any = true;
+    }
+  }
+  if (__syncthreads_or(ran_any) && lane == 0) atomicOr(&A.ran[round], 1u);
+}
+
 // Exclusive prefix sums over the lanes of one segment.  Sequential over chunks of
 // 256 lanes, Hillis-Steele inside a chunk.
 __global__ __launch_bounds__(HJ_BLOCK) void hj_scan(const hj_args A) {
@@ -421,9 +567,11 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   if (err) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 
-extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, void *stream) {
-  dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages), block(HJ_BLOCK);
-  hipLaunchKernelGGL(hj_sync_round, grid, block, 0, (hipStream_t)stream, *A, round, max_iters);
+extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,
+ void *stream) {
+  dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
+  if (sparse) hipLaunchKernelGGL(hj_sync_sparse, grid, dim3(64), 0, (hipStream_t)stream, *A, round, max_iters);
+  else hipLaunchKernelGGL(hj_sync_round, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_scan(const hj_args *A, int total_segs, void *stream) {
