@@ -334,11 +334,13 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
   HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
-  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16, sparse_from = 1;
+  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16, sparse_from = 1, write_gmem = 1;
   if (it0 < 0) {
     const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group" (tuning knob)
     it0 = 3; it1 = 3; group = 6;
     if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
+    e = getenv("JGA_HUFF_WRITE_GMEM");               // write pass reads the scan from global memory
+    if (e) write_gmem = atoi(e) != 0;
     e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (tuning knob)
     if (e) sparse_from = atoi(e);
     e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching (tuning knob)
@@ -362,7 +364,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;
   if (hj_launch_scan(&A, (int)b->total_seg, st)) return jga_fail("huff: launch failed");
   HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
-  if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+  if (hj_launch_write(&A, (int)b->max_nsub, write_gmem, st)) return jga_fail("huff: launch failed");
   HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
   HOK(hipStreamSynchronize(st));
   for (int i = 0; i < b->nimages; i++) {

@@ -30,7 +30,8 @@ extern "C" {
 /* sparse != 0: the one-wave-per-group variant for rounds in which few lanes still move */
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, void *stream);
-int hj_launch_write(const hj_args *A, int max_nsub, void *stream);
+/* gmem != 0: the write pass reads the scan from global memory instead of an LDS copy */
+int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,46 @@ struct hj_lds_src {
   };
 };
 
+// Bit source straight from the clean scan in global memory, for the write pass: the lane
+// keeps the two dwords under its position in registers and a third one in flight, and only
+// issues a (lane-divergent, L1-resident) dword load when its position crosses into the next
+// dword — about every fifth symbol.  No LDS copy of the scan, so the write pass's LDS budget
+// goes to the block buffers alone and more workgroups fit a CU.
+struct hj_gmem_src {
+  const uint8_t *row;                // address of the dword holding the subsequence's first byte
+  uint32_t bit0;                     // clean-scan bit position of that dword
+  uint32_t ndw;                      // dwords readable from `row` on
+  typedef void has_reader;
+  struct reader {
+    const uint32_t *base;
+    uint32_t bit0, ndw;
+    int32_t r1, stop1, d;
+    uint32_t w0, w1, w2;
+    __device__ __forceinline__ uint32_t fetch(int32_t i) const {
+      const int32_t k = i < 0 ? 0 : ((uint32_t)i < ndw ? i : (int32_t)ndw - 1);
+      return __builtin_bswap32(base[k]);
+    }
+    __device__ __forceinline__ void init(const hj_gmem_src &src, uint64_t pos, uint64_t stop_bit) {
+      base = reinterpret_cast<const uint32_t *>(src.row); bit0 = src.bit0; ndw = src.ndw;
+      r1 = (int32_t)((uint32_t)pos - bit0) - 1;
+      stop1 = (int32_t)((uint32_t)stop_bit - bit0) - 1;
+      d = r1 >> 5;
+      w0 = fetch(d); w1 = fetch(d + 1); w2 = fetch(d + 2);
+    }
+    __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
+    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w0, w1, ~(uint32_t)r1); }
+    __device__ __forceinline__ void skip(int n) {
+      r1 += n;
+      const int32_t nd = r1 >> 5;
+      if (nd != d) {                 // a symbol is at most 31 bits: one dword further at most
+        d = nd; w0 = w1; w1 = w2;
+        w2 = fetch(d + 2);
+      }
+    }
+    __device__ __forceinline__ uint64_t tell() const { return (uint64_t)((uint32_t)(r1 + 1) + bit0); }
+  };
+};
+
 struct hj_lane_ctx {                 // what a lane knows about its subsequence
   uint32_t g, si, i;                 // batch-global subsequence, image-local segment, index in segment
   uint32_t seg_start, seg_end, seg_nsub, seg_mcu0, seg_nmcu;
@@ -80,6 +120,7 @@ static __device__ __forceinline__ void hj_stage_image(hj_image *dst, const hj_im
 // Common prologue: lane context, tables and the group's subsequences staged in LDS.
 // Returns false for lanes beyond the image's last subsequence (they still took part
 // in staging).  lds_start[t] receives the clean-scan byte offset of subsequence t.
+template <bool STAGE_ROWS = true>
 static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_image &im,
  hj_tables *lds_tabs, uint32_t *lds_win, uint32_t *lds_start, hj_lane_ctx &L) {
   const uint32_t li = blockIdx.x*HJ_BLOCK + threadIdx.x;
@@ -110,7 +151,7 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
   const uint8_t *scan = A.scan + im.scan_off;
   const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;      // bytes present in the batch buffer
   const uint32_t nsubs = im.nsub - blockIdx.x*HJ_BLOCK < HJ_BLOCK ? im.nsub - blockIdx.x*HJ_BLOCK : HJ_BLOCK;
-  for (uint32_t c = threadIdx.x; c < nsubs*HJ_SUB_DWORDS; c += HJ_BLOCK) {
+  for (uint32_t c = threadIdx.x; STAGE_ROWS && c < nsubs*HJ_SUB_DWORDS; c += HJ_BLOCK) {
     const uint32_t sub = c/HJ_SUB_DWORDS, d = c - sub*HJ_SUB_DWORDS;
     uint32_t a = (lds_start[sub] & ~3u) + 4*d;
     if (a + 4 > padded) a = padded - 4;
@@ -522,10 +563,15 @@ struct hj_block_out {
   __device__ __forceinline__ void flush_partial(int slot, bool) { scatter(slot); }
 };
 
+// GMEM = true (default): the scan is read from global memory (hj_gmem_src; 44 KB of LDS, three
+// workgroups per CU, 1.17 ms per 48 x 4K); GMEM = false: rows staged in LDS like the sync
+// rounds' (80 KB, two per CU, 1.35 ms; JGA_HUFF_WRITE_GMEM=0).  The dense sync round is the
+// other way round (1.19 ms from LDS, 1.5 ms from global memory): it re-reads each row ~2.4x.
+template <bool GMEM>
 __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
-  __shared__ uint32_t lds_win_mem[1 + HJ_WIN_DWORDS];      // [0]: the dword "before" row 0 (hj_lds_src::reader)
-  uint32_t *lds_win = lds_win_mem + 1;
+  __shared__ uint32_t lds_win_mem[GMEM ? 1 : 1 + HJ_WIN_DWORDS];   // [0]: the dword "before" row 0 (hj_lds_src::reader)
+  uint32_t *lds_win = lds_win_mem + (GMEM ? 0 : 1);
   __shared__ uint32_t lds_blk[HJ_BLOCK*HJ_BLK_STRIDE];
   __shared__ hj_image s_im;
   __shared__ uint8_t s_dezz[64];
@@ -538,8 +584,15 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   // 1 KB of the block buffers, which are zeroed afterwards
   uint32_t *lds_start = lds_blk;
   hj_lane_ctx L;
-  const bool on = hj_prologue(A, im0, &lds_tabs, lds_win, lds_start, L);   // syncs: s_im ready
+  const bool on = hj_prologue<!GMEM>(A, im0, &lds_tabs, lds_win, lds_start, L);   // syncs: s_im ready
   hj_lds_src src = hj_source(lds_win, lds_start, threadIdx.x);
+  hj_gmem_src gsrc;
+  {
+    const uint32_t a = lds_start[threadIdx.x] & ~3u;
+    gsrc.row = A.scan + im0.scan_off + a;
+    gsrc.bit0 = a << 3;
+    gsrc.ndw = (((im0.scan_len + 16 + 15) & ~15u) - a) >> 2;
+  }
   __syncthreads();
   uint32_t *blk = lds_blk + threadIdx.x*HJ_BLK_STRIDE;
 #pragma unroll
@@ -562,8 +615,10 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
   out.rank_lane = s_rank + (threadIdx.x & ~63u);
   out.init(L.seg_mcu0 + b0/(uint32_t)im.nslots);
   out.flush_lanes = A.flush_lanes;
-  const int err = hj_write_decode(src, im, &lds_tabs, s_dezz, start, stop, live ? total - b0 : 0u,
-   live ? A.D[3*L.g + 0] : 0, live ? A.D[3*L.g + 1] : 0, live ? A.D[3*L.g + 2] : 0, out);
+  const uint32_t nblk = live ? total - b0 : 0u;
+  const int p0 = live ? A.D[3*L.g + 0] : 0, p1 = live ? A.D[3*L.g + 1] : 0, p2 = live ? A.D[3*L.g + 2] : 0;
+  const int err = GMEM ? hj_write_decode(gsrc, im, &lds_tabs, s_dezz, start, stop, nblk, p0, p1, p2, out)
+   : hj_write_decode(src, im, &lds_tabs, s_dezz, start, stop, nblk, p0, p1, p2, out);
   if (err) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 
@@ -578,8 +633,9 @@ extern "C" int hj_launch_scan(const hj_args *A, int total_segs, void *stream) {
   hipLaunchKernelGGL(hj_scan, dim3(total_segs), dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A);
   return (int)hipGetLastError();
 }
-extern "C" int hj_launch_write(const hj_args *A, int max_nsub, void *stream) {
+extern "C" int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream) {
   dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages), block(HJ_BLOCK);
-  hipLaunchKernelGGL(hj_write, grid, block, 0, (hipStream_t)stream, *A);
+  if (gmem) hipLaunchKernelGGL(hj_write<true>, grid, block, 0, (hipStream_t)stream, *A);
+  else hipLaunchKernelGGL(hj_write<false>, grid, block, 0, (hipStream_t)stream, *A);
   return (int)hipGetLastError();
 }
