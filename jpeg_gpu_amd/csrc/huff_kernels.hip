@@ -279,15 +279,13 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
 // The same round for the LATER launches, when only a minority of the lanes still moves.
 // A launch then costs (groups with a moving lane) x (latency of one run) / (workgroups
 // in flight), whatever the groups hold — so this variant trades lanes for residency: ONE
-// wave per group of 256 subsequences, the scan rows of the (at most 64) lanes it runs at a
-// time staged on demand into a 9 KB pool instead of all 256 rows up front.  26 KB of LDS
-// instead of 54: six groups in flight per CU instead of three.  Same indexing, same
-// hand-over protocol and same results as hj_sync_round.
+// wave per group of 256 subsequences, running at most 64 of them at a time, each reading its
+// scan row from global memory (hj_gmem_src: every row is read once here, nothing to reuse).
+// 18 KB of LDS instead of 54: nine groups in flight per CU instead of three.  Same
+// indexing, same hand-over protocol and same results as hj_sync_round.
 #define HJ_POOL 64
 __global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round, int max_iters) {
   __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
-  __shared__ uint32_t pool_mem[1 + HJ_POOL*HJ_SUB_STRIDE + 8];
-  uint32_t *pool = pool_mem + 1;
   __shared__ uint64_t lds_S[HJ_BLOCK + 1];
   __shared__ hj_run16 lds_R[HJ_BLOCK];
   __shared__ uint32_t lds_stop[HJ_BLOCK], lds_start[HJ_BLOCK];
@@ -370,21 +368,17 @@ __global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round,
     __syncthreads();
     for (uint32_t c0 = 0; c0 < total; c0 += HJ_POOL) {
       const uint32_t nact = total - c0 < HJ_POOL ? total - c0 : HJ_POOL;
-      // their scan rows -> the pool (row r = the r-th lane of this batch)
-      for (uint32_t c = lane; c < nact*HJ_SUB_DWORDS; c += 64) {
-        const uint32_t r = c/HJ_SUB_DWORDS, d = c - r*HJ_SUB_DWORDS;
-        uint32_t a = (lds_start[lds_act[c0 + r]] & ~3u) + 4*d;
-        if (a + 4 > padded) a = padded - 4;
-        pool[r*HJ_SUB_STRIDE + d] = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(scan + a));
-      }
-      __syncthreads();
       if (lane < nact) {
         const uint32_t sub = lds_act[c0 + lane];
         const uint64_t start = lds_S[sub];
         const uint32_t sb = lds_stop[sub];
-        hj_lds_src src;
-        src.base = pool + lane*HJ_SUB_STRIDE;
-        src.bit0 = (lds_start[sub] & ~3u) << 3;
+        hj_gmem_src src;
+        {
+          const uint32_t a = lds_start[sub] & ~3u;
+          src.row = scan + a;
+          src.bit0 = a << 3;
+          src.ndw = (padded - a) >> 2;
+        }
         const hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)(sb & 0x7fffffffu)*8);
         hj_run16 r16;
         r16.nblocks = (uint16_t)r.nblocks;
