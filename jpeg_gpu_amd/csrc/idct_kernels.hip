@@ -298,8 +298,11 @@ DEV void store_rgb_row(uint8_t *o, const uint4 a, const uint2 b2, bool fast,
 // The same row for a whole wave whose 64 lanes own 64 horizontally adjacent blocks, all
 // inside the image: the wave's 1536 bytes are contiguous, so they go through a per-wave LDS
 // line and leave as 16 bytes per lane, back to back (1 KB + 512 B bursts) instead of
-// 16 + 8 bytes at a 24-byte stride.  `row0` = address of lane 0's first pixel (16-byte aligned).
-DEV void store_rgb_row_wave(uint32_t *wstage, int lane, uint8_t *row0, const uint4 a, const uint2 b2) {
+// 16 + 8 bytes at a 24-byte stride.  `row0` = address of lane 0's first pixel (16-byte aligned);
+// `nchunks` = 16-byte pieces to store: 96 for a full wave, 1.5 per block when only the first
+// (even number of) lanes hold blocks inside the image — the last tile of a row.
+DEV void store_rgb_row_wave(uint32_t *wstage, int lane, uint8_t *row0, const uint4 a, const uint2 b2,
+ int nchunks) {
   uint2 *w2 = reinterpret_cast<uint2 *>(wstage) + lane*3;
   w2[0] = make_uint2(a.x, a.y);
   w2[1] = make_uint2(a.z, a.w);
@@ -308,8 +311,8 @@ DEV void store_rgb_row_wave(uint32_t *wstage, int lane, uint8_t *row0, const uin
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const uint4 *r4 = reinterpret_cast<const uint4 *>(wstage);
-  st_nt(reinterpret_cast<uint4 *>(row0) + lane, r4[lane]);
-  if (lane < 32) st_nt(reinterpret_cast<uint4 *>(row0) + 64 + lane, r4[64 + lane]);
+  if (lane < nchunks) st_nt(reinterpret_cast<uint4 *>(row0) + lane, r4[lane]);
+  if (64 + lane < nchunks) st_nt(reinterpret_cast<uint4 *>(row0) + 64 + lane, r4[64 + lane]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
@@ -450,8 +453,9 @@ struct rgb_cfg {
 // Upsample + convert + store pixel rows [0, NROWS) of one luma block.
 template <int XDEC, int YDEC, bool CLAMP, int NROWS>
 DEV void colour_rows(const float (&t)[64], const float *ub, const float *vb, uint8_t *obase,
- long long pitch, bool fast, int x0, int y0, int width, int height, bool wfast, uint32_t *wstage,
+ long long pitch, bool fast, int x0, int y0, int width, int height, int wchunks, uint32_t *wstage,
  int lane) {
+  const bool wfast = wchunks != 0;
   typedef rgb_cfg<XDEC, YDEC> cfg;
   chroma_row<cfg::CW> cr;
 #pragma unroll
@@ -469,7 +473,7 @@ DEV void colour_rows(const float (&t)[64], const float *ub, const float *vb, uin
     uint2 b;
     rgb_row<XDEC, cfg::CW, CLAMP>(t + k*8, cr, a, b);
     if (wfast) {                       // wave-uniform (as is y0 when wfast)
-      if (y0 + k < height) store_rgb_row_wave(wstage, lane, obase - lane*24 + k*pitch, a, b);
+      if (y0 + k < height) store_rgb_row_wave(wstage, lane, obase - lane*24 + k*pitch, a, b, wchunks);
     }
     else if (y0 + k < height) store_rgb_row(obase + k*pitch, a, b, fast, x0, width);
   }
@@ -582,18 +586,22 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
 
   if (is_luma) {
     const int x0 = bx*8, y0 = by*8;
-    // all 64 lanes of the wave inside the image and the run 16-byte aligned: staged stores
+    // the wave's first n lanes (n even) inside the image and the run 16-byte aligned: staged
+    // stores, in which the other lanes only lend a hand with the copy
+    const unsigned long long inside = __builtin_amdgcn_ballot_w64(valid && x0 + 8 <= P.width);
+    const int nin = (int)__builtin_popcountll(inside);
     const bool wfast = cfg::STAGE_STORES && P.out_aligned && (pitch & 15) == 0
-     && __builtin_amdgcn_ballot_w64(valid && x0 + 8 <= P.width) == ~0ull
+     && nin >= 2 && (nin & 1) == 0 && inside == (nin == 64 ? ~0ull : (1ull << nin) - 1ull)
      && (((uintptr_t)img_out + (unsigned long long)__builtin_amdgcn_readfirstlane(x0)*3u) & 15u) == 0;
-    if (!valid) return;
+    const int wchunks = wfast ? nin*3/2 : 0;
+    if (!valid && !wfast) return;
     // chroma patch of this luma block: rows suby*CH.., cols subx*CW..
     const float *ub = chroma + ((suby*cfg::CH)*cfg::TILE + cb)*8 + subx*cfg::CW;
     const float *vb = ub + 8*cfg::TILE*8;
     uint8_t *obase = img_out + (long long)y0*pitch + (long long)x0*3;
     const bool fast = P.out_aligned && x0 + 8 <= P.width;
-    if (clip) colour_rows<XDEC, YDEC, true, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height, wfast, wstage, lane);
-    else colour_rows<XDEC, YDEC, false, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height, wfast, wstage, lane);
+    if (clip) colour_rows<XDEC, YDEC, true, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height, wchunks, wstage, lane);
+    else colour_rows<XDEC, YDEC, false, cfg::OWN>(t, ub, vb, obase, pitch, fast, x0, y0, P.width, P.height, wchunks, wstage, lane);
     return;
   }
 
@@ -626,12 +634,14 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
     uint2 b;
     rgb_row<XDEC, cfg::CW, false>(y8, cr, a, b);             // already clamped by its luma lane
     const int x0 = ubx*8, yy = uby*8 + k;
+    const unsigned long long inside = __builtin_amdgcn_ballot_w64(live && x0 + 8 <= P.width);
+    const int nin = (int)__builtin_popcountll(inside);
     const bool wfast = cfg::STAGE_STORES && P.out_aligned && (pitch & 15) == 0
-     && __builtin_amdgcn_ballot_w64(live && x0 + 8 <= P.width) == ~0ull
+     && nin >= 2 && (nin & 1) == 0 && inside == (nin == 64 ? ~0ull : (1ull << nin) - 1ull)
      && (((uintptr_t)img_out + (unsigned long long)__builtin_amdgcn_readfirstlane(x0)*3u) & 15u) == 0;
     uint8_t *o = img_out + (long long)yy*pitch + (long long)x0*3;
     if (wfast) {                       // (yy is wave-uniform then)
-      if (yy < P.height) store_rgb_row_wave(wstage, lane, o - lane*24, a, b);
+      if (yy < P.height) store_rgb_row_wave(wstage, lane, o - lane*24, a, b, nin*3/2);
     }
     else if (live && yy < P.height) {
       store_rgb_row(o, a, b, P.out_aligned && x0 + 8 <= P.width, x0, P.width);
