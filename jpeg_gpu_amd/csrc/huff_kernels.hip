@@ -416,11 +416,12 @@ __global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round,
   if (__syncthreads_or(ran_any) && lane == 0) atomicOr(&A.ran[round], 1u);
 }
 
+#define HJ_SCAN_BLOCK 1024          /* lanes scanned per step (few segments: make them wide) */
 // Exclusive prefix sums over the lanes of one segment.  Sequential over chunks of
 // 256 lanes, Hillis-Steele inside a chunk.
-__global__ __launch_bounds__(HJ_BLOCK) void hj_scan(const hj_args A) {
-  __shared__ uint32_t sb[HJ_BLOCK];
-  __shared__ int sd[3][HJ_BLOCK];
+__global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
+  __shared__ uint32_t sb[HJ_SCAN_BLOCK];
+  __shared__ int sd[3][HJ_SCAN_BLOCK];
   // blockIdx.x = batch-global segment; find its image (few images: linear search)
   const uint32_t gs = blockIdx.x;
   int img = 0;
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_scan(const hj_args A) {
   uint32_t base_b = 0;
   int base_d[3] = {0, 0, 0};
   bool bad = false;
-  for (uint32_t c0 = 0; c0 < sg.nsub; c0 += HJ_BLOCK) {
+  for (uint32_t c0 = 0; c0 < sg.nsub; c0 += HJ_SCAN_BLOCK) {
     const uint32_t i = c0 + threadIdx.x;
     const bool on = i < sg.nsub;
     const uint32_t g = im.sub0 + sg.sub0 + i;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_scan(const hj_args A) {
     sb[threadIdx.x] = r.nblocks;
     sd[0][threadIdx.x] = r.dcsum[0]; sd[1][threadIdx.x] = r.dcsum[1]; sd[2][threadIdx.x] = r.dcsum[2];
     __syncthreads();
-    for (int d = 1; d < HJ_BLOCK; d <<= 1) {
+    for (int d = 1; d < HJ_SCAN_BLOCK; d <<= 1) {
       uint32_t vb = 0;
       int v0 = 0, v1 = 0, v2 = 0;
       if ((int)threadIdx.x >= d) {
@@ -464,8 +465,8 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_scan(const hj_args A) {
       const uint64_t st = A.S[g + im.seg0 + si];
       if (excl < total && hj_slot(st) != (int)(excl % (uint32_t)im.nslots)) bad = true;
     }
-    base_b += sb[HJ_BLOCK - 1];
-    base_d[0] += sd[0][HJ_BLOCK - 1]; base_d[1] += sd[1][HJ_BLOCK - 1]; base_d[2] += sd[2][HJ_BLOCK - 1];
+    base_b += sb[HJ_SCAN_BLOCK - 1];
+    base_d[0] += sd[0][HJ_SCAN_BLOCK - 1]; base_d[1] += sd[1][HJ_SCAN_BLOCK - 1]; base_d[2] += sd[2][HJ_SCAN_BLOCK - 1];
     __syncthreads();
   }
   if (base_b < total) bad = true;                            // data ran out before the last MCU
@@ -624,7 +625,7 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_scan(const hj_args *A, int total_segs, void *stream) {
-  hipLaunchKernelGGL(hj_scan, dim3(total_segs), dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A);
+  hipLaunchKernelGGL(hj_scan, dim3(total_segs), dim3(HJ_SCAN_BLOCK), 0, (hipStream_t)stream, *A);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream) {
