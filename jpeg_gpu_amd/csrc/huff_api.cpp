@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "huff_kernels.h"
@@ -155,6 +156,7 @@ struct phase_barrier {
 JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *jpegs,
  const int *sizes, int n, jga_geom *geom, void *stream) {
   if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
+  const auto t_p0 = std::chrono::steady_clock::now();
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
   std::atomic<int> next_a(0), next_b(0), next_c(0), failed(0), irregular(0);
@@ -283,7 +285,14 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   b->nimages = n;
   // the scan region is sized from the raw lengths; the bytes between an image's clean
   // stream (+16 pad) and the next image's start are never read
+  const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  const auto t_h = std::chrono::steady_clock::now();
   HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->blob_size, hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (trace) {
+    fprintf(stderr, "  prepare: host %.2f ms, hipMemcpyAsync call %.2f ms (%zu MB)\n",
+     std::chrono::duration<double, std::milli>(t_h - t_p0).count(),
+     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h).count(), b->blob_size >> 20);
+  }
   if (geom) *geom = b->geom;
   return EXIT_SUCCESS;
 }

@@ -19,6 +19,8 @@
 // rest.  While one lane waits for its GPU work the others prepare their next group.
 #include <hip/hip_runtime_api.h>
 #include <atomic>
+#include <chrono>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
@@ -262,6 +264,8 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     l.hb = jga_huff_create(l.hb_images, l.hb_scan);
     if (!l.hb) { l.hb_images = 0; l.hb_scan = 0; return EXIT_FAILURE; }
   }
+  const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  const auto t_a = std::chrono::steady_clock::now();
   jga_huff_set_threads(l.hb, threads);
   // A lone image whose Huffman tables do not fit the device lookup format takes the host
   // entropy stage (csrc/entropy.c) instead; everything after it is the same.
@@ -286,6 +290,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
    || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*m, true))) {
     return EXIT_FAILURE;
   }
+  const auto t_b = std::chrono::steady_clock::now();
   if (host_entropy) {
     unsigned short q[192];
     memset(q, 0, sizeof(q));
@@ -300,6 +305,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     if (!HOK(hipMemcpyAsync(l.d_q, jga_huff_qtabs(l.hb), 384*(size_t)m, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
     if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
   }
+  const auto t_c = std::chrono::steady_clock::now();
   bool scattered = false;
   for (int i = 0; i < m; i++) scattered = scattered || jobv[i]->dev_out != nullptr;
   if (!scattered) {
@@ -325,6 +331,13 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     }
   }
   if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;
+  if (trace) {
+    const auto t_d = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "lane group of %d: prepare %.2f ms, entropy decode %.2f ms, idct+out+sync %.2f ms\n",
+     m, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d));
+  }
   const long long up = host_entropy ? g.coef_shorts*2 : jga_huff_upload_bytes(l.hb)/m;
   for (int i = 0; i < m; i++) {
     if (copy_back && jobv[i]->host_out) memcpy(jobv[i]->host_out, l.h_out + ostride*i, (size_t)out_bytes);
