@@ -315,8 +315,8 @@ typedef struct jga_pipeline_config {
   int transport;               /* what crosses PCIe: 0 = dense QUANT planes,
                                 * 1 = PACK words + block index, expanded by jga_unpack_batch,
                                 * 2 = the entropy-coded bytes: no host Huffman, jga_huff_* on
-                                *     the GPU (depth = lanes in flight, default 3) */
-  int batch;                   /* transport 2: images per GPU entropy batch (0 = 16); a group
+                                *     the GPU (depth = lanes in flight, default 6) */
+  int batch;                   /* transport 2: images per GPU entropy batch (0 = 24); a group
                                 * must share one geometry, otherwise it is decoded one by one */
 } jga_pipeline_config;
 

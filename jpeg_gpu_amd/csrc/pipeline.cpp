@@ -413,7 +413,7 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     return nullptr;
   }
   if (pl->cfg.transport == 2) {
-    pl->lanes.resize(pl->cfg.depth > 0 ? pl->cfg.depth : 3);
+    pl->lanes.resize(pl->cfg.depth > 0 ? pl->cfg.depth : 6);
     for (auto &l : pl->lanes) {
       if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")) {
         jga_pipeline_destroy(pl);
@@ -438,7 +438,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
   int failed = 0;
   for (int i = 0; i < n; i++) jobs[i].status = EXIT_FAILURE;
   if (pl->cfg.transport == 2) {
-    const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 16;
+    const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 24;
     const int nl = (int)pl->lanes.size();
     int per = pl->cfg.nthreads/nl;
     if (per < 1) per = 1;
