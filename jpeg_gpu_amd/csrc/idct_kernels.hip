@@ -431,8 +431,8 @@ struct rgb_cfg {
   // lanes convert their first OWN rows from registers and hand the last SHARE rows to the
   // chroma lanes through LDS ([row][luma block][8] floats).
   static constexpr int NLB = LW*LH*TILE;                   // luma blocks per tile
-  // (measured, tools/ab_variants.sh: 4:2:0 best at 1 shared row, -1.4 %; 4:4:4 at 3, -4 %: the
-  // hardware back-fills most of the idle slots by itself)
+  // (measured, tools/ab_variants.sh: 4:2:0 best at 1 shared row — 0.430 ms against 0.445 with
+  // none and 0.433 with two; 4:4:4 at 3, -4 %: the hardware back-fills most idle slots itself)
 #ifndef JGA_SHARE_1
 #define JGA_SHARE_1 3                /* 4:4:4: 1 luma block per MCU */
 #define JGA_SHARE_2 4                /* 4:2:2, 4:4:0 */
