@@ -152,3 +152,23 @@ def test_plugin_entropy_stage_choice(gpu, orc, jpg, entropy):
     _, rgb = orc.decode_rgb(data)
     out = run("-o", "rgb", "--frames", "4", "--check", path, env=env).stdout.strip().split("\n")
     assert out[-1].endswith("%08x" % zlib.adler32(rgb.tobytes()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"JGA_STAGED": "0"}, {"JGA_HUFF_WRITE_GMEM": "0"},
+                                 {"JGA_HUFF_SPARSE_FROM": "99"}, {"JGA_HUFF_ITERS": "1,1,3"},
+                                 {"JGA_HUFF_FLUSH": "1"}, {"JGA_PLUGIN_REGISTER": "0"}])
+def test_alternate_code_paths_give_the_same_pixels(gpu, orc, jpg, env):
+    """Every tuning knob selects a different route to the same result: per-lane loads in the
+    YUV kernel, the write pass with LDS-staged rows, dense rounds only, one in-group iteration
+    per launch, unbatched block write-out, staged D2H."""
+    import oracle
+    path, data = jpg(777, 431, "420", quality=88, restart_interval=0)
+    _, rgb = orc.decode_rgb(data)
+    want = "%08x" % zlib.adler32(rgb.tobytes())
+    for stage in ("rgb", "yuv"):
+        out = run("-o", stage, "--frames", "2", "--check", path, env=env).stdout.strip().split("\n")
+        assert out[-1].endswith(want), (env, stage)
+    _, planes = orc.decode(data, oracle.YUV)
+    for a, b in zip(numbers(run("--dump", "-o", "yuv", path, env=env).stdout), planes):
+        assert np.array_equal(a, b)
