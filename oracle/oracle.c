@@ -7,12 +7,13 @@
  *
  * Every function restates one piece of negge/jpeg_gpu's CPU path and cites the
  * reference file:line it follows (paths relative to the reference root).  The
- * restatement is PINNED: tests/test_oracle_vs_ref.py compares it bit-for-bit
- * with the reference's own sources compiled into oracle/_ref/ (see
- * oracle/Makefile), tests/test_oracle_golden.py with committed vectors that
- * were produced by that compiled reference (tests/golden/, generator
- * tests/golden/make_golden.py), and tests/test_idct_ieee1180.py re-runs the
- * reference's own IEEE-1180 unit test procedure (test/dct.c:229-261).
+ * restatement is PINNED by tests/test_oracle_pins.py: bit-for-bit against the
+ * reference's own sources compiled into oracle/_ref/ (see oracle/Makefile;
+ * test_oracle_equals_reference_*), against committed vectors that were
+ * produced by that compiled reference (tests/golden/, generator
+ * tests/golden/make_golden.py; test_golden_*, test_pack_consumer_*), against
+ * SURVEY Appendix C known answers, and by the reference's own IEEE-1180 unit
+ * test procedure (test/dct.c:229-261; test_ieee1180_accuracy).
  *
  * Exception: the upsample + YCbCr->RGB stage has NO CPU code and
  * no test in the reference (only GLSL, res/unyuv.fs.glsl) — for that stage
