@@ -10,7 +10,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JGA_LIB_PATH") or os.path.join(_HERE, "libjpeg_gpu_amd.so")   # (override: A/B builds)
 
-# Symbols include/jpeg_gpu_amd.h declares (checked by tests/test_abi.py).
+# Symbols include/jpeg_gpu_amd.h declares (checked by tests/test_layout_abi.py).
 EXPORTED = [
     "HIPJPEG_DECODE_CTX_VTBL", "jga_version", "jga_last_error", "jga_image_init",
     "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",

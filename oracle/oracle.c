@@ -38,7 +38,7 @@
 /* Per-axis scale factors, src/dct.c:89-98.  Written from their closed forms
  * S[0] = 1/(2*sqrt(2)), S[k] = cos(k*pi/16)/2 (doc/dct8.pdf); each rounds to
  * the same binary32 as the reference literal (bit patterns checked in
- * tests/test_oracle_constants.py). */
+ * tests/test_oracle_pins.py). */
 static const float ORC_S[8] = {
   (float)0.35355339059327373,  /* 3eb504f3 */
   (float)0.49039264020161522,  /* 3efb14be */
