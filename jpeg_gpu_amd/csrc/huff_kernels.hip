@@ -120,10 +120,10 @@ static __device__ __forceinline__ void hj_stage_image(hj_image *dst, const hj_im
 // Common prologue: lane context, tables and the group's subsequences staged in LDS.
 // Returns false for lanes beyond the image's last subsequence (they still took part
 // in staging).  lds_start[t] receives the clean-scan byte offset of subsequence t.
-template <bool STAGE_ROWS = true>
+template <bool STAGE_ROWS = true, int NB = HJ_BLOCK>
 static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_image &im,
  hj_tables *lds_tabs, uint32_t *lds_win, uint32_t *lds_start, hj_lane_ctx &L) {
-  const uint32_t li = blockIdx.x*HJ_BLOCK + threadIdx.x;
+  const uint32_t li = blockIdx.x*NB + threadIdx.x;
   const bool in_range = li < im.nsub;
   L.g = 0; L.si = 0; L.i = 0; L.stop_byte = 0;
   L.seg_start = L.seg_end = L.seg_nsub = L.seg_mcu0 = L.seg_nmcu = 0;
@@ -144,14 +144,14 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
   {
     const uint4 *tsrc = reinterpret_cast<const uint4 *>(A.tables + blockIdx.y);
     uint4 *tdst = reinterpret_cast<uint4 *>(lds_tabs);
-    for (int k = threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += HJ_BLOCK) tdst[k] = tsrc[k];
+    for (int k = threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += NB) tdst[k] = tsrc[k];
   }
   __syncthreads();
   // subsequence t: HJ_SUB_DWORDS dwords from (start & ~3)
   const uint8_t *scan = A.scan + im.scan_off;
   const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;      // bytes present in the batch buffer
-  const uint32_t nsubs = im.nsub - blockIdx.x*HJ_BLOCK < HJ_BLOCK ? im.nsub - blockIdx.x*HJ_BLOCK : HJ_BLOCK;
-  for (uint32_t c = threadIdx.x; STAGE_ROWS && c < nsubs*HJ_SUB_DWORDS; c += HJ_BLOCK) {
+  const uint32_t nsubs = im.nsub - blockIdx.x*NB < NB ? im.nsub - blockIdx.x*NB : NB;
+  for (uint32_t c = threadIdx.x; STAGE_ROWS && c < nsubs*HJ_SUB_DWORDS; c += NB) {
     const uint32_t sub = c/HJ_SUB_DWORDS, d = c - sub*HJ_SUB_DWORDS;
     uint32_t a = (lds_start[sub] & ~3u) + 4*d;
     if (a + 4 > padded) a = padded - 4;
@@ -558,28 +558,31 @@ struct hj_block_out {
   __device__ __forceinline__ void flush_partial(int slot, bool) { scatter(slot); }
 };
 
-// GMEM = true (default): the scan is read from global memory (hj_gmem_src; 44 KB of LDS, three
-// workgroups per CU, 1.17 ms per 48 x 4K); GMEM = false: rows staged in LDS like the sync
-// rounds' (80 KB, two per CU, 1.35 ms; JGA_HUFF_WRITE_GMEM=0).  The dense sync round is the
+// GMEM = true (default): the scan is read from global memory (hj_gmem_src) and a workgroup is
+// 512 lanes: 78 KB of LDS (block buffers + one copy of the tables), 2 x 8 waves per CU, 1.11 ms
+// per 48 x 4K; GMEM = false: rows staged in LDS like the sync rounds' (256 lanes, 80 KB, 2 x 4
+// waves per CU, 1.35 ms; JGA_HUFF_WRITE_GMEM=0).  The dense sync round is the
 // other way round (1.19 ms from LDS, 1.5 ms from global memory): it re-reads each row ~2.4x.
+#define HJ_WRITE_BLOCK 512           /* write pass from global memory: 78 KB of LDS, 2 x 8 waves per CU */
 template <bool GMEM>
-__global__ __launch_bounds__(HJ_BLOCK) void hj_write(const hj_args A) {
+__global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(const hj_args A) {
+  constexpr int NB = GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK;
   __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
   __shared__ uint32_t lds_win_mem[GMEM ? 1 : 1 + HJ_WIN_DWORDS];   // [0]: the dword "before" row 0 (hj_lds_src::reader)
   uint32_t *lds_win = lds_win_mem + (GMEM ? 0 : 1);
-  __shared__ uint32_t lds_blk[HJ_BLOCK*HJ_BLK_STRIDE];
+  __shared__ uint32_t lds_blk[NB*HJ_BLK_STRIDE];
   __shared__ hj_image s_im;
   __shared__ uint8_t s_dezz[64];
-  __shared__ uint8_t s_rank[HJ_BLOCK];
+  __shared__ uint8_t s_rank[NB];
   const hj_image im0 = A.images[blockIdx.y];
-  if (blockIdx.x*HJ_BLOCK >= im0.nsub) return;              // grid.x covers the largest image
+  if (blockIdx.x*NB >= im0.nsub) return;              // grid.x covers the largest image
   hj_stage_image(&s_im, A.images + blockIdx.y);
   if (threadIdx.x < 64) s_dezz[threadIdx.x] = HJ_DEZZ[threadIdx.x];
   // the subsequence start offsets are only needed while staging: they borrow the first
   // 1 KB of the block buffers, which are zeroed afterwards
   uint32_t *lds_start = lds_blk;
   hj_lane_ctx L;
-  const bool on = hj_prologue<!GMEM>(A, im0, &lds_tabs, lds_win, lds_start, L);   // syncs: s_im ready
+  const bool on = hj_prologue<!GMEM, NB>(A, im0, &lds_tabs, lds_win, lds_start, L);   // syncs: s_im ready
   hj_lds_src src = hj_source(lds_win, lds_start, threadIdx.x);
   hj_gmem_src gsrc;
   {
@@ -629,8 +632,13 @@ extern "C" int hj_launch_scan(const hj_args *A, int total_segs, void *stream) {
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream) {
-  dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages), block(HJ_BLOCK);
-  if (gmem) hipLaunchKernelGGL(hj_write<true>, grid, block, 0, (hipStream_t)stream, *A);
-  else hipLaunchKernelGGL(hj_write<false>, grid, block, 0, (hipStream_t)stream, *A);
+  if (gmem) {
+    dim3 grid((max_nsub + HJ_WRITE_BLOCK - 1)/HJ_WRITE_BLOCK, A->nimages);
+    hipLaunchKernelGGL(hj_write<true>, grid, dim3(HJ_WRITE_BLOCK), 0, (hipStream_t)stream, *A);
+  }
+  else {
+    dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
+    hipLaunchKernelGGL(hj_write<false>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A);
+  }
   return (int)hipGetLastError();
 }
