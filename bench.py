@@ -308,7 +308,7 @@ def main():
                               copy_back=copy_back, transport=transport, batch=24, depth=6)
             # enough images for every worker to reach steady state (its two slots allocated in the
             # warm-up, then several images each); the fast path needs more to ramp
-            n = args.e2e_images*6 if transport == 2 else max(args.e2e_images, 4*nthr)
+            n = args.e2e_images*12 if transport == 2 else max(args.e2e_images, 4*nthr)
             if copy_back:
                 n = min(n, 288)                   # 25 MB of host pixels per image
             jobs = [jpegs[i % len(jpegs)] for i in range(n)]
@@ -329,7 +329,7 @@ def main():
         e2e["host_threads"] = nthr
         e2e["note"] = "JPEG bytes in host RAM -> RGB; PCIe- and host-inclusive, not `value`. " \
                       "Default/pack transports: host Huffman threads + pinned hipMemcpyAsync + " \
-                      "fused kernel; gpu_entropy: host only unstuffs, 6 lanes x 24 images"
+                      "fused kernel; gpu_entropy: host only unstuffs, 6 lanes x 24 images, 3 with kernels queued at a time"
         out["e2e"] = e2e
 
     if rank == 0 and world == 1 and not args.no_pack:

@@ -33,6 +33,7 @@ struct jga_huff_batch {
   uint32_t *d_B;
   int16_t *d_D;
   uint32_t *d_ran, *d_errors;
+  uint32_t *d_part;            // chunk totals of the prefix-sum pass
   uint32_t *h_ran;             // pinned readback
   hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
@@ -67,6 +68,7 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipMalloc((void **)&b->d_R, sizeof(hj_run)*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_B, 4*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_D, 6*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_part, hj_scan_part_bytes(b->sub_cap, b->sub_cap)) == hipSuccess
    && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS) == hipSuccess
    && hipMalloc((void **)&b->d_errors, 4*(size_t)max_images) == hipSuccess
    && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess
@@ -89,6 +91,7 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_last_in) (void)hipFree(b->d_last_in);
   if (b->d_R) (void)hipFree(b->d_R);
   if (b->d_B) (void)hipFree(b->d_B);
+  if (b->d_part) (void)hipFree(b->d_part);
   if (b->d_D) (void)hipFree(b->d_D);
   if (b->d_ran) (void)hipFree(b->d_ran);
   if (b->d_errors) (void)hipFree(b->d_errors);
@@ -109,11 +112,13 @@ static bool grow_batch(jga_huff_batch *b, size_t need_sub, size_t need_blob) {
     if (b->d_R) (void)hipFree(b->d_R);
     if (b->d_B) (void)hipFree(b->d_B);
     if (b->d_D) (void)hipFree(b->d_D);
-    b->d_last_in = NULL; b->d_R = NULL; b->d_B = NULL; b->d_D = NULL; b->sub_cap = 0;
+    if (b->d_part) (void)hipFree(b->d_part);
+    b->d_last_in = NULL; b->d_R = NULL; b->d_B = NULL; b->d_D = NULL; b->d_part = NULL; b->sub_cap = 0;
     if (hipMalloc((void **)&b->d_last_in, 8*cap) != hipSuccess
      || hipMalloc((void **)&b->d_R, sizeof(hj_run)*cap) != hipSuccess
      || hipMalloc((void **)&b->d_B, 4*cap) != hipSuccess
-     || hipMalloc((void **)&b->d_D, 6*cap) != hipSuccess) {
+     || hipMalloc((void **)&b->d_D, 6*cap) != hipSuccess
+     || hipMalloc((void **)&b->d_part, hj_scan_part_bytes(cap, cap)) != hipSuccess) {
       return false;
     }
     b->sub_cap = cap;
@@ -325,6 +330,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   A.R = b->d_R;
   A.B = b->d_B;
   A.D = b->d_D;
+  A.scan_part = b->d_part;
   A.ran = b->d_ran;
   A.errors = b->d_errors;
   A.coef = (int16_t *)d_coef;
@@ -371,7 +377,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   }
   b->last_rounds = 0;
   while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;
-  if (hj_launch_scan(&A, (int)b->total_seg, st)) return jga_fail("huff: launch failed");
+  if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
   HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
   if (hj_launch_write(&A, (int)b->max_nsub, write_gmem, st)) return jga_fail("huff: launch failed");
   HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));

@@ -1,6 +1,7 @@
 /* huff_kernels.h — launch arguments of the GPU entropy stage (huff_kernels.hip). */
 #ifndef JGA_HUFF_KERNELS_H
 #define JGA_HUFF_KERNELS_H (1)
+#include <stddef.h>
 #include "huff_common.h"
 
 #define HJ_MAX_ROUNDS 256
@@ -16,6 +17,7 @@ typedef struct hj_args {
   hj_run *R;                   /* result of each lane's latest run */
   uint32_t *B;                 /* blocks before the lane, within its segment */
   int16_t *D;                  /* [3*sub] DC sums before the lane */
+  uint32_t *scan_part;         /* chunk totals of the prefix-sum pass (hj_scan_part_bytes) */
   uint32_t *ran;               /* [HJ_MAX_ROUNDS] non-zero if any lane ran in that round */
   uint32_t *errors;            /* [nimages] bit0 inconsistent stream, bit1 bad coefficient index */
   int16_t *coef;               /* image i at coef + i*coef_stride */
@@ -29,7 +31,8 @@ extern "C" {
 #endif
 /* sparse != 0: the one-wave-per-group variant for rounds in which few lanes still move */
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
-int hj_launch_scan(const hj_args *A, int total_segs, void *stream);
+int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
+size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);
 /* gmem != 0: the write pass reads the scan from global memory instead of an LDS copy */
 int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream);
 #ifdef __cplusplus

@@ -416,60 +416,109 @@ __global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round,
   if (__syncthreads_or(ran_any) && lane == 0) atomicOr(&A.ran[round], 1u);
 }
 
-#define HJ_SCAN_BLOCK 1024          /* lanes scanned per step (few segments: make them wide) */
-// Exclusive prefix sums over the lanes of one segment.  Sequential over chunks of
-// 256 lanes, Hillis-Steele inside a chunk.
+#define HJ_SCAN_BLOCK 1024          /* threads per chunk */
+#define HJ_SCAN_ITEMS 4             /* consecutive lanes summed by one thread */
+#define HJ_SCAN_CHUNK_LOG2 12       /* HJ_SCAN_BLOCK*HJ_SCAN_ITEMS lanes per workgroup */
+static_assert(HJ_SCAN_BLOCK*HJ_SCAN_ITEMS == 1 << HJ_SCAN_CHUNK_LOG2, "chunk size");
+// Exclusive prefix sums (blocks completed, DC differences per component) over the lanes of
+// every segment, in two launches so that a long segment is not one workgroup's serial loop
+// (one 4K 4:4:4 image without restart markers: 196 us -> 2 x ~10): a workgroup takes a chunk
+// of 4096 lanes (each thread sums four consecutive lanes, a shuffle scan runs over the
+// wavefront, the sixteen wave totals go through LDS);
+//   FINAL = false  stores the chunk's totals,
+//   FINAL = true   adds the totals of the chunks before it in the segment and writes B / D.
+// Chunk c of segment gs keeps its totals at scan_part[gs + (first lane of the segment >> 12)
+// + c]: distinct and increasing over the batch, below total_seg + total_sub/4096 + 1.
+template <bool FINAL>
 __global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
-  __shared__ uint32_t sb[HJ_SCAN_BLOCK];
-  __shared__ int sd[3][HJ_SCAN_BLOCK];
+  __shared__ uint32_t wtot[HJ_SCAN_BLOCK/64][4];
   // blockIdx.x = batch-global segment; find its image (few images: linear search)
-  const uint32_t gs = blockIdx.x;
+  const uint32_t gs = blockIdx.x, c = blockIdx.y;
   int img = 0;
   while (img + 1 < A.nimages && A.images[img + 1].seg0 <= gs) img++;
   const hj_image im = A.images[img];
   const hj_segment sg = A.segs[gs];
+  const uint32_t c0 = c << HJ_SCAN_CHUNK_LOG2;
+  if (c0 >= sg.nsub) return;
   const uint32_t si = gs - im.seg0;
   const uint32_t total = sg.nmcu*(uint32_t)im.nslots;
-  uint32_t base_b = 0;
-  int base_d[3] = {0, 0, 0};
-  bool bad = false;
-  for (uint32_t c0 = 0; c0 < sg.nsub; c0 += HJ_SCAN_BLOCK) {
-    const uint32_t i = c0 + threadIdx.x;
-    const bool on = i < sg.nsub;
-    const uint32_t g = im.sub0 + sg.sub0 + i;
-    hj_run r;
-    r.nblocks = 0; r.dcsum[0] = r.dcsum[1] = r.dcsum[2] = 0;
-    if (on) r = A.R[g];
-    sb[threadIdx.x] = r.nblocks;
-    sd[0][threadIdx.x] = r.dcsum[0]; sd[1][threadIdx.x] = r.dcsum[1]; sd[2][threadIdx.x] = r.dcsum[2];
-    __syncthreads();
-    for (int d = 1; d < HJ_SCAN_BLOCK; d <<= 1) {
-      uint32_t vb = 0;
-      int v0 = 0, v1 = 0, v2 = 0;
-      if ((int)threadIdx.x >= d) {
-        vb = sb[threadIdx.x - d];
-        v0 = sd[0][threadIdx.x - d]; v1 = sd[1][threadIdx.x - d]; v2 = sd[2][threadIdx.x - d];
-      }
-      __syncthreads();
-      sb[threadIdx.x] += vb;
-      sd[0][threadIdx.x] += v0; sd[1][threadIdx.x] += v1; sd[2][threadIdx.x] += v2;
-      __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t first = im.sub0 + sg.sub0;
+  uint32_t *part = A.scan_part + 4*(size_t)(gs + (first >> HJ_SCAN_CHUNK_LOG2) + c);
+  const uint32_t i0 = c0 + threadIdx.x*HJ_SCAN_ITEMS;
+  const uint32_t g0 = first + i0;
+  uint32_t v[HJ_SCAN_ITEMS][4];                              // [0] blocks, [1..3] DC sums (mod 2^16)
+  uint32_t slot[HJ_SCAN_ITEMS];
+  uint32_t mine[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < HJ_SCAN_ITEMS; j++) {
+    v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0;
+    slot[j] = 0;
+    if (i0 + j < sg.nsub) {
+      const hj_run r = A.R[g0 + j];
+      if (FINAL) slot[j] = (uint32_t)hj_slot(A.S[g0 + j + im.seg0 + si]);
+      v[j][0] = r.nblocks;
+      v[j][1] = (uint32_t)(int)r.dcsum[0]; v[j][2] = (uint32_t)(int)r.dcsum[1]; v[j][3] = (uint32_t)(int)r.dcsum[2];
     }
-    if (on) {
-      const uint32_t excl = base_b + sb[threadIdx.x] - r.nblocks;
-      A.B[g] = excl;
-      A.D[3*g + 0] = (int16_t)(base_d[0] + sd[0][threadIdx.x] - r.dcsum[0]);
-      A.D[3*g + 1] = (int16_t)(base_d[1] + sd[1][threadIdx.x] - r.dcsum[1]);
-      A.D[3*g + 2] = (int16_t)(base_d[2] + sd[2][threadIdx.x] - r.dcsum[2]);
-      // the slot a lane starts in must agree with the number of blocks before it
-      const uint64_t st = A.S[g + im.seg0 + si];
-      if (excl < total && hj_slot(st) != (int)(excl % (uint32_t)im.nslots)) bad = true;
-    }
-    base_b += sb[HJ_SCAN_BLOCK - 1];
-    base_d[0] += sd[0][HJ_SCAN_BLOCK - 1]; base_d[1] += sd[1][HJ_SCAN_BLOCK - 1]; base_d[2] += sd[2][HJ_SCAN_BLOCK - 1];
-    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 4; f++) mine[f] += v[j][f];
   }
-  if (base_b < total) bad = true;                            // data ran out before the last MCU
+  uint32_t run[4] = {0, 0, 0, 0};
+  if (FINAL) {                                               // chunks before this one
+    for (uint32_t k = 1; k <= c; k++) {
+#pragma unroll
+      for (int f = 0; f < 4; f++) run[f] += part[f - 4*(int)k];
+    }
+  }
+  uint32_t inc[4] = {mine[0], mine[1], mine[2], mine[3]};
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      const uint32_t x = (uint32_t)__shfl_up((int)inc[f], d);
+      if ((int)lane >= d) inc[f] += x;
+    }
+  }
+  if (lane == 63u) {
+#pragma unroll
+    for (int f = 0; f < 4; f++) wtot[wave][f] = inc[f];
+  }
+  __syncthreads();
+  uint32_t tot[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int f = 0; f < 4; f++) run[f] += inc[f] - mine[f];
+  for (uint32_t w = 0; w < HJ_SCAN_BLOCK/64; w++) {
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+      const uint32_t x = wtot[w][f];
+      tot[f] += x;
+      if (w < wave) run[f] += x;
+    }
+  }
+  if (!FINAL) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int f = 0; f < 4; f++) part[f] = tot[f];
+    }
+    return;
+  }
+  bool bad = false;
+  // data ran out before the last MCU (seen by the segment's last chunk)
+  if (c0 + (1u << HJ_SCAN_CHUNK_LOG2) >= sg.nsub && threadIdx.x == 0 && run[0] + tot[0] < total) bad = true;
+#pragma unroll
+  for (int j = 0; j < HJ_SCAN_ITEMS; j++) {
+    if (i0 + j < sg.nsub) {
+      const uint32_t g = g0 + j;
+      A.B[g] = run[0];
+      A.D[3*g + 0] = (int16_t)run[1];
+      A.D[3*g + 1] = (int16_t)run[2];
+      A.D[3*g + 2] = (int16_t)run[3];
+      // the slot a lane starts in must agree with the number of blocks before it
+      if (run[0] < total && slot[j] != run[0] % (uint32_t)im.nslots) bad = true;
+    }
+#pragma unroll
+    for (int f = 0; f < 4; f++) run[f] += v[j][f];
+  }
   if (bad) atomicOr(&A.errors[img], 1u);
 }
 
@@ -627,9 +676,14 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
   else hipLaunchKernelGGL(hj_sync_round, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters);
   return (int)hipGetLastError();
 }
-extern "C" int hj_launch_scan(const hj_args *A, int total_segs, void *stream) {
-  hipLaunchKernelGGL(hj_scan, dim3(total_segs), dim3(HJ_SCAN_BLOCK), 0, (hipStream_t)stream, *A);
+extern "C" int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream) {
+  const dim3 grid(total_segs, (max_nsub + (1 << HJ_SCAN_CHUNK_LOG2) - 1) >> HJ_SCAN_CHUNK_LOG2);
+  if (grid.y > 1) hipLaunchKernelGGL(hj_scan<false>, grid, dim3(HJ_SCAN_BLOCK), 0, (hipStream_t)stream, *A);
+  hipLaunchKernelGGL(hj_scan<true>, grid, dim3(HJ_SCAN_BLOCK), 0, (hipStream_t)stream, *A);
   return (int)hipGetLastError();
+}
+extern "C" size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs) {
+  return 16*(total_segs + (total_subs >> HJ_SCAN_CHUNK_LOG2) + 2);
 }
 extern "C" int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream) {
   if (gmem) {

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime_api.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -71,6 +73,14 @@ struct jga_pipeline {
   jga_pipeline_config cfg;
   std::vector<worker> workers;
   std::vector<hlane> lanes;
+  // transport 2: how many lanes may have kernels queued at a time.  The other lanes
+  // prepare and upload their next group meanwhile, so the device always finds work: with
+  // every lane free to launch, the streams share the device evenly, all groups finish
+  // together and all lanes then parse and upload together with the device idle (23 % of
+  // the time, measured).
+  std::mutex dev_mutex;
+  std::condition_variable dev_cv;
+  int dev_slots = 3;
 };
 
 namespace {
@@ -243,6 +253,25 @@ bool grow(void **p, long long *cap, long long want, bool pinned) {
   return true;
 }
 
+struct device_turn {                 // one of jga_pipeline::dev_slots, held for a group's kernels
+  jga_pipeline *pl;
+  bool held = false;
+  explicit device_turn(jga_pipeline *p) : pl(p) {}
+  void take() {
+    std::unique_lock<std::mutex> lk(pl->dev_mutex);
+    pl->dev_cv.wait(lk, [this] { return pl->dev_slots > 0; });
+    pl->dev_slots--;
+    held = true;
+  }
+  void give() {
+    if (!held) return;
+    { std::lock_guard<std::mutex> lk(pl->dev_mutex); pl->dev_slots++; }
+    pl->dev_cv.notify_one();
+    held = false;
+  }
+  ~device_turn() { give(); }
+};
+
 // Decode jobs[0..m) as ONE batch of the GPU entropy stage.  Fails as a whole (mixed
 // geometry, a corrupt member, ...); the caller then retries the members one by one.
 int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads) {
@@ -290,6 +319,8 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
    || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*m, true))) {
     return EXIT_FAILURE;
   }
+  device_turn turn(pl);
+  turn.take();                        // (the group's upload is already in flight)
   const auto t_b = std::chrono::steady_clock::now();
   if (host_entropy) {
     unsigned short q[192];
@@ -331,6 +362,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     }
   }
   if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;
+  turn.give();
   if (trace) {
     const auto t_d = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -428,6 +460,8 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
   }
   if (pl->cfg.transport == 2) {
     pl->lanes.resize(pl->cfg.depth > 0 ? pl->cfg.depth : 6);
+    if (const char *e = getenv("JGA_PIPE_DEVICE_SLOTS")) pl->dev_slots = atoi(e) > 0 ? atoi(e) : 1;   // tuning knob
+    if (pl->dev_slots > (int)pl->lanes.size()) pl->dev_slots = (int)pl->lanes.size();
     for (auto &l : pl->lanes) {
       if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")) {
         jga_pipeline_destroy(pl);
