@@ -34,6 +34,7 @@ struct jga_huff_batch {
   int16_t *d_D;
   uint32_t *d_ran, *d_errors;
   uint32_t *d_part;            // chunk totals of the prefix-sum pass
+  int sub_log2, force_sub_log2;  // subsequence length of the current batch / JGA_HUFF_SUB
   uint32_t *h_ran;             // pinned readback
   hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
@@ -57,7 +58,12 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   memset(static_cast<void *>(b), 0, offsetof(jga_huff_batch, qtab));
   b->max_images = max_images;
   b->max_scan = max_scan_bytes;
-  b->sub_cap = (size_t)(max_scan_bytes/HJ_SUB_BYTES) + (size_t)max_images*4096 + 1024;
+  // (grow_batch covers streams cut into very many restart intervals)
+  b->sub_cap = (size_t)(max_scan_bytes >> hj_choose_sub_log2((uint64_t)max_scan_bytes)) + (size_t)max_images*4096 + 1024;
+  if (const char *e = getenv("JGA_HUFF_SUB")) {               // tuning knob / tests: 32, 64 or 128
+    const int v = atoi(e);
+    b->force_sub_log2 = v == 32 ? 5 : v == 64 ? 6 : v == 128 ? 7 : 0;
+  }
   const size_t seg_cap = b->sub_cap;   // worst case one segment per subsequence
   b->blob_cap = align_up(sizeof(hj_image)*max_images, 256) + align_up(sizeof(hj_segment)*seg_cap, 256)
    + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_tables)*max_images, 256)
@@ -200,6 +206,9 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
         o += align_up((size_t)prep[i].avail + 16, 16);
       }
       if ((long long)o > b->max_scan + 64ll*n) fatal.store(2);
+      // subsequence length of this batch (the stuffed length is close enough to the clean one)
+      b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o);
+      for (int i = 0; i < n; i++) prep[i].sub_log2 = b->sub_log2;
       b->off_scan = 0;
       b->scan_bytes = align_up(o, 256);
       if (fatal.load()) stop.store(1);
@@ -266,7 +275,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
         segs[seg0 + si] = sg;
         for (uint32_t k = 0; k < sg.nsub; k++) {
           sub_seg[sub0 + sg.sub0 + k] = (uint32_t)si;
-          const uint32_t byte = sg.start + k*HJ_SUB_BYTES; // guess: a symbol starts on this byte
+          const uint32_t byte = sg.start + (k << b->sub_log2); // guess: a symbol starts on this byte
           S[sub0 + seg0 + sg.sub0 + si + k] = hj_pack((uint64_t)byte*8, 0, 0);
         }
         S[sub0 + seg0 + sg.sub0 + si + sg.nsub] = 0;
@@ -363,6 +372,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
     if (flush_lanes < 1) flush_lanes = 1;
   }
   A.flush_lanes = flush_lanes;
+  A.sub_log2 = b->sub_log2;
   const int GROUP = group;
   for (;;) {
     for (int k = 0; k < GROUP && round < HJ_MAX_ROUNDS; k++, round++) {

@@ -23,6 +23,7 @@ typedef struct hj_args {
   int16_t *coef;               /* image i at coef + i*coef_stride */
   long long coef_stride;
   int nimages;
+  int sub_log2;                /* subsequence length = 1 << sub_log2 bytes (5..7) */
   int flush_lanes;             /* finished blocks a wave collects before writing them out */
 } hj_args;
 

@@ -22,9 +22,12 @@
 
 #define HJ_BLOCK 256
 // staged scan bytes: 256 subsequences x 35 dwords (3 alignment + 128 + look-ahead bytes)
-#define HJ_SUB_DWORDS 35
-#define HJ_SUB_STRIDE 35            /* odd: lanes walking their own copies hit different banks */
-#define HJ_WIN_DWORDS (HJ_BLOCK*HJ_SUB_STRIDE + 8)
+// A staged subsequence row: its bytes from (start & ~3) plus what the last symbol may reach
+// past the end, (1 << sub_log2)/4 + 3 dwords = 11, 19 or 35 (odd: lanes walking their own rows
+// hit different banks).
+#define HJ_SUB_DWORDS_MAX (HJ_SUB_BYTES_MAX/4 + 3)
+#define HJ_WIN_DWORDS (HJ_BLOCK*HJ_SUB_DWORDS_MAX + 8)
+static __device__ __forceinline__ uint32_t hj_sub_dwords(const hj_args &A) { return (1u << (A.sub_log2 - 2)) + 3u; }
 #define HJ_BLK_STRIDE 33            /* dwords per lane's block buffer (32 + 1 against conflicts) */
 
 __device__ const uint8_t HJ_DEZZ[64] = {     // T.81 Figure A.6: zig-zag index -> natural index
@@ -135,8 +138,8 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
     L.i = li - sg.sub0;
     L.seg_start = sg.start; L.seg_end = sg.end; L.seg_nsub = sg.nsub;
     L.seg_mcu0 = sg.mcu0; L.seg_nmcu = sg.nmcu;
-    my_start = sg.start + L.i*HJ_SUB_BYTES;
-    L.stop_byte = my_start + HJ_SUB_BYTES;
+    my_start = sg.start + (L.i << A.sub_log2);
+    L.stop_byte = my_start + (1u << A.sub_log2);
     if (L.stop_byte > sg.end) L.stop_byte = sg.end;
   }
   lds_start[threadIdx.x] = my_start;
@@ -147,15 +150,17 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
     for (int k = threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += NB) tdst[k] = tsrc[k];
   }
   __syncthreads();
-  // subsequence t: HJ_SUB_DWORDS dwords from (start & ~3)
+  // subsequence t: hj_sub_dwords() dwords from (start & ~3)
   const uint8_t *scan = A.scan + im.scan_off;
   const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;      // bytes present in the batch buffer
   const uint32_t nsubs = im.nsub - blockIdx.x*NB < NB ? im.nsub - blockIdx.x*NB : NB;
-  for (uint32_t c = threadIdx.x; STAGE_ROWS && c < nsubs*HJ_SUB_DWORDS; c += NB) {
-    const uint32_t sub = c/HJ_SUB_DWORDS, d = c - sub*HJ_SUB_DWORDS;
+  const uint32_t sdw = hj_sub_dwords(A);
+  const uint32_t magic = 0xFFFFFFFFu/sdw + 1u;                 // c/sdw == umulhi(c, magic) for c < 2^16
+  for (uint32_t c = threadIdx.x; STAGE_ROWS && c < nsubs*sdw; c += NB) {
+    const uint32_t sub = __umulhi(c, magic), d = c - sub*sdw;
     uint32_t a = (lds_start[sub] & ~3u) + 4*d;
     if (a + 4 > padded) a = padded - 4;
-    lds_win[sub*HJ_SUB_STRIDE + d] = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(scan + a));
+    lds_win[sub*sdw + d] = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(scan + a));
   }
   __syncthreads();
   return in_range;
@@ -163,9 +168,9 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
 
 // Bit source of subsequence `sub` of the group.
 static __device__ __forceinline__ hj_lds_src hj_source(const uint32_t *lds_win,
- const uint32_t *lds_start, uint32_t sub) {
+ const uint32_t *lds_start, uint32_t sub, uint32_t sdw) {
   hj_lds_src s;
-  s.base = lds_win + sub*HJ_SUB_STRIDE;
+  s.base = lds_win + sub*sdw;
   s.bit0 = (lds_start[sub] & ~3u) << 3;
   return s;
 }
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
       const uint32_t sub = lds_act[t];
       const uint64_t start = lds_S[sub];
       const uint32_t sb = lds_stop[sub];
-      const hj_run r = hj_sync_decode(hj_source(lds_win, lds_start, sub), s_im, &lds_tabs, start,
+      const hj_run r = hj_sync_decode(hj_source(lds_win, lds_start, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
        (uint64_t)(sb & 0x7fffffffu)*8);
       hj_run16 r16;
       r16.nblocks = (uint16_t)r.nblocks;
@@ -327,8 +332,8 @@ __global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round,
       sidx[q] = g[q] + im.seg0 + si;
       st = A.S[sidx[q]];
       dirty = st != A.last_in[g[q]];
-      start = sg.start + i*HJ_SUB_BYTES;
-      stop = start + HJ_SUB_BYTES;
+      start = sg.start + (i << A.sub_log2);
+      stop = start + (1u << A.sub_log2);
       if (stop > sg.end) stop = sg.end;
       if (i + 1 < sg.nsub) stop |= 0x80000000u;
     }
@@ -632,7 +637,7 @@ __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(c
   uint32_t *lds_start = lds_blk;
   hj_lane_ctx L;
   const bool on = hj_prologue<!GMEM, NB>(A, im0, &lds_tabs, lds_win, lds_start, L);   // syncs: s_im ready
-  hj_lds_src src = hj_source(lds_win, lds_start, threadIdx.x);
+  hj_lds_src src = hj_source(lds_win, lds_start, threadIdx.x, hj_sub_dwords(A));
   hj_gmem_src gsrc;
   {
     const uint32_t a = lds_start[threadIdx.x] & ~3u;

@@ -169,7 +169,7 @@ int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsig
     s.start = clean_start;
     s.end = w;
     s.sub0 = nsub;
-    s.nsub = (s.end - s.start + HJ_SUB_BYTES - 1)/HJ_SUB_BYTES;
+    s.nsub = (s.end - s.start + (1u << out->sub_log2) - 1) >> out->sub_log2;
     if (s.nsub == 0) s.nsub = 1;
     s.mcu0 = mcu0;
     s.nmcu = ri ? (total_mcus - mcu0 < ri ? total_mcus - mcu0 : ri) : total_mcus;

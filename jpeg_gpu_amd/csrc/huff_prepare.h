@@ -18,7 +18,8 @@ struct hj_prepared {
   // between the two steps:
   jga_scan_desc *desc;              // marker segments (owned; freed by hj_prepare_scan / _drop)
   uint32_t avail;                   // bytes from the start of the scan to the end of the file
-  hj_prepared() : scan_len(0), raw_len(0), desc(nullptr), avail(0) {}
+  int sub_log2;                     // subsequence length hj_prepare_scan cuts the segments into (set by the caller)
+  hj_prepared() : scan_len(0), raw_len(0), desc(nullptr), avail(0), sub_log2(HJ_SUB_LOG2_MAX) {}
   ~hj_prepared();
   hj_prepared(const hj_prepared &) = delete;
   hj_prepared &operator=(const hj_prepared &) = delete;

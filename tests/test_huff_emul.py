@@ -18,10 +18,12 @@ def emul(lib):
     E.huff_emul_decode.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int,
                                    C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_longlong)]
+    E.huff_emul_set_sub.argtypes = [C.c_int]
     return E
 
 
-def run(E, lib, data, jacobi=1):
+def run(E, lib, data, jacobi=1, sub=128):
+    assert E.huff_emul_set_sub(sub) == 0
     _, g = lib.geom_of(data)
     got = np.zeros(g.coef_shorts, np.int16)
     r, n, runs = C.c_int(), C.c_int(), C.c_longlong()
@@ -32,12 +34,13 @@ def run(E, lib, data, jacobi=1):
 
 @pytest.mark.parametrize("sampling", ["grey", "444", "422", "420", "440", "411"])
 @pytest.mark.parametrize("ri", [0, -1, 1, 5])
-def test_emulated_gpu_decode_equals_host_decode(emul, lib, synth, sampling, ri):
+@pytest.mark.parametrize("sub", [32, 64, 128])
+def test_emulated_gpu_decode_equals_host_decode(emul, lib, synth, sampling, ri, sub):
     for q, size in ((90, (333, 211)), (35, (97, 64))):
         data = synth.synthetic_jpeg(size[0], size[1], sampling, quality=q, restart_interval=ri,
                                     seed=q)
         _, g = lib.geom_of(data)
-        rc, got, rounds, nsub, runs = run(emul, lib, data)
+        rc, got, rounds, nsub, runs = run(emul, lib, data, sub=sub)
         assert rc == 0
         assert np.array_equal(got, lib.entropy_decode(data, g))
         assert rounds <= nsub + 1
@@ -45,8 +48,9 @@ def test_emulated_gpu_decode_equals_host_decode(emul, lib, synth, sampling, ri):
 
 def test_golden_and_levels(emul, lib, synth, golden_jpegs):
     for name in golden_jpegs.names:
-        rc, got, *_ = run(emul, lib, golden_jpegs.jpeg(name))
-        assert rc == 0 and np.array_equal(got, golden_jpegs[name + ".quant"]), name
+        for sub in (32, 64, 128):
+            rc, got, *_ = run(emul, lib, golden_jpegs.jpeg(name), sub=sub)
+            assert rc == 0 and np.array_equal(got, golden_jpegs[name + ".quant"]), (name, sub)
     # dense full-magnitude levels, long zero runs, stuffed FF bytes galore
     rng = np.random.default_rng(4)
     n = synth.coef_shorts(256, 128, "420")
@@ -54,9 +58,10 @@ def test_golden_and_levels(emul, lib, synth, golden_jpegs):
     lv.reshape(-1, 64)[::2, 5:] = 0
     data = synth.encode_levels(lv, 256, 128, "420")
     assert data.count(b"\xff\x00") > 50
-    rc, got, rounds, nsub, runs = run(emul, lib, data)
     _, g = lib.geom_of(data)
-    assert rc == 0 and np.array_equal(got, lib.entropy_decode(data, g))
+    for sub in (32, 64, 128):
+        rc, got, rounds, nsub, runs = run(emul, lib, data, sub=sub)
+        assert rc == 0 and np.array_equal(got, lib.entropy_decode(data, g)), sub
 
 
 def test_rounds_are_few(emul, lib, synth):
@@ -64,3 +69,6 @@ def test_rounds_are_few(emul, lib, synth):
     data = synth.synthetic_jpeg(1920, 1080, "420", quality=90, seed=1)
     rc, got, rounds, nsub, runs = run(emul, lib, data)
     assert rc == 0 and rounds < 40 and runs < 4 * nsub
+    # shorter subsequences need more hand-overs to fall into step, not more bytes decoded
+    rc, got, rounds32, nsub32, runs32 = run(emul, lib, data, sub=32)
+    assert rc == 0 and nsub32 > 3 * nsub and rounds32 < 80 and runs32 < 8 * nsub32

@@ -40,11 +40,21 @@ struct block_out {
   }
 };
 
+static int g_sub_log2 = HJ_SUB_LOG2_MAX;
+// Subsequence length (32, 64 or 128 bytes) of the following decodes.
+extern "C" __attribute__((visibility("default")))
+int huff_emul_set_sub(int bytes) {
+  if (bytes != 32 && bytes != 64 && bytes != 128) return 1;
+  g_sub_log2 = bytes == 32 ? 5 : bytes == 64 ? 6 : 7;
+  return 0;
+}
+
 extern "C" __attribute__((visibility("default")))
 int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long coef_shorts,
  int jacobi, int *rounds_out, int *nsub_out, long long *runs_out) {
   hj_prepared P;
   (void)DEZZ_INIT;
+  P.sub_log2 = g_sub_log2;
   if (hj_prepare_image(jpeg, size, &P) != EXIT_SUCCESS) return 1;
   if (coef_shorts < P.geom.coef_shorts) return 2;
   init_dezz();
@@ -57,7 +67,7 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
     const hj_segment &sg = P.segs[si];
     for (uint32_t i = 0; i < sg.nsub; i++) {
       sub_seg[sg.sub0 + i] = (uint32_t)si;
-      const uint32_t byte = sg.start + i*HJ_SUB_BYTES;
+      const uint32_t byte = sg.start + (i << g_sub_log2);
       S[sg.sub0 + si + i] = hj_pack((uint64_t)byte*8, 0, 0);
     }
     S[sg.sub0 + si + sg.nsub] = 0;
@@ -76,7 +86,7 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
       const uint32_t i = g - sg.sub0;
       const uint64_t start = jacobi ? snap[g + si] : S[g + si];
       if (start == last_in[g]) continue;
-      uint32_t stop_byte = sg.start + (i + 1)*HJ_SUB_BYTES;
+      uint32_t stop_byte = sg.start + ((i + 1) << g_sub_log2);
       if (stop_byte > sg.end) stop_byte = sg.end;
       hj_mem_src src; src.s = P.clean.data();
       R[g] = hj_sync_decode(src, P.im, &P.tabs, start, (uint64_t)stop_byte*8);
