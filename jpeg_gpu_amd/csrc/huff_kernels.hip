@@ -79,17 +79,19 @@ struct hj_gmem_src {
     const uint32_t *base;
     uint32_t bit0, ndw;
     int32_t r1, stop1, d;
-    uint32_t w0, w1, w2;
-    __device__ __forceinline__ uint32_t fetch(int32_t i) const {
+    uint32_t w0, w1, w2raw;            // w2raw: the dword after w1 as loaded (not yet byte-swapped)
+    // The dword two ahead is requested at a crossing and first TOUCHED at the next one (the
+    // byte swap waits for the load): a run never stalls on the load it has just issued.
+    __device__ __forceinline__ uint32_t fetch_raw(int32_t i) const {
       const int32_t k = i < 0 ? 0 : ((uint32_t)i < ndw ? i : (int32_t)ndw - 1);
-      return __builtin_bswap32(base[k]);
+      return base[k];
     }
     __device__ __forceinline__ void init(const hj_gmem_src &src, uint64_t pos, uint64_t stop_bit) {
       base = reinterpret_cast<const uint32_t *>(src.row); bit0 = src.bit0; ndw = src.ndw;
       r1 = (int32_t)((uint32_t)pos - bit0) - 1;
       stop1 = (int32_t)((uint32_t)stop_bit - bit0) - 1;
       d = r1 >> 5;
-      w0 = fetch(d); w1 = fetch(d + 1); w2 = fetch(d + 2);
+      w0 = __builtin_bswap32(fetch_raw(d)); w1 = __builtin_bswap32(fetch_raw(d + 1)); w2raw = fetch_raw(d + 2);
     }
     __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
     __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w0, w1, ~(uint32_t)r1); }
@@ -97,8 +99,8 @@ struct hj_gmem_src {
       r1 += n;
       const int32_t nd = r1 >> 5;
       if (nd != d) {                 // a symbol is at most 31 bits: one dword further at most
-        d = nd; w0 = w1; w1 = w2;
-        w2 = fetch(d + 2);
+        d = nd; w0 = w1; w1 = __builtin_bswap32(w2raw);
+        w2raw = fetch_raw(d + 2);
       }
     }
     __device__ __forceinline__ uint64_t tell() const { return (uint64_t)((uint32_t)(r1 + 1) + bit0); }
@@ -285,74 +287,64 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
 // A launch then costs (groups with a moving lane) x (latency of one run) / (workgroups
 // in flight), whatever the groups hold — so this variant trades lanes for residency: ONE
 // wave per group of 256 subsequences, running at most 64 of them at a time, each reading its
-// scan row from global memory (hj_gmem_src: every row is read once here, nothing to reuse).
-// 18 KB of LDS instead of 54: nine groups in flight per CU instead of three.  Same
-// indexing, same hand-over protocol and same results as hj_sync_round.
-#define HJ_POOL 64
-__global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round, int max_iters) {
+// scan row from global memory (hj_gmem_src: every row is read once here, nothing to reuse)
+// and looking its byte range up when it runs; run results go straight to global memory.
+// Four groups (waves) share a workgroup's copy of the tables and never meet at a barrier
+// after it is staged: 23 KB of LDS per 4 groups instead of 54 KB per group, 28 groups in
+// flight per CU instead of three.  Same indexing, same hand-over protocol and same results as
+// hj_sync_round.
+#define HJ_SPARSE_GROUPS 4
+static __device__ __forceinline__ void hj_wave_sync() {      // LDS hand-over inside one wavefront
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_args A, int round, int max_iters) {
+  constexpr int NG = HJ_SPARSE_GROUPS;
   __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
-  __shared__ uint64_t lds_S[HJ_BLOCK + 1];
-  __shared__ hj_run16 lds_R[HJ_BLOCK];
-  __shared__ uint32_t lds_stop[HJ_BLOCK], lds_start[HJ_BLOCK];
-  __shared__ uint8_t lds_dirty[HJ_BLOCK], lds_ran[HJ_BLOCK];
-  __shared__ uint16_t lds_act[HJ_BLOCK];
-  __shared__ uint32_t lds_sidx_last;
+  __shared__ uint64_t lds_S_all[NG][HJ_BLOCK + 1];
+  __shared__ uint8_t lds_dirty_all[NG][HJ_BLOCK], lds_ran_all[NG][HJ_BLOCK];
+  __shared__ uint16_t lds_act_all[NG][HJ_BLOCK];
   __shared__ hj_image s_im;
   const hj_image im = A.images[blockIdx.y];
-  const uint32_t lane = threadIdx.x;
-  {
-    // cheap exit before anything else: did any lane's start state move since its last run?
-    bool need = false;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t li = blockIdx.x*HJ_BLOCK + (uint32_t)q*64u + lane;
-      if (li < im.nsub) {
-        const uint32_t gg = im.sub0 + li;
-        need = need || A.S[gg + im.seg0 + A.sub_seg[gg]] != A.last_in[gg];
-      }
-    }
-    if (!__syncthreads_or(need)) return;
-  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t group = blockIdx.x*NG + wave;               // this wave's 256 subsequences
+  uint64_t *lds_S = lds_S_all[wave];
+  uint8_t *lds_dirty = lds_dirty_all[wave], *lds_ran = lds_ran_all[wave];
+  uint16_t *lds_act = lds_act_all[wave];
   // lane l describes subsequences l, l+64, l+128, l+192 of the group
   uint32_t g[4], sidx[4];
   bool on[4], any = false;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
-    const uint32_t t = (uint32_t)q*64u + lane, li = blockIdx.x*HJ_BLOCK + t;
+    const uint32_t t = (uint32_t)q*64u + lane, li = group*HJ_BLOCK + t;
     on[q] = li < im.nsub;
     g[q] = 0; sidx[q] = 0;
     uint64_t st = 0;
-    uint32_t start = 0, stop = 0;
     bool dirty = false;
     if (on[q]) {
       g[q] = im.sub0 + li;
-      const uint32_t si = A.sub_seg[g[q]];
-      const hj_segment sg = A.segs[im.seg0 + si];
-      const uint32_t i = li - sg.sub0;
-      sidx[q] = g[q] + im.seg0 + si;
+      sidx[q] = g[q] + im.seg0 + A.sub_seg[g[q]];
       st = A.S[sidx[q]];
       dirty = st != A.last_in[g[q]];
-      start = sg.start + (i << A.sub_log2);
-      stop = start + (1u << A.sub_log2);
-      if (stop > sg.end) stop = sg.end;
-      if (i + 1 < sg.nsub) stop |= 0x80000000u;
     }
     lds_S[t] = st;
     lds_dirty[t] = dirty;
     lds_ran[t] = 0;
-    lds_start[t] = start;
-    lds_stop[t] = stop;
-    if (t == HJ_BLOCK - 1) lds_sidx_last = sidx[q];
     any = any || dirty;
   }
-  if (!__syncthreads_or(any)) return;
+  const uint32_t sidx_last = (uint32_t)__shfl((int)sidx[3], 63);   // entry of the group's last subsequence
+  if (!__syncthreads_or(any)) return;            // nothing moved in any of the four groups
   hj_stage_image(&s_im, A.images + blockIdx.y);
   {
     const uint4 *tsrc = reinterpret_cast<const uint4 *>(A.tables + blockIdx.y);
     uint4 *tdst = reinterpret_cast<uint4 *>(&lds_tabs);
-    for (int k = (int)lane; k < (int)(sizeof(hj_tables)/16); k += 64) tdst[k] = tsrc[k];
+    for (int k = (int)threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += 64*NG) tdst[k] = tsrc[k];
   }
   __syncthreads();
+  // from here on every wave is on its own: no workgroup barriers
+  if (__ballot(any) == 0ull) return;
   const uint8_t *scan = A.scan + im.scan_off;
   const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;
   for (int it = 0; it < max_iters; it++) {
@@ -370,34 +362,39 @@ __global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round,
       total += (uint32_t)__popcll(m);
     }
     if (total == 0) break;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < total; c0 += HJ_POOL) {
-      const uint32_t nact = total - c0 < HJ_POOL ? total - c0 : HJ_POOL;
+    hj_wave_sync();
+    for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+      const uint32_t nact = total - c0 < 64u ? total - c0 : 64u;
       if (lane < nact) {
         const uint32_t sub = lds_act[c0 + lane];
         const uint64_t start = lds_S[sub];
-        const uint32_t sb = lds_stop[sub];
+        // where the subsequence lies (only the lanes that run look this up)
+        const uint32_t li = group*HJ_BLOCK + sub, gg = im.sub0 + li;
+        const hj_segment sg = A.segs[im.seg0 + A.sub_seg[gg]];
+        const uint32_t i = li - sg.sub0;
+        const uint32_t first = sg.start + (i << A.sub_log2);
+        uint32_t stop = first + (1u << A.sub_log2);
+        if (stop > sg.end) stop = sg.end;
         hj_gmem_src src;
         {
-          const uint32_t a = lds_start[sub] & ~3u;
+          const uint32_t a = first & ~3u;
           src.row = scan + a;
           src.bit0 = a << 3;
           src.ndw = (padded - a) >> 2;
         }
-        const hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)(sb & 0x7fffffffu)*8);
-        hj_run16 r16;
-        r16.nblocks = (uint16_t)r.nblocks;
-        r16.dcsum[0] = r.dcsum[0]; r16.dcsum[1] = r.dcsum[1]; r16.dcsum[2] = r.dcsum[2];
-        lds_R[sub] = r16;
+        hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)stop*8);
+        const uint64_t end_state = r.end_state;
+        r.end_state = 0; r.error = 0;
+        A.R[gg] = r;                             // (a later run of the same subsequence overwrites it)
         lds_ran[sub] = 1;
-        if (sb & 0x80000000u) {
+        if (i + 1 < sg.nsub) {
           if (sub + 1 < HJ_BLOCK) {
-            if (lds_S[sub + 1] != r.end_state) { lds_S[sub + 1] = r.end_state; lds_dirty[sub + 1] = 1; }
+            if (lds_S[sub + 1] != end_state) { lds_S[sub + 1] = end_state; lds_dirty[sub + 1] = 1; }
           }
-          else A.S[lds_sidx_last + 1] = r.end_state;       // first subsequence of the next group
+          else A.S[sidx_last + 1] = end_state;   // first subsequence of the next group
         }
       }
-      __syncthreads();
+      hj_wave_sync();
     }
   }
   // publish (as hj_sync_round)
@@ -409,16 +406,11 @@ __global__ __launch_bounds__(64) void hj_sync_sparse(const hj_args A, int round,
     const uint64_t st = lds_S[t];
     if (t > 0 && st != A.S[sidx[q]]) A.S[sidx[q]] = st;
     if (lds_ran[t]) {
-      const hj_run16 r16 = lds_R[t];
-      hj_run r;
-      r.end_state = 0; r.nblocks = r16.nblocks; r.error = 0;
-      r.dcsum[0] = r16.dcsum[0]; r.dcsum[1] = r16.dcsum[1]; r.dcsum[2] = r16.dcsum[2];
-      A.R[g[q]] = r;
       A.last_in[g[q]] = lds_dirty[t] ? ~0ull : st;
       ran_any = true;
     }
   }
-  if (__syncthreads_or(ran_any) && lane == 0) atomicOr(&A.ran[round], 1u);
+  if (__ballot(ran_any) != 0ull && lane == 0) atomicOr(&A.ran[round], 1u);
 }
 
 #define HJ_SCAN_BLOCK 1024          /* threads per chunk */
@@ -677,7 +669,10 @@ __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(c
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,
  void *stream) {
   dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
-  if (sparse) hipLaunchKernelGGL(hj_sync_sparse, grid, dim3(64), 0, (hipStream_t)stream, *A, round, max_iters);
+  if (sparse) {
+    const dim3 sgrid((grid.x + HJ_SPARSE_GROUPS - 1)/HJ_SPARSE_GROUPS, grid.y);
+    hipLaunchKernelGGL(hj_sync_sparse, sgrid, dim3(64*HJ_SPARSE_GROUPS), 0, (hipStream_t)stream, *A, round, max_iters);
+  }
   else hipLaunchKernelGGL(hj_sync_round, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters);
   return (int)hipGetLastError();
 }
