@@ -411,7 +411,7 @@ uint64_t geometry_key(const unsigned char *p, int size) {
       uint64_t k = ((uint64_t)((f[1] << 8) | f[2]) << 48) | ((uint64_t)((f[3] << 8) | f[4]) << 32)
        | ((uint64_t)f[5] << 24);
       for (int c = 0; c < f[5] && c < 3 && 8 + 3*c < len - 2; c++) k |= (uint64_t)f[7 + 3*c] << (8*c);
-      return k | 1ull << 63;
+      return k | 1ull << 31;                        // (never 0; Nf only needs bits 24..26)
     }
     if (m == 0xDA || m == 0xD9) return 0;
     i += 2 + len;
@@ -504,7 +504,12 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
           else { groups.back().push_back(&jobs[i]); continue; }      // unparsable: fails on its own
         }
         groups[it->second].push_back(&jobs[i]);
-        if ((int)groups[it->second].size() >= batch) open.erase(it);
+        // `batch` counts 4K frames; smaller frames fill a group to about the same number of
+        // pixels (a launch takes at least one run's latency however little it decodes)
+        const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
+        long long scale = px > 0 ? (3840ll*2160 + px/2)/px : 1;
+        scale = scale < 1 ? 1 : scale > 16 ? 16 : scale;
+        if ((long long)groups[it->second].size() >= batch*scale) open.erase(it);
       }
     }
     for (int t = 0; t < nl; t++) {
