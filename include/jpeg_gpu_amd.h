@@ -353,6 +353,9 @@ int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  void *stream);
 long long jga_huff_upload_bytes(const jga_huff_batch *b);
 int jga_huff_last_rounds(const jga_huff_batch *b);
+/* Subsequences the HOST walked in the last decode because the stream did not fall into step
+ * on its own (periodic data: flat areas, letterbox bars); 0 for ordinary photographs. */
+int jga_huff_last_assisted(const jga_huff_batch *b);
 const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);

@@ -36,6 +36,9 @@ struct jga_huff_batch {
   uint32_t *d_part;            // chunk totals of the prefix-sum pass
   int sub_log2, force_sub_log2;  // subsequence length of the current batch / JGA_HUFF_SUB
   uint32_t *h_ran;             // pinned readback
+  uint64_t *h_states;          // pinned, lazily: S and last_in read back for assist_chains()
+  size_t h_states_cap;         // entries
+  int last_assisted;           // subsequences the host walked in the last decode
   hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
   size_t sub_cap;
@@ -93,6 +96,7 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (!b) return;
   if (b->h_blob) (void)hipHostFree(b->h_blob);
   if (b->h_ran) (void)hipHostFree(b->h_ran);
+  if (b->h_states) (void)hipHostFree(b->h_states);
   if (b->d_blob) (void)hipFree(b->d_blob);
   if (b->d_last_in) (void)hipFree(b->d_last_in);
   if (b->d_R) (void)hipFree(b->d_R);
@@ -317,11 +321,78 @@ JGA_EXPORT void jga_huff_set_threads(jga_huff_batch *b, int nthreads) { b->prepa
 // Bytes uploaded by the last prepare() (tables + states + compressed scan data).
 JGA_EXPORT long long jga_huff_upload_bytes(const jga_huff_batch *b) { return (long long)b->blob_size; }
 JGA_EXPORT int jga_huff_last_rounds(const jga_huff_batch *b) { return b->last_rounds; }
+JGA_EXPORT int jga_huff_last_assisted(const jga_huff_batch *b) { return b->last_assisted; }
 // Quantisation tables of the prepared batch: nimages*3*64 uint16 (host memory).
 JGA_EXPORT const unsigned short *jga_huff_qtabs(const jga_huff_batch *b) { return b->qtab.data(); }
 
 // Decode the prepared batch into d_coef (image i at d_coef + i*coef_stride shorts).
 // May be called repeatedly on the same prepared batch (state is reset each time).
+// Streams that do not self-synchronise.  Periodic data — flat areas, letterbox bars: blocks
+// of "DC difference 0, EOB" — can be parsed out of step for ever, so the true states only
+// travel down such a stretch one subsequence per run, at the speed of ONE lane (128 bytes in
+// ~50 us: a 36 KB bar would take 14 ms, a flat 4K frame hundreds of rounds).  When the rounds
+// have not settled after JGA_HUFF_ASSIST_AFTER of them (default 12; a photograph needs 4-6),
+// the host walks those stretches itself: it reads the states back, and in every segment starts
+// at each lane whose start state moved since its last run (the first such lane's state is
+// true by induction from the segment start), decodes on with the same hj_sync_decode the
+// kernels run (~100x a lane's speed) and writes the state at every subsequence boundary, until
+// it arrives in a state from which the next lane has already run.  The corrected states go
+// back up; one more round re-runs all those lanes at once, from true states.
+static int assist_chains(jga_huff_batch *b, hipStream_t st) {
+  const size_t ns = (size_t)b->total_sub + b->total_seg, nl = b->total_sub;
+  if (b->h_states_cap < ns + nl) {
+    if (b->h_states) (void)hipHostFree(b->h_states);
+    b->h_states = NULL; b->h_states_cap = 0;
+    HOK(hipHostMalloc((void **)&b->h_states, 8*(ns + nl), hipHostMallocDefault));
+    b->h_states_cap = ns + nl;
+  }
+  uint64_t *S = b->h_states, *last_in = b->h_states + ns;
+  HOK(hipMemcpyAsync(S, b->d_blob + b->off_S, 8*ns, hipMemcpyDeviceToHost, st));
+  HOK(hipMemcpyAsync(last_in, b->d_last_in, 8*nl, hipMemcpyDeviceToHost, st));
+  HOK(hipStreamSynchronize(st));
+  const hj_image *images = (const hj_image *)(b->h_blob + b->off_images);
+  const hj_segment *segs = (const hj_segment *)(b->h_blob + b->off_segs);
+  const hj_tables *tables = (const hj_tables *)(b->h_blob + b->off_tables);
+  std::atomic<int> next(0), walked(0);
+  auto work = [&]() {
+    for (int i = next.fetch_add(1); i < b->nimages; i = next.fetch_add(1)) {
+      const hj_image &im = images[i];
+      hj_mem_src src;
+      src.s = b->h_blob + b->off_scan + im.scan_off;
+      for (uint32_t si = 0; si < im.nseg; si++) {
+        const hj_segment &sg = segs[im.seg0 + si];
+        uint64_t *Ss = S + im.sub0 + im.seg0 + sg.sub0 + si;       // nsub + 1 entries
+        const uint64_t *Ls = last_in + im.sub0 + sg.sub0;
+        for (uint32_t k = 0; k < sg.nsub; k++) {
+          if (Ss[k] == Ls[k]) continue;                            // ran from its current state
+          for (;;) {                                               // walk on from lane k
+            uint32_t stop = sg.start + ((k + 1) << b->sub_log2);
+            if (stop > sg.end) stop = sg.end;
+            const hj_run r = hj_sync_decode(src, im, &tables[i], Ss[k], (uint64_t)stop*8);
+            walked.fetch_add(1, std::memory_order_relaxed);
+            if (k + 1 >= sg.nsub) break;
+            k++;
+            if (Ss[k] == r.end_state && Ls[k] == r.end_state) break;   // that lane ran from here
+            Ss[k] = r.end_state;
+            if (Ls[k] == r.end_state) break;                       // (its output stands as well)
+          }
+        }
+      }
+    }
+  };
+  {
+    int nt = b->prepare_threads > 0 ? b->prepare_threads : 8;
+    if (nt > b->nimages) nt = b->nimages;
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+  }
+  b->last_assisted += walked.load();
+  HOK(hipMemcpyAsync(b->d_blob + b->off_S, S, 8*ns, hipMemcpyHostToDevice, st));
+  return EXIT_SUCCESS;
+}
+
 JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  void *stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -358,7 +429,8 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
   HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
-  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16, sparse_from = 1, write_gmem = 1;
+  b->last_assisted = 0;
+  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16, sparse_from = 1, write_gmem = 1, assist_after = 12;
   if (it0 < 0) {
     const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group" (tuning knob)
     it0 = 3; it1 = 3; group = 6;
@@ -367,6 +439,8 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
     if (e) write_gmem = atoi(e) != 0;
     e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (tuning knob)
     if (e) sparse_from = atoi(e);
+    e = getenv("JGA_HUFF_ASSIST_AFTER");             // rounds before the host walks the unsettled stretches
+    if (e) assist_after = atoi(e) > 0 ? atoi(e) : 1;
     e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching (tuning knob)
     if (e) flush_lanes = atoi(e);
     if (flush_lanes < 1) flush_lanes = 1;
@@ -384,6 +458,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
     HOK(hipStreamSynchronize(st));
     if (b->h_ran[round - 1] == 0) break;                   // a round in which nothing moved
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
+    if (round >= assist_after && assist_chains(b, st) != EXIT_SUCCESS) return EXIT_FAILURE;
   }
   b->last_rounds = 0;
   while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;

@@ -22,7 +22,7 @@ EXPORTED = [
     "jga_stream_sync", "jga_set_device", "jga_stream_create", "jga_stream_destroy",
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
-    "jga_huff_decode", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_qtabs",
+    "jga_huff_decode", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_qtabs",
     "jga_huff_set_threads",
 ]
 
@@ -103,6 +103,7 @@ L.jga_huff_decode.argtypes = [_vp, _vp, _ll, _vp]
 L.jga_huff_upload_bytes.argtypes = [_vp]
 L.jga_huff_upload_bytes.restype = _ll
 L.jga_huff_last_rounds.argtypes = [_vp]
+L.jga_huff_last_assisted.argtypes = [_vp]
 L.jga_huff_set_threads.argtypes = [_vp, _i]
 L.jga_huff_set_threads.restype = None
 L.jga_huff_qtabs.argtypes = [_vp]
@@ -393,6 +394,9 @@ class HuffBatch:
         check(L.jga_huff_decode(self.ptr, d_coef_ptr, coef_stride, stream))
         return L.jga_huff_last_rounds(self.ptr)
 
+    def assisted(self):
+        return L.jga_huff_last_assisted(self.ptr)
+
     def upload_bytes(self):
         return L.jga_huff_upload_bytes(self.ptr)
 
@@ -452,6 +456,7 @@ def gpu_entropy_decode(jpegs):
         d = DeviceBuffer(stride * 2 * len(jpegs))
         try:
             rounds = hb.decode(d.ptr, stride)
+            gpu_entropy_decode.assisted = hb.assisted()          # (for tests: host-walked subsequences)
             raw = d.download(dtype=np.int16).reshape(len(jpegs), stride)
             return g, raw[:, :g.coef_shorts].copy(), rounds
         finally:

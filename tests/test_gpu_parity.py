@@ -385,6 +385,70 @@ def test_gpu_huffman_equals_host_entropy_stage(gpu, synth, sampling, ri):
         assert np.array_equal(c, gpu.entropy_decode(d, g)), (sampling, ri)
 
 
+def _letterboxed(gpu, synth, w, h, sampling, seed):
+    """A synthetic photograph whose top and bottom quarters are flat (all levels zero)."""
+    data = synth.synthetic_jpeg(w, h, sampling, quality=90, seed=seed)
+    hdr, g = gpu.geom_of(data)
+    lv = gpu.entropy_decode(data, g).copy()
+    for p in range(g.nplanes):
+        pl = g.plane[p]
+        plane = lv[pl.coef_off:pl.coef_off + pl.hblocks * pl.vblocks * 64].reshape(-1, pl.hblocks * 64)
+        rows = plane.shape[0]
+        plane[:rows // 4] = 0
+        plane[rows - rows // 4:] = 0
+    return synth.encode_levels(lv, w, h, sampling, qtab=gpu.qtab_of(hdr))
+
+
+@pytest.mark.parametrize("sampling", ["420", "444", "grey"])
+def test_gpu_huffman_periodic_streams_that_never_fall_into_step(gpu, synth, sampling):
+    """Flat data parses out of step for ever (no self-synchronisation): the rounds alone would
+    need one run per subsequence; the host walks those stretches (huff_api.cpp assist_chains)
+    and the result is still the host entropy stage's."""
+    w, h = 1920, 1080
+    n = synth.coef_shorts(w, h, sampling)
+    cases = {}
+    lv = np.zeros(n, np.int16)
+    cases["zero"] = lv.copy()
+    lv.reshape(-1, 64)[:, 0] = 5
+    lv.reshape(-1, 64)[::2, 0] = -5
+    cases["alternating dc"] = lv.copy()
+    lv = np.zeros(n, np.int16)
+    lv.reshape(-1, 64)[:, 63] = 1
+    cases["zrl zrl zrl + last ac"] = lv
+    assisted = 0
+    for name, lv in cases.items():
+        data = synth.encode_levels(lv, w, h, sampling)
+        g, coefs, rounds = gpu.gpu_entropy_decode([data])
+        assert np.array_equal(coefs[0], gpu.entropy_decode(data, g)), (sampling, name)
+        assisted += gpu.gpu_entropy_decode.assisted
+    assert assisted > 0                      # at least one of them needed the host's walk
+    # an ordinary photograph never does
+    data = synth.synthetic_jpeg(w, h, sampling, quality=90, seed=3)
+    g, coefs, rounds = gpu.gpu_entropy_decode([data])
+    assert np.array_equal(coefs[0], gpu.entropy_decode(data, g))
+    assert gpu.gpu_entropy_decode.assisted == 0 and rounds <= 8
+
+
+def test_gpu_huffman_letterboxed_frames_in_a_batch_and_through_the_pipeline(gpu, orc, synth):
+    """Photographs with flat bars (video frames): mixed in one batch with ordinary ones."""
+    from jpeg_gpu_amd import abi
+    datas = [_letterboxed(gpu, synth, 1280, 720, "420", seed=s) for s in (1, 2)]
+    datas.insert(1, synth.synthetic_jpeg(1280, 720, "420", quality=90, seed=9))
+    g, coefs, rounds = gpu.gpu_entropy_decode(datas)
+    for d, c in zip(datas, coefs):
+        assert np.array_equal(c, gpu.entropy_decode(d, g))
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2,
+                      batch=4, depth=2)
+    try:
+        outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in datas]
+        rc, _ = pl.run(datas, host_outs=outs)
+        assert rc == 0
+        for d, o in zip(datas, outs):
+            assert np.array_equal(o, orc.decode_rgb(d)[1].ravel())
+    finally:
+        pl.close()
+
+
 def test_gpu_huffman_golden_jpegs(gpu, golden_jpegs):
     """Pillow-made files (optimised tables, DRI) + ours, against the reference's QUANT planes."""
     for name in golden_jpegs.names:
