@@ -305,16 +305,16 @@ def main():
         for copy_back, transport in ((False, 0), (True, 0), (False, 1), (False, 2), (True, 2)):
             nt = max(1, min(os.cpu_count() or 1, 96)) if transport == 2 else nthr
             pl = lib.Pipeline(device=local_rank, nthreads=nt, out=abi.JPEG_DECODE_RGB,
-                              copy_back=copy_back, transport=transport, batch=24, depth=6)
+                              copy_back=copy_back, transport=transport, batch=48, depth=6)
             # enough images for every worker to reach steady state (its two slots allocated in the
             # warm-up, then several images each); the fast path needs more to ramp
-            n = args.e2e_images*12 if transport == 2 else max(args.e2e_images, 4*nthr)
+            n = args.e2e_images*24 if transport == 2 else max(args.e2e_images, 4*nthr)
             if copy_back:
                 n = min(n, 288)                   # 25 MB of host pixels per image
             jobs = [jpegs[i % len(jpegs)] for i in range(n)]
             # the caller's pixel buffers exist before the clock starts (zeros: pages touched)
             outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
-            nw = 144 if transport == 2 else 2*nthr                     # warm: slots/lanes, pages
+            nw = 288 if transport == 2 else 2*nthr                     # warm: slots/lanes, pages
             pl.run(jobs[:nw], host_outs=outs[:nw] if outs else None)
             t0 = time.perf_counter()
             rc, done = pl.run(jobs, host_outs=outs)
@@ -329,7 +329,7 @@ def main():
         e2e["host_threads"] = nthr
         e2e["note"] = "JPEG bytes in host RAM -> RGB; PCIe- and host-inclusive, not `value`. " \
                       "Default/pack transports: host Huffman threads + pinned hipMemcpyAsync + " \
-                      "fused kernel; gpu_entropy: host only unstuffs, 6 lanes x 24 images, 3 with kernels queued at a time"
+                      "fused kernel; gpu_entropy: host only unstuffs, 6 lanes x 48 images, 3 with kernels queued at a time"
         out["e2e"] = e2e
 
     if rank == 0 and world == 1 and not args.no_pack:

@@ -316,7 +316,7 @@ typedef struct jga_pipeline_config {
                                 * 1 = PACK words + block index, expanded by jga_unpack_batch,
                                 * 2 = the entropy-coded bytes: no host Huffman, jga_huff_* on
                                 *     the GPU (depth = lanes in flight, default 6) */
-  int batch;                   /* transport 2: 4K frames per GPU entropy batch (0 = 24); smaller
+  int batch;                   /* transport 2: 4K frames per GPU entropy batch (0 = 48); smaller
                                 * frames fill a group to about the same pixel count (up to 16x
                                 * as many); jobs are grouped by geometry in arrival order */
 } jga_pipeline_config;

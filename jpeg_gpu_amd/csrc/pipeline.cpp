@@ -486,7 +486,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
   int failed = 0;
   for (int i = 0; i < n; i++) jobs[i].status = EXIT_FAILURE;
   if (pl->cfg.transport == 2) {
-    const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 24;
+    const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 48;
     const int nl = (int)pl->lanes.size();
     int per = pl->cfg.nthreads/nl;
     if (per < 1) per = 1;
