@@ -110,6 +110,22 @@ def cpu_baseline(jpegs, seconds):
                   "(oracle.orc_decode_rgb, %.1f s)" % (done, W, H, threads, dt),
         "single_core_value": round(W * H / t1 / 1e6, 1),
     }
+    # libjpeg-turbo where the box has it (Pillow's bundled copy): a sanity line, not the oracle —
+    # its integer IDCT differs from src/dct.c by +-1 on ~2 % of samples
+    try:
+        import io
+        from PIL import Image, features
+        best = 1e9
+        for _ in range(5):
+            t0 = time.perf_counter()
+            Image.open(io.BytesIO(jpegs[0])).convert("RGB").load()
+            best = min(best, time.perf_counter() - t0)
+        res["libjpeg_turbo_single_core"] = {
+            "value": round(W * H / best / 1e6, 1), "unit": "Mpixel/s",
+            "note": "Pillow %s (libjpeg-turbo %s), full RGB decode, best of 5" % (
+                Image.__version__, features.version("libjpeg_turbo") or "?")}
+    except Exception as e:  # not importable on this box
+        res["libjpeg_turbo_single_core"] = {"value": None, "note": "not available (%s)" % type(e).__name__}
     if oracle.Reference.available():
         ref = oracle.Reference()
         t0 = time.perf_counter()
