@@ -263,6 +263,22 @@ def main():
         },
     }
 
+    if rank == 0:
+        # what a plain device-to-device copy of the same volume reaches on this box (SURVEY.md
+        # 8d: "state the measured copy ceiling next to the spec"): bytes read + bytes written
+        src = torch.empty(alg_bytes // 2, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        out["roofline"]["device_copy_GBps"] = round(2 * src.numel() * 10 / e0.elapsed_time(e1) / 1e6, 1)
+        del src, dst
+
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_seconds)
 
