@@ -188,7 +188,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
   typename hj_reader_of<Src>::type br;
   hj_run r;
   int k = hj_k(start), c = hj_slot(start);
-  int dc0 = 0, dc1 = 0, dc2 = 0;
+  int dcall = 0, dc1 = 0, dc2 = 0;                         // component 0's sum = all - 1 - 2
   uint32_t nblocks = 0;
   br.init(src, hj_pos(start), stop_bit);
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
@@ -200,7 +200,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
     br.skip(len + s);
     if (isdc) {                                            // DC difference, extended
       const int v = hj_value(w, len, s);
-      dc0 += comp == 0 ? v : 0;
+      dcall += v;
       dc1 += comp == 1 ? v : 0;
       dc2 += comp == 2 ? v : 0;
     }
@@ -213,7 +213,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
   }
   r.nblocks = nblocks;
   r.error = 0;
-  r.dcsum[0] = (int16_t)dc0; r.dcsum[1] = (int16_t)dc1; r.dcsum[2] = (int16_t)dc2;
+  r.dcsum[0] = (int16_t)(dcall - dc1 - dc2); r.dcsum[1] = (int16_t)dc1; r.dcsum[2] = (int16_t)dc2;
   r.end_state = hj_pack(br.tell(), c, k);
   return r;
 }

@@ -71,27 +71,27 @@ struct hj_lds_src {
 // dword — about every fifth symbol.  No LDS copy of the scan, so the write pass's LDS budget
 // goes to the block buffers alone and more workgroups fit a CU.
 struct hj_gmem_src {
-  const uint8_t *row;                // address of the dword holding the subsequence's first byte
-  uint32_t bit0;                     // clean-scan bit position of that dword
-  uint32_t ndw;                      // dwords readable from `row` on
+  const uint32_t *scan32;            // the image's clean scan as dwords (wave-uniform address)
+  uint32_t dw0;                      // dword holding the subsequence's first byte
+  uint32_t ndw;                      // dwords readable from scan32 on (scan + its 16 pad bytes)
   typedef void has_reader;
   struct reader {
-    const uint32_t *base;
-    uint32_t bit0, ndw;
-    int32_t r1, stop1, d;
+    const uint32_t *scan32;
+    uint32_t dw0, bit0;
+    int32_t r1, stop1, d;            // positions relative to bit0 = 32*dw0, minus one (as hj_lds_src)
     uint32_t w0, w1, w2raw;            // w2raw: the dword after w1 as loaded (not yet byte-swapped)
     // The dword two ahead is requested at a crossing and first TOUCHED at the next one (the
     // byte swap waits for the load): a run never stalls on the load it has just issued.
-    __device__ __forceinline__ uint32_t fetch_raw(int32_t i) const {
-      const int32_t k = i < 0 ? 0 : ((uint32_t)i < ndw ? i : (int32_t)ndw - 1);
-      return base[k];
-    }
     __device__ __forceinline__ void init(const hj_gmem_src &src, uint64_t pos, uint64_t stop_bit) {
-      base = reinterpret_cast<const uint32_t *>(src.row); bit0 = src.bit0; ndw = src.ndw;
+      scan32 = src.scan32; dw0 = src.dw0; bit0 = src.dw0 << 5;
       r1 = (int32_t)((uint32_t)pos - bit0) - 1;
       stop1 = (int32_t)((uint32_t)stop_bit - bit0) - 1;
       d = r1 >> 5;
-      w0 = __builtin_bswap32(fetch_raw(d)); w1 = __builtin_bswap32(fetch_raw(d + 1)); w2raw = fetch_raw(d + 2);
+      const uint32_t last = src.ndw - 1u;
+      const uint32_t i0 = d < 0 ? dw0 : dw0 + (uint32_t)d;         // (the dword before bit 0 is never looked at)
+      w0 = __builtin_bswap32(scan32[i0 < last ? i0 : last]);
+      w1 = __builtin_bswap32(scan32[dw0 + (uint32_t)(d + 1) < last ? dw0 + (uint32_t)(d + 1) : last]);
+      w2raw = scan32[dw0 + (uint32_t)(d + 2) < last ? dw0 + (uint32_t)(d + 2) : last];
     }
     __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
     __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w0, w1, ~(uint32_t)r1); }
@@ -100,7 +100,9 @@ struct hj_gmem_src {
       const int32_t nd = r1 >> 5;
       if (nd != d) {                 // a symbol is at most 31 bits: one dword further at most
         d = nd; w0 = w1; w1 = __builtin_bswap32(w2raw);
-        w2raw = fetch_raw(d + 2);
+        // no clamp: a run stops within 31 bits of its subsequence's end, and 16 pad bytes
+        // follow every image's scan in the batch buffer
+        w2raw = scan32[dw0 + (uint32_t)(d + 2)];
       }
     }
     __device__ __forceinline__ uint64_t tell() const { return (uint64_t)((uint32_t)(r1 + 1) + bit0); }
@@ -377,10 +379,9 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
         if (stop > sg.end) stop = sg.end;
         hj_gmem_src src;
         {
-          const uint32_t a = first & ~3u;
-          src.row = scan + a;
-          src.bit0 = a << 3;
-          src.ndw = (padded - a) >> 2;
+          src.scan32 = reinterpret_cast<const uint32_t *>(scan);
+          src.dw0 = first >> 2;
+          src.ndw = padded >> 2;
         }
         hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)stop*8);
         const uint64_t end_state = r.end_state;
@@ -632,10 +633,9 @@ __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(c
   hj_lds_src src = hj_source(lds_win, lds_start, threadIdx.x, hj_sub_dwords(A));
   hj_gmem_src gsrc;
   {
-    const uint32_t a = lds_start[threadIdx.x] & ~3u;
-    gsrc.row = A.scan + im0.scan_off + a;
-    gsrc.bit0 = a << 3;
-    gsrc.ndw = (((im0.scan_len + 16 + 15) & ~15u) - a) >> 2;
+    gsrc.scan32 = reinterpret_cast<const uint32_t *>(A.scan + im0.scan_off);
+    gsrc.dw0 = lds_start[threadIdx.x] >> 2;
+    gsrc.ndw = ((im0.scan_len + 16 + 15) & ~15u) >> 2;
   }
   __syncthreads();
   uint32_t *blk = lds_blk + threadIdx.x*HJ_BLK_STRIDE;
