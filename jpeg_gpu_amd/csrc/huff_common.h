@@ -234,6 +234,9 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
 // that enough lanes are waiting, and then all of them write together — the write-out
 // code runs once per several symbols instead of once per symbol.
 // DC values are integrated from `pred` (predictors at the start of the run).
+#ifndef HJ_WRITE_UNROLL
+#define HJ_WRITE_UNROLL 2
+#endif
 template <class Src, class Out>
 HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T,
  const uint8_t *dezz, uint64_t start, uint64_t stop_bit, uint32_t max_blocks,
@@ -248,9 +251,14 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
   br.init(src, hj_pos(start), stop_bit);
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
   for (;;) {
-    const bool running = !waiting && br.before_stop() && n < max_blocks;
+    bool running = !waiting && br.before_stop() && n < max_blocks;
     if (!out.any(running || waiting)) break;
-    if (running) {
+    // HJ_WRITE_UNROLL symbols between two looks at the write-out condition: the loop control
+    // and the wave votes are as many instructions as a symbol's decode
+#pragma unroll
+    for (int u = 0; u < HJ_WRITE_UNROLL; u++) {
+      if (u) running = !waiting && br.before_stop() && n < max_blocks;
+      if (!running) continue;
       const uint32_t w = br.window();
       const int isdc = k == 0;
       const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
