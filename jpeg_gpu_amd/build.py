@@ -68,7 +68,19 @@ def check_no_fma(asm_path):
 
 
 def build(force=False, verbose=False):
+    """Compile what is out of date.  Safe to call from several processes at once (one rank per
+    GPU calls it): an exclusive file lock serialises them, the others find everything built."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     headers = [os.path.join(CSRC, h) for h in ("jga_internal.h", "kernel_params.h", "huff_common.h",
                                                "huff_kernels.h", "huff_prepare.h", "pack_params.h")]
     headers.append(os.path.join(HERE, "..", "include", "jpeg_gpu_amd.h"))

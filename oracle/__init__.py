@@ -57,8 +57,14 @@ class Info(C.Structure):
 
 def build(quiet=True):
     """(Re)build liboracle.so and, when /root/reference exists, _ref/."""
-    subprocess.run(["make", "-C", _HERE] + (["-s"] if quiet else []), check=True,
-                   stdout=subprocess.DEVNULL if quiet else None)
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:     # one rank per GPU may call this
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.run(["make", "-C", _HERE] + (["-s"] if quiet else []), check=True,
+                           stdout=subprocess.DEVNULL if quiet else None)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def _u8p(a):
