@@ -230,13 +230,14 @@ def main():
     value = rate / 1e6
     alg_bytes = B * (g.coef_blocks * 128 + g.rgb_bytes)
     achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, valu = None, {}
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
             if pmc.get("batch") == B and pmc.get("workload") == "%dx%d %s" % (W, H, SAMPLING):
                 traffic = pmc.get("hbm_bytes_per_launch")
+                valu = {k: pmc[k] for k in ("valu_insts_per_wave", "valu_busy_4clk") if k in pmc}
         except Exception:
             traffic = None
     out = {
@@ -260,6 +261,9 @@ def main():
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms_per_launch": round(ev_ms, 4),
+            # the other roof, from the same PMC passes as `traffic` (profiles/): the kernel is
+            # co-limited by vector-ALU issue
+            **({"valu": dict(valu, source="profiles/pmc_latest.json")} if valu else {}),
         },
     }
 

@@ -67,8 +67,19 @@ if avg_ns:
 open(os.path.join(dst, "%s_rocprof_summary.md" % tag), "w").write("\n".join(out) + "\n")
 json.dump(bench, open(os.path.join(dst, "%s_bench.json" % tag), "w"), indent=1)
 if traffic:
-    json.dump({"workload": "3840x2160 420", "batch": batch, "hbm_bytes_per_launch": int(traffic),
-               "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
-               "source": "profiles/%s_rocprof_summary.md" % tag},
-              open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+    latest = {"workload": "3840x2160 420", "batch": batch, "hbm_bytes_per_launch": int(traffic),
+              "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
+              "source": "profiles/%s_rocprof_summary.md" % tag}
+    if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c and "SQ_WAVES" in c:
+        # vector-ALU side of the same launch: wave instructions, and the busy fraction by the
+        # 4-cycles-per-wave64-instruction convention (1024 SIMDs; GRBM_GUI_ACTIVE sums 8 XCDs)
+        latest["valu_insts_per_launch"] = int(c["SQ_INSTS_VALU"])
+        latest["valu_insts_per_wave"] = round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1)
+        latest["valu_busy_4clk"] = round(c.get("SQ_ACTIVE_INST_VALU", c["SQ_INSTS_VALU"]) * 4
+                                         / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
+        out.append("VALU: %d wave-instructions per launch (%.0f per wave); busy %.2f of the SIMD cycles at "
+                   "4 clk per instruction" % (latest["valu_insts_per_launch"], latest["valu_insts_per_wave"],
+                                             latest["valu_busy_4clk"]))
+    json.dump(latest, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+open(os.path.join(dst, "%s_rocprof_summary.md" % tag), "w").write("\n".join(out) + "\n")
 print("\n".join(out))
