@@ -39,3 +39,22 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_graft_entry_smoke_runs(gpu):
+    """__graft_entry__.smoke(): one small decode on cuda:0 checked against the oracle."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()
+    __graft_entry__.smoke()
+
+
+def test_graft_entry_build_is_idempotent():
+    """build() with everything already built returns quickly and leaves the library loadable."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__
+    __graft_entry__.build()
+    __graft_entry__.build()
+    assert os.path.exists(os.path.join(ROOT, "jpeg_gpu_amd", "libjpeg_gpu_amd.so"))
+    assert os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))
