@@ -420,6 +420,15 @@ def block_slots(g):
     return out
 
 
+def real_coef_mask(g):
+    """(coef_shorts,) bool: positions of the coefficient buffer that belong to a real block (the
+    packed layout has holes between plane rows)."""
+    real = np.zeros(g.coef_shorts, bool)
+    for _, off in block_slots(g):
+        real[off[:, None] + np.arange(64)] = True
+    return real
+
+
 def gpu_unpack(g, packs, indexes, pack_words=None):
     """jga_unpack_batch on same-geometry images -> (n, coef_shorts) int16 (unwritten slots 0)."""
     n = len(packs)
@@ -455,10 +464,15 @@ def gpu_entropy_decode(jpegs):
         stride = _align(g.coef_shorts * 2) // 2
         d = DeviceBuffer(stride * 2 * len(jpegs))
         try:
+            # poison the planes: every coefficient of every real block must be WRITTEN by the
+            # decode (it clears nothing but the blocks it assembles from pieces)
+            d.upload(np.full(stride * len(jpegs), 0x5A5A, np.int16))
             rounds = hb.decode(d.ptr, stride)
             gpu_entropy_decode.assisted = hb.assisted()          # (for tests: host-walked subsequences)
             raw = d.download(dtype=np.int16).reshape(len(jpegs), stride)
-            return g, raw[:, :g.coef_shorts].copy(), rounds
+            out = raw[:, :g.coef_shorts].copy()
+            out[:, ~real_coef_mask(g)] = 0                        # layout holes: no block lives there
+            return g, out, rounds
         finally:
             d.free()
     finally:

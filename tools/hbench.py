@@ -47,4 +47,5 @@ for rep in range(3):
               mp / t_h, t_i * 1e3, mp / (t_h + t_i)))
 want = lib.entropy_decode(jpegs[0], g)
 got = d_coef.download(g.coef_shorts * 2, dtype=np.int16)
-print("coefficients equal host stage:", bool(np.array_equal(got, want)))
+m = lib.real_coef_mask(g)
+print("coefficients equal host stage:", bool(np.array_equal(got[m], want[m])))

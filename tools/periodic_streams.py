@@ -11,7 +11,8 @@ def run(name, data):
         stride = (g.coef_shorts * 2 + 255) // 256 * 128
         d = lib.DeviceBuffer(stride * 2)
         t0 = time.perf_counter(); rounds = hb.decode(d.ptr, stride); dt = time.perf_counter() - t0
-        ok = np.array_equal(d.download(g.coef_shorts * 2, dtype=np.int16), lib.entropy_decode(data, g))
+        m = lib.real_coef_mask(g)
+        ok = np.array_equal(d.download(g.coef_shorts * 2, dtype=np.int16)[m], lib.entropy_decode(data, g)[m])
         print(name, len(data), "bytes:", rounds, "rounds, %d subsequences walked by the host, %.2f ms, equal %s" % (hb.assisted(), dt * 1e3, ok))
     except Exception as e:
         print(name, "FAILED:", e)
