@@ -430,21 +430,29 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
   b->last_assisted = 0;
-  static int it0 = -1, it1 = -1, group = -1, flush_lanes = 16, sparse_from = 1, write_gmem = 1, assist_after = 12;
-  if (it0 < 0) {
-    const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group" (tuning knob)
-    it0 = 3; it1 = 3; group = 6;
-    if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
-    e = getenv("JGA_HUFF_WRITE_GMEM");               // write pass reads the scan from global memory
-    if (e) write_gmem = atoi(e) != 0;
-    e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (tuning knob)
-    if (e) sparse_from = atoi(e);
-    e = getenv("JGA_HUFF_ASSIST_AFTER");             // rounds before the host walks the unsettled stretches
-    if (e) assist_after = atoi(e) > 0 ? atoi(e) : 1;
-    e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching (tuning knob)
-    if (e) flush_lanes = atoi(e);
-    if (flush_lanes < 1) flush_lanes = 1;
-  }
+  // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
+  struct knobs {
+    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = 1, write_gmem = 1, assist_after = 12;
+    knobs() {
+      const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group": in-group iterations, rounds per host check
+      if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
+      if (it0 < 1) it0 = 1;
+      if (it1 < 1) it1 = 1;
+      if (group < 1) group = 1;
+      e = getenv("JGA_HUFF_WRITE_GMEM");               // write pass reads the scan from global memory
+      if (e) write_gmem = atoi(e) != 0;
+      e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel
+      if (e) sparse_from = atoi(e);
+      e = getenv("JGA_HUFF_ASSIST_AFTER");             // rounds before the host walks the unsettled stretches
+      if (e) assist_after = atoi(e) > 0 ? atoi(e) : 1;
+      e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching
+      if (e) flush_lanes = atoi(e);
+      if (flush_lanes < 1) flush_lanes = 1;
+    }
+  };
+  static const knobs K;
+  const int it0 = K.it0, it1 = K.it1, group = K.group, flush_lanes = K.flush_lanes,
+            sparse_from = K.sparse_from, write_gmem = K.write_gmem, assist_after = K.assist_after;
   A.flush_lanes = flush_lanes;
   A.sub_log2 = b->sub_log2;
   const int GROUP = group;

@@ -52,11 +52,7 @@ struct hipjpeg_ctx {
 };
 
 int gpu_entropy_wanted(void) {
-  static int mode = -1;
-  if (mode < 0) {
-    const char *e = getenv("JGA_PLUGIN_ENTROPY");
-    mode = (e && strcmp(e, "host") == 0) ? 0 : 1;
-  }
+  static const int mode = [] { const char *e = getenv("JGA_PLUGIN_ENTROPY"); return (e && strcmp(e, "host") == 0) ? 0 : 1; }();
   return mode;
 }
 
@@ -65,11 +61,7 @@ int gpu_entropy_wanted(void) {
 // decoder context lives (the harness does; a caller that frees and re-allocates its image
 // between frames would leave a stale registration behind).  Default: the staged copy.
 bool registered(hipjpeg_ctx *c, void *p, size_t bytes) {
-  static int want = -1;
-  if (want < 0) {
-    const char *e = getenv("JGA_PLUGIN_REGISTER");
-    want = (e && strcmp(e, "1") == 0) ? 1 : 0;
-  }
+  static const int want = [] { const char *e = getenv("JGA_PLUGIN_REGISTER"); return (e && strcmp(e, "1") == 0) ? 1 : 0; }();
   if (!want || !p || !bytes) return false;
   int free_slot = -1;
   for (int i = 0; i < 4; i++) {
