@@ -24,7 +24,7 @@ struct jga_huff_batch {
   int max_images;
   long long max_scan;
   // host staging (pinned)
-  unsigned char *h_blob;       // scan | images | segs | sub_seg | tables | S, one upload
+  unsigned char *h_blob;       // scan | images | segs | tables: one upload (device blob: + sub_seg | S)
   size_t blob_cap;
   // device
   unsigned char *d_blob;
@@ -45,7 +45,7 @@ struct jga_huff_batch {
   // current batch
   int nimages;
   uint32_t total_sub, total_seg, max_nsub;
-  size_t off_images, off_segs, off_subseg, off_tables, off_S, off_scan, blob_size, scan_bytes;
+  size_t off_images, off_segs, off_subseg, off_tables, off_S, off_scan, blob_size, upload_size, scan_bytes;
   int prepare_threads;
   jga_geom geom;
   std::vector<unsigned short> qtab;
@@ -247,8 +247,9 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       size_t o = b->scan_bytes;
       b->off_images = o; o += align_up(sizeof(hj_image)*n, 256);
       b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
-      b->off_subseg = o; o += align_up(4*total_sub, 256);
       b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
+      b->upload_size = o;           // what crosses PCIe; the rest is written by hj_init_states
+      b->off_subseg = o; o += align_up(4*total_sub, 256);
       b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
       b->blob_size = o;
       const size_t need_sub = total_sub > total_seg ? total_sub : total_seg;
@@ -260,9 +261,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
     // phase C: descriptors, tables, lane start states of each image
     hj_image *images = (hj_image *)(b->h_blob + b->off_images);
     hj_segment *segs = (hj_segment *)(b->h_blob + b->off_segs);
-    uint32_t *sub_seg = (uint32_t *)(b->h_blob + b->off_subseg);
     hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
-    uint64_t *S = (uint64_t *)(b->h_blob + b->off_S);
     for (;;) {
       const int i = next_c.fetch_add(1);
       if (i >= n) break;
@@ -274,16 +273,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       images[i] = p.im;
       tables[i] = p.tabs;
       memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
-      for (size_t si = 0; si < p.segs.size(); si++) {
-        const hj_segment &sg = p.segs[si];
-        segs[seg0 + si] = sg;
-        for (uint32_t k = 0; k < sg.nsub; k++) {
-          sub_seg[sub0 + sg.sub0 + k] = (uint32_t)si;
-          const uint32_t byte = sg.start + (k << b->sub_log2); // guess: a symbol starts on this byte
-          S[sub0 + seg0 + sg.sub0 + si + k] = hj_pack((uint64_t)byte*8, 0, 0);
-        }
-        S[sub0 + seg0 + sg.sub0 + si + sg.nsub] = 0;
-      }
+      for (size_t si = 0; si < p.segs.size(); si++) segs[seg0 + si] = p.segs[si];
     }
   };
   {
@@ -305,11 +295,11 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   // stream (+16 pad) and the next image's start are never read
   const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
   const auto t_h = std::chrono::steady_clock::now();
-  HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->blob_size, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, (hipStream_t)stream));
   if (trace) {
     fprintf(stderr, "  prepare: host %.2f ms, hipMemcpyAsync call %.2f ms (%zu MB)\n",
      std::chrono::duration<double, std::milli>(t_h - t_p0).count(),
-     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h).count(), b->blob_size >> 20);
+     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h).count(), b->upload_size >> 20);
   }
   if (geom) *geom = b->geom;
   return EXIT_SUCCESS;
@@ -319,7 +309,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
 JGA_EXPORT void jga_huff_set_threads(jga_huff_batch *b, int nthreads) { b->prepare_threads = nthreads; }
 
 // Bytes uploaded by the last prepare() (tables + states + compressed scan data).
-JGA_EXPORT long long jga_huff_upload_bytes(const jga_huff_batch *b) { return (long long)b->blob_size; }
+JGA_EXPORT long long jga_huff_upload_bytes(const jga_huff_batch *b) { return (long long)b->upload_size; }
 JGA_EXPORT int jga_huff_last_rounds(const jga_huff_batch *b) { return b->last_rounds; }
 JGA_EXPORT int jga_huff_last_assisted(const jga_huff_batch *b) { return b->last_assisted; }
 // Quantisation tables of the prepared batch: nimages*3*64 uint16 (host memory).
@@ -417,8 +407,8 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   A.coef_stride = coef_stride;
   A.nimages = b->nimages;
   // reset: states back to the guesses, "never ran", planes zero (only non-zeros are written)
-  HOK(hipMemcpyAsync(b->d_blob + b->off_S, b->h_blob + b->off_S, 8*(size_t)(b->total_sub + b->total_seg),
-   hipMemcpyHostToDevice, st));
+  A.sub_log2 = b->sub_log2;
+  if (hj_launch_init(&A, (int)b->total_seg, st)) return jga_fail("huff: launch failed");
   HOK(hipMemsetAsync(b->d_last_in, 0xFF, 8*(size_t)b->total_sub, st));
   HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));
   HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));

@@ -666,6 +666,33 @@ __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(c
   if (err) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 
+// Start states and segment numbers of every subsequence, written on the device instead of
+// uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
+// (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
+// their first byte.  One wavefront per segment.
+__global__ __launch_bounds__(64) void hj_init_states(const hj_args A, uint32_t *sub_seg) {
+  const uint32_t gs = blockIdx.x;
+  int lo = 0, hi = A.nimages - 1;                           // image of this (batch-global) segment
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (A.images[mid].seg0 <= gs) lo = mid; else hi = mid - 1;
+  }
+  const hj_image *im = A.images + lo;
+  const uint32_t sub0 = im->sub0, seg0 = im->seg0, si = gs - seg0;
+  const hj_segment sg = A.segs[gs];
+  uint64_t *S = A.S + sub0 + seg0 + sg.sub0 + si;           // nsub + 1 entries
+  uint32_t *ss = sub_seg + sub0 + sg.sub0;
+  for (uint32_t k = threadIdx.x; k < sg.nsub; k += 64) {
+    ss[k] = si;
+    S[k] = hj_pack((uint64_t)(sg.start + (k << A.sub_log2))*8, 0, 0);
+  }
+  if (threadIdx.x == 0) S[sg.nsub] = 0;
+}
+extern "C" int hj_launch_init(const hj_args *A, int total_segs, void *stream) {
+  hipLaunchKernelGGL(hj_init_states, dim3(total_segs), dim3(64), 0, (hipStream_t)stream, *A,
+   const_cast<uint32_t *>(A->sub_seg));
+  return (int)hipGetLastError();
+}
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,
  void *stream) {
   dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
