@@ -666,7 +666,7 @@ __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(c
   if (err) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 
-// Start states and segment numbers of every subsequence, written on the device instead of
+// Start states, segment numbers and "never ran" marks of every subsequence, written on the device instead of
 // uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
 // (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
 // their first byte.  One wavefront per segment.
@@ -682,9 +682,11 @@ __global__ __launch_bounds__(64) void hj_init_states(const hj_args A, uint32_t *
   const hj_segment sg = A.segs[gs];
   uint64_t *S = A.S + sub0 + seg0 + sg.sub0 + si;           // nsub + 1 entries
   uint32_t *ss = sub_seg + sub0 + sg.sub0;
+  uint64_t *last_in = A.last_in + sub0 + sg.sub0;
   for (uint32_t k = threadIdx.x; k < sg.nsub; k += 64) {
     ss[k] = si;
     S[k] = hj_pack((uint64_t)(sg.start + (k << A.sub_log2))*8, 0, 0);
+    last_in[k] = ~0ull;                                      // "never ran"
   }
   if (threadIdx.x == 0) S[sg.nsub] = 0;
 }
