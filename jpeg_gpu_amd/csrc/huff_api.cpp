@@ -408,7 +408,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   A.nimages = b->nimages;
   // reset: states back to the guesses, "never ran", planes zero (only non-zeros are written)
   A.sub_log2 = b->sub_log2;
-  if (hj_launch_init(&A, (int)b->total_seg, st)) return jga_fail("huff: launch failed");
+  if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
   HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));
   HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
   // the planes are only touched by the write pass: zero them on the side stream, behind

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 /* sparse != 0: the one-wave-per-group variant for rounds in which few lanes still move */
 /* fills sub_seg and the start states S (guesses) on the device */
-int hj_launch_init(const hj_args *A, int total_segs, void *stream);
+int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, void *stream);
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);

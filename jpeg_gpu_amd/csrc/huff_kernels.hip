@@ -669,8 +669,8 @@ __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(c
 // Start states, segment numbers and "never ran" marks of every subsequence, written on the device instead of
 // uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
 // (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
-// their first byte.  One wavefront per segment.
-__global__ __launch_bounds__(64) void hj_init_states(const hj_args A, uint32_t *sub_seg) {
+// their first byte.  A workgroup takes 4096 subsequences of one segment.
+__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg) {
   const uint32_t gs = blockIdx.x;
   int lo = 0, hi = A.nimages - 1;                           // image of this (batch-global) segment
   while (lo < hi) {
@@ -683,15 +683,18 @@ __global__ __launch_bounds__(64) void hj_init_states(const hj_args A, uint32_t *
   uint64_t *S = A.S + sub0 + seg0 + sg.sub0 + si;           // nsub + 1 entries
   uint32_t *ss = sub_seg + sub0 + sg.sub0;
   uint64_t *last_in = A.last_in + sub0 + sg.sub0;
-  for (uint32_t k = threadIdx.x; k < sg.nsub; k += 64) {
+  const uint32_t k0 = blockIdx.y << 12;
+  if (k0 >= sg.nsub) return;
+  const uint32_t k1 = k0 + 4096u < sg.nsub ? k0 + 4096u : sg.nsub;
+  for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
     ss[k] = si;
     S[k] = hj_pack((uint64_t)(sg.start + (k << A.sub_log2))*8, 0, 0);
     last_in[k] = ~0ull;                                      // "never ran"
   }
-  if (threadIdx.x == 0) S[sg.nsub] = 0;
+  if (k1 == sg.nsub && threadIdx.x == 0) S[sg.nsub] = 0;
 }
-extern "C" int hj_launch_init(const hj_args *A, int total_segs, void *stream) {
-  hipLaunchKernelGGL(hj_init_states, dim3(total_segs), dim3(64), 0, (hipStream_t)stream, *A,
+extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, void *stream) {
+  hipLaunchKernelGGL(hj_init_states, dim3(total_segs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
    const_cast<uint32_t *>(A->sub_seg));
   return (int)hipGetLastError();
 }
