@@ -277,17 +277,22 @@ def test_pipeline(gpu, orc, synth, transport):
         pl.close()
 
 
-def test_pipeline_gpu_entropy_batches(gpu, orc, synth):
+@pytest.mark.parametrize("device_slots", [None, "1", "9"])
+def test_pipeline_gpu_entropy_batches(gpu, orc, synth, monkeypatch, device_slots):
     """transport 2 on a stream of same-geometry images: full groups, a ragged last group,
-    results left in HBM at caller-given addresses and in internal buffers."""
+    results left in HBM at caller-given addresses and in internal buffers; with the default
+    number of lanes allowed on the device at a time, with one, and with no limit."""
     from jpeg_gpu_amd import abi
+    if device_slots:
+        monkeypatch.setenv("JGA_PIPE_DEVICE_SLOTS", device_slots)
     datas = [synth.synthetic_jpeg(640, 360, "420", quality=50 + i, seed=i, restart_interval=(i % 2) * 40)
              for i in range(37)]
     _, g = gpu.geom_of(datas[0])
     want = [orc.decode_rgb(d)[1].reshape(-1) for d in datas]
     outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in datas]
+    # `batch` counts 4K frames: 640x360 frames fill a group 16 to 1 -> groups of 16, 16 and 5
     pl = gpu.Pipeline(device=0, nthreads=6, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2,
-                      batch=8, depth=2)
+                      batch=1, depth=3)
     dbuf = gpu.DeviceBuffer(gpu._align(g.rgb_bytes) * len(datas))
     try:
         rc, jobs = pl.run(datas, host_outs=outs)
