@@ -606,10 +606,11 @@ struct hj_block_out {
 };
 
 // GMEM = true (default): the scan is read from global memory (hj_gmem_src) and a workgroup is
-// 512 lanes: 78 KB of LDS (block buffers + one copy of the tables), 2 x 8 waves per CU, 1.11 ms
+// 512 lanes: 78 KB of LDS (block buffers + one copy of the tables), 2 x 8 waves per CU, 0.78 ms
 // per 48 x 4K; GMEM = false: rows staged in LDS like the sync rounds' (256 lanes, 80 KB, 2 x 4
-// waves per CU, 1.35 ms; JGA_HUFF_WRITE_GMEM=0).  The dense sync round is the
-// other way round (1.19 ms from LDS, 1.5 ms from global memory): it re-reads each row ~2.4x.
+// waves per CU, ~1.3 ms; JGA_HUFF_WRITE_GMEM=0).  The dense sync round is the other way round
+// (1.14 ms from LDS, 1.33-1.50 ms from global memory): all its lanes run and it re-reads each
+// row ~2.4x.
 #define HJ_WRITE_BLOCK 512           /* write pass from global memory: 78 KB of LDS, 2 x 8 waves per CU */
 template <bool GMEM>
 __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(const hj_args A) {
