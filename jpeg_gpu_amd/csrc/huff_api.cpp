@@ -358,7 +358,7 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
           for (;;) {                                               // walk on from lane k
             uint32_t stop = sg.start + ((k + 1) << b->sub_log2);
             if (stop > sg.end) stop = sg.end;
-            const hj_run r = hj_sync_decode(src, im, &tables[i], Ss[k], (uint64_t)stop*8);
+            const hj_run r = hj_sync_decode(src, im, &tables[i], Ss[k], (uint64_t)stop*8, k + 1 >= sg.nsub);
             walked.fetch_add(1, std::memory_order_relaxed);
             if (k + 1 >= sg.nsub) break;
             k++;

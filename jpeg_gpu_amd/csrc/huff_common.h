@@ -179,9 +179,13 @@ HJ_HD int hj_value(uint32_t w, int len, int s) {
 // of a register (an indexed private array would live in scratch).  Every lane of a wave executes
 // every instruction of a divergent loop, so the per-symbol instruction count is
 // what the rounds cost.
+// `last`: the subsequence is the last one of its segment, so `stop_bit` is also where the
+// segment's data ends.  A symbol that reaches past it borrows bits of the next segment (or the
+// pad): a block it would complete does not count — the data ended early, as the host stage says
+// of such a stream (entropy.c, xjpeg.c:593-629).
 template <class Src>
 HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables *T,
- uint64_t start, uint64_t stop_bit) {
+ uint64_t start, uint64_t stop_bit, bool last = false) {
   uint32_t slot_comp_bits = 0;
   for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
   const int nslots = im.nslots;
@@ -211,6 +215,8 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
     comp = (int)((slot_comp_bits >> (2*c)) & 3u);
     k = done ? 0 : kn;
   }
+  // (k == 0 with a block counted: the run's final symbol completed it)
+  if (last && k == 0 && nblocks > 0 && br.tell() > stop_bit) nblocks--;   // ...with bits the segment does not have
   r.nblocks = nblocks;
   r.error = 0;
   r.dcsum[0] = (int16_t)(dcall - dc1 - dc2); r.dcsum[1] = (int16_t)dc1; r.dcsum[2] = (int16_t)dc2;

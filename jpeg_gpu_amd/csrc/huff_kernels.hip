@@ -251,7 +251,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
       const uint64_t start = lds_S[sub];
       const uint32_t sb = lds_stop[sub];
       const hj_run r = hj_sync_decode(hj_source(lds_win, lds_start, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
-       (uint64_t)(sb & 0x7fffffffu)*8);
+       (uint64_t)(sb & 0x7fffffffu)*8, (sb >> 31) == 0u);
       hj_run16 r16;
       r16.nblocks = (uint16_t)r.nblocks;
       r16.dcsum[0] = r.dcsum[0]; r16.dcsum[1] = r.dcsum[1]; r16.dcsum[2] = r.dcsum[2];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
           src.dw0 = first >> 2;
           src.ndw = padded >> 2;
         }
-        hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)stop*8);
+        hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)stop*8, i + 1 >= sg.nsub);
         const uint64_t end_state = r.end_state;
         r.end_state = 0; r.error = 0;
         A.R[gg] = r;                             // (a later run of the same subsequence overwrites it)

@@ -454,6 +454,23 @@ def test_gpu_huffman_letterboxed_frames_in_a_batch_and_through_the_pipeline(gpu,
         pl.close()
 
 
+def test_gpu_huffman_block_finished_with_the_next_intervals_bits_is_an_early_end(gpu, synth):
+    """A restart interval cut short by a few bits: the symbol that would complete its last block
+    reaches into the next interval.  The host stage calls that "entropy data ended early"; so
+    must the GPU stage (found by tools/fuzz_gpu_huff.py 41)."""
+    d = bytearray(synth.synthetic_jpeg(205, 126, "grey", quality=70, restart_interval=3, seed=190))
+    d[5526] ^= 1 << 5
+    d[5023] = 30
+    del d[1876]
+    del d[2596]
+    d = bytes(d)
+    _, g = gpu.geom_of(d)
+    with pytest.raises(gpu.JgaError, match="ended early"):
+        gpu.entropy_decode(d, g)
+    with pytest.raises(gpu.JgaError, match="ended early"):
+        gpu.gpu_entropy_decode([d])
+
+
 def test_gpu_huffman_golden_jpegs(gpu, golden_jpegs):
     """Pillow-made files (optimised tables, DRI) + ours, against the reference's QUANT planes."""
     for name in golden_jpegs.names:

@@ -89,7 +89,7 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
       uint32_t stop_byte = sg.start + ((i + 1) << g_sub_log2);
       if (stop_byte > sg.end) stop_byte = sg.end;
       hj_mem_src src; src.s = P.clean.data();
-      R[g] = hj_sync_decode(src, P.im, &P.tabs, start, (uint64_t)stop_byte*8);
+      R[g] = hj_sync_decode(src, P.im, &P.tabs, start, (uint64_t)stop_byte*8, i + 1 >= sg.nsub);
       last_in[g] = start;
       if (i + 1 < sg.nsub) S[g + si + 1] = R[g].end_state;
       ran = true;
