@@ -1,5 +1,6 @@
 """Corrupt scan bytes at random and push the files through the GPU entropy stage: it must
-return (error or result), never hang; where both stages accept a file, count agreement."""
+return (error or result), never hang; where both stages accept a file, count agreement.
+Usage: fuzz_gpu_huff.py [seed] [n] [wide]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +10,15 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 stats = {"gpu_err": 0, "host_err": 0, "both_ok_equal": 0, "both_ok_diff": 0, "gpu_ok_host_err": 0, "gpu_err_host_ok": 0}
 t0 = time.time()
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 200):
-    samp = ["420", "444", "grey", "422"][it % 4]
-    ri = [0, 3, -1][it % 3]
-    d = bytearray(synth.synthetic_jpeg(200 + it % 37, 120 + it % 23, samp, quality=70, restart_interval=ri, seed=it))
+    if len(sys.argv) > 3:             # wide variant: every sampling, larger frames, more restart patterns
+        samp = ["420", "444", "grey", "422", "440", "411"][it % 6]
+        ri = [0, 1, 2, 7, -1][it % 5]
+        d = bytearray(synth.synthetic_jpeg(300 + (it * 37) % 400, 150 + (it * 23) % 300, samp,
+                                           quality=30 + (it * 13) % 66, restart_interval=ri, seed=it))
+    else:
+        samp = ["420", "444", "grey", "422"][it % 4]
+        ri = [0, 3, -1][it % 3]
+        d = bytearray(synth.synthetic_jpeg(200 + it % 37, 120 + it % 23, samp, quality=70, restart_interval=ri, seed=it))
     sos = d.find(b"\xff\xda")
     lo = sos + 14
     for _ in range(int(rng.integers(1, 6))):
