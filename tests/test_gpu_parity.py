@@ -277,6 +277,29 @@ def test_pipeline(gpu, orc, synth, transport):
         pl.close()
 
 
+def test_pipeline_gpu_entropy_group_with_a_damaged_scan(gpu, orc, synth):
+    """One member of a same-geometry group has a damaged scan: the group's batch decode fails as
+    a whole, its members are then decoded one by one — the damaged one alone reports failure."""
+    from jpeg_gpu_amd import abi
+    datas = [synth.synthetic_jpeg(320, 200, "420", quality=80, seed=i) for i in range(6)]
+    bad = bytearray(datas[2])
+    sos = bad.find(b"\xff\xda")
+    del bad[sos + 200:sos + 1200]                 # a kilobyte of entropy-coded data missing
+    datas[2] = bytes(bad)
+    _, g = gpu.geom_of(datas[0])
+    outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in datas]
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2,
+                      batch=1, depth=2)           # 320x200 frames: groups of 16 -> one group of 6
+    try:
+        rc, jobs = pl.run(datas, host_outs=outs)
+        assert rc == 1
+        assert [jobs[i].status for i in range(6)] == [0, 0, 1, 0, 0, 0]
+        for i in (0, 1, 3, 4, 5):
+            assert np.array_equal(outs[i], orc.decode_rgb(datas[i])[1].reshape(-1)), i
+    finally:
+        pl.close()
+
+
 @pytest.mark.parametrize("device_slots", [None, "1", "9"])
 def test_pipeline_gpu_entropy_batches(gpu, orc, synth, monkeypatch, device_slots):
     """transport 2 on a stream of same-geometry images: full groups, a ragged last group,
