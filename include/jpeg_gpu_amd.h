@@ -356,6 +356,12 @@ int jga_huff_last_rounds(const jga_huff_batch *b);
 /* Subsequences the HOST walked in the last decode because the stream did not fall into step
  * on its own (periodic data: flat areas, letterbox bars); 0 for ordinary photographs. */
 int jga_huff_last_assisted(const jga_huff_batch *b);
+/* After a jga_huff_decode that returned EXIT_FAILURE because of damaged DATA: how many images
+ * of the batch were affected (0: the failure was something else), and image i's verdict (0 ok,
+ * bit 0 "entropy data ended early" / inconsistent stream, bit 1 coefficient index outside the
+ * block).  The planes of the other images are complete and correct. */
+int jga_huff_image_errors(const jga_huff_batch *b);
+int jga_huff_image_error(const jga_huff_batch *b, int i);
 const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);

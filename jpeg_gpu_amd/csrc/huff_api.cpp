@@ -39,6 +39,7 @@ struct jga_huff_batch {
   uint64_t *h_states;          // pinned, lazily: S and last_in read back for assist_chains()
   size_t h_states_cap;         // entries
   int last_assisted;           // subsequences the host walked in the last decode
+  int image_errors;            // images of the last decode whose data was damaged
   hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
   size_t sub_cap;
@@ -419,6 +420,7 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
   b->last_assisted = 0;
+  b->image_errors = 0;
   // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
   struct knobs {
     int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = 1, write_gmem = 1, assist_after = 12;
@@ -464,13 +466,26 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   if (hj_launch_write(&A, (int)b->max_nsub, write_gmem, st)) return jga_fail("huff: launch failed");
   HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
   HOK(hipStreamSynchronize(st));
+  // per-image verdicts stay readable (jga_huff_image_error): the other images of the batch
+  // are decoded correctly whatever one damaged member did
+  b->image_errors = 0;
+  int first = -1;
   for (int i = 0; i < b->nimages; i++) {
     if (b->h_ran[HJ_MAX_ROUNDS + i]) {
-      return jga_fail("huff: image %d: %s", i, (b->h_ran[HJ_MAX_ROUNDS + i] & 2)
-       ? "Error indexing outside block." : "Error, entropy data ended early.");
+      if (first < 0) first = i;
+      b->image_errors++;
     }
   }
+  if (first >= 0) {
+    return jga_fail("huff: image %d: %s", first, (b->h_ran[HJ_MAX_ROUNDS + first] & 2)
+     ? "Error indexing outside block." : "Error, entropy data ended early.");
+  }
   return EXIT_SUCCESS;
+}
+
+JGA_EXPORT int jga_huff_image_errors(const jga_huff_batch *b) { return b->image_errors; }
+JGA_EXPORT int jga_huff_image_error(const jga_huff_batch *b, int i) {
+  return (i >= 0 && i < b->nimages) ? (int)b->h_ran[HJ_MAX_ROUNDS + i] : -1;
 }
 
 }  // extern "C"

@@ -298,7 +298,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   jga_huff_set_threads(l.hb, threads);
   // A lone image whose Huffman tables do not fit the device lookup format takes the host
   // entropy stage (csrc/entropy.c) instead; everything after it is the same.
-  bool host_entropy = false;
+  bool host_entropy = false, damaged = false;
   jpeg_header hdr;
   if (jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream) != EXIT_SUCCESS) {
     if (m != 1 || !strstr(jga_last_error(), "too irregular")) return EXIT_FAILURE;
@@ -334,7 +334,12 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   }
   else {
     if (!HOK(hipMemcpyAsync(l.d_q, jga_huff_qtabs(l.hb), 384*(size_t)m, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
-    if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
+    // damaged data in some members does not spoil the others' planes: go on, and report the
+    // damaged ones alone (anything else — a launch failure — fails the group)
+    if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) {
+      if (jga_huff_image_errors(l.hb) <= 0) return EXIT_FAILURE;
+      damaged = true;
+    }
   }
   const auto t_c = std::chrono::steady_clock::now();
   bool scattered = false;
@@ -389,7 +394,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   for (int i = 0; i < m; i++) {
     jobv[i]->width = g.width; jobv[i]->height = g.height; jobv[i]->nplanes = g.nplanes;
     jobv[i]->h2d_bytes = up;
-    jobv[i]->status = EXIT_SUCCESS;
+    jobv[i]->status = (damaged && jga_huff_image_error(l.hb, i) != 0) ? EXIT_FAILURE : EXIT_SUCCESS;
   }
   return EXIT_SUCCESS;
 }
