@@ -348,27 +348,8 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
   auto work = [&]() {
     for (int i = next.fetch_add(1); i < b->nimages; i = next.fetch_add(1)) {
       const hj_image &im = images[i];
-      hj_mem_src src;
-      src.s = b->h_blob + b->off_scan + im.scan_off;
-      for (uint32_t si = 0; si < im.nseg; si++) {
-        const hj_segment &sg = segs[im.seg0 + si];
-        uint64_t *Ss = S + im.sub0 + im.seg0 + sg.sub0 + si;       // nsub + 1 entries
-        const uint64_t *Ls = last_in + im.sub0 + sg.sub0;
-        for (uint32_t k = 0; k < sg.nsub; k++) {
-          if (Ss[k] == Ls[k]) continue;                            // ran from its current state
-          for (;;) {                                               // walk on from lane k
-            uint32_t stop = sg.start + ((k + 1) << b->sub_log2);
-            if (stop > sg.end) stop = sg.end;
-            const hj_run r = hj_sync_decode(src, im, &tables[i], Ss[k], (uint64_t)stop*8, k + 1 >= sg.nsub);
-            walked.fetch_add(1, std::memory_order_relaxed);
-            if (k + 1 >= sg.nsub) break;
-            k++;
-            if (Ss[k] == r.end_state && Ls[k] == r.end_state) break;   // that lane ran from here
-            Ss[k] = r.end_state;
-            if (Ls[k] == r.end_state) break;                       // (its output stands as well)
-          }
-        }
-      }
+      walked.fetch_add(hj_walk_unsettled(im, segs + im.seg0, &tables[i], b->h_blob + b->off_scan + im.scan_off,
+       S + im.sub0 + im.seg0, last_in + im.sub0, b->sub_log2), std::memory_order_relaxed);
     }
   };
   {

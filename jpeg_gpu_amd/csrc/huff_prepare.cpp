@@ -204,3 +204,30 @@ int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out) {
   out->clean.resize((size_t)out->scan_len + 16);
   return EXIT_SUCCESS;
 }
+
+int hj_walk_unsettled(const hj_image &im, const hj_segment *segs, const hj_tables *tabs,
+ const unsigned char *clean, uint64_t *S, const uint64_t *last_in, int sub_log2) {
+  hj_mem_src src;
+  src.s = clean;
+  int walked = 0;
+  for (uint32_t si = 0; si < im.nseg; si++) {
+    const hj_segment &sg = segs[si];
+    uint64_t *Ss = S + sg.sub0 + si;                             // nsub + 1 entries
+    const uint64_t *Ls = last_in + sg.sub0;
+    for (uint32_t k = 0; k < sg.nsub; k++) {
+      if (Ss[k] == Ls[k]) continue;                              // ran from its current state
+      for (;;) {                                                 // walk on from lane k
+        uint32_t stop = sg.start + ((k + 1) << sub_log2);
+        if (stop > sg.end) stop = sg.end;
+        const hj_run r = hj_sync_decode(src, im, tabs, Ss[k], (uint64_t)stop*8, k + 1 >= sg.nsub);
+        walked++;
+        if (k + 1 >= sg.nsub) break;
+        k++;
+        if (Ss[k] == r.end_state && Ls[k] == r.end_state) break; // that lane ran from here
+        Ss[k] = r.end_state;
+        if (Ls[k] == r.end_state) break;                         // (its output stands as well)
+      }
+    }
+  }
+  return walked;
+}

@@ -38,4 +38,15 @@ int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsig
 // Both steps, clean stream kept in out->clean (emulation / tests).
 int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out);
 
+// Host walk over the stretches of ONE image that have not settled (streams that do not
+// self-synchronise: flat areas, letterbox bars).  `S` / `last_in` are the image's slices of the
+// state arrays read back from the device (S: nsub + nseg entries, segment s of the image at
+// S + sg.sub0 + s; last_in: nsub entries), `clean` its clean scan.  In every segment, from each
+// lane whose start state moved since its last run (the first such lane's state is true by
+// induction from the segment start) it decodes on with hj_sync_decode, writing the state at
+// every subsequence boundary, until it arrives in a state the next lane has already run from.
+// Returns the number of subsequences walked.
+int hj_walk_unsettled(const hj_image &im, const hj_segment *segs, const hj_tables *tabs,
+ const unsigned char *clean, uint64_t *S, const uint64_t *last_in, int sub_log2);
+
 #endif

@@ -19,6 +19,9 @@ def emul(lib):
                                    C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_longlong)]
     E.huff_emul_set_sub.argtypes = [C.c_int]
+    E.huff_emul_set_assist.argtypes = [C.c_int]
+    E.huff_emul_set_assist.restype = None
+    E.huff_emul_walked.restype = C.c_longlong
     return E
 
 
@@ -72,3 +75,47 @@ def test_rounds_are_few(emul, lib, synth):
     # shorter subsequences need more hand-overs to fall into step, not more bytes decoded
     rc, got, rounds32, nsub32, runs32 = run(emul, lib, data, sub=32)
     assert rc == 0 and nsub32 > 3 * nsub and rounds32 < 80 and runs32 < 8 * nsub32
+
+
+@pytest.mark.parametrize("sampling", ["420", "444", "grey"])
+def test_streams_that_never_fall_into_step_and_the_host_walk(emul, lib, synth, sampling):
+    """Periodic data (flat blocks) can be parsed out of step for ever: the rounds alone then
+    need about one round per subsequence.  With the host walk of the unsettled stretches
+    (huff_prepare.cpp hj_walk_unsettled, what huff_api.cpp's assist_chains applies on the GPU
+    path) the same streams settle two rounds after it, with the same coefficients."""
+    w, h = 640, 360
+    n = synth.coef_shorts(w, h, sampling)
+    cases = []
+    lv = np.zeros(n, np.int16)
+    cases.append(lv.copy())
+    lv.reshape(-1, 64)[:, 0] = 5
+    lv.reshape(-1, 64)[::2, 0] = -5
+    cases.append(lv.copy())
+    lv = np.zeros(n, np.int16)
+    lv.reshape(-1, 64)[:, 63] = 1
+    cases.append(lv)
+    slow = 0
+    try:
+        for lv in cases:
+            data = synth.encode_levels(lv, w, h, sampling)
+            _, g = lib.geom_of(data)
+            want = lib.entropy_decode(data, g)
+            emul.huff_emul_set_assist(0)
+            rc, got, rounds_alone, nsub, _ = run(emul, lib, data)
+            assert rc == 0 and np.array_equal(got, want)
+            emul.huff_emul_set_assist(4)
+            rc, got, rounds, nsub, _ = run(emul, lib, data)
+            assert rc == 0 and np.array_equal(got, want)
+            assert rounds <= 4 + 3
+            if rounds_alone > 12:
+                slow += 1
+                assert emul.huff_emul_walked() > 0 and rounds < rounds_alone
+        assert slow > 0                  # at least one of the cases really does not self-synchronise
+        # an ordinary photograph never needs the walk (36 single-run rounds here = the GPU
+        # path's 12 launches of up to 3 in-group iterations)
+        emul.huff_emul_set_assist(36)
+        data = synth.synthetic_jpeg(w, h, sampling, quality=90, seed=3)
+        rc, got, rounds, nsub, _ = run(emul, lib, data)
+        assert rc == 0 and emul.huff_emul_walked() == 0
+    finally:
+        emul.huff_emul_set_assist(0)

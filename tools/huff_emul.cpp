@@ -49,6 +49,16 @@ int huff_emul_set_sub(int bytes) {
   return 0;
 }
 
+static int g_assist_after = 0;
+// After this many rounds without settling, the host walk of huff_api.cpp's assist_chains()
+// (hj_walk_unsettled) is applied once per further round; 0 = never.  Returns walked
+// subsequences of the last decode through huff_emul_walked().
+static long long g_walked = 0;
+extern "C" __attribute__((visibility("default")))
+void huff_emul_set_assist(int rounds) { g_assist_after = rounds; }
+extern "C" __attribute__((visibility("default")))
+long long huff_emul_walked(void) { return g_walked; }
+
 extern "C" __attribute__((visibility("default")))
 int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long coef_shorts,
  int jacobi, int *rounds_out, int *nsub_out, long long *runs_out) {
@@ -74,6 +84,7 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
   }
   int rounds = 0;
   long long runs = 0;
+  g_walked = 0;
   for (;;) {
     bool ran = false;
     // jacobi: every lane of a round reads the states as they were when the round
@@ -106,6 +117,10 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
     }
     rounds++;
     if (rounds > (int)nsub + 4) return 3;
+    if (g_assist_after > 0 && rounds >= g_assist_after) {
+      g_walked += hj_walk_unsettled(P.im, P.segs.data(), &P.tabs, P.clean.data(), S.data(), last_in.data(),
+       g_sub_log2);
+    }
   }
   // per-segment exclusive prefix sums + write pass
   for (size_t si = 0; si < P.segs.size(); si++) {
