@@ -40,6 +40,7 @@ struct jga_huff_batch {
   size_t h_states_cap;         // entries
   int last_assisted;           // subsequences the host walked in the last decode
   int image_errors;            // images of the last decode whose data was damaged
+  int assist_hint;             // the previous decode needed the host walk
   hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
   size_t sub_cap;
@@ -438,10 +439,13 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
     HOK(hipStreamSynchronize(st));
     if (b->h_ran[round - 1] == 0) break;                   // a round in which nothing moved
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
-    if (round >= assist_after && assist_chains(b, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+    // (a batch object whose previous decode needed the walk — the same camera, the same
+    // letterbox — gets it at the first check instead of waiting out twelve rounds)
+    if (round >= (b->assist_hint ? 1 : assist_after) && assist_chains(b, st) != EXIT_SUCCESS) return EXIT_FAILURE;
   }
   b->last_rounds = 0;
   while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;
+  b->assist_hint = b->last_assisted > 0;
   if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
   HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
   if (hj_launch_write(&A, (int)b->max_nsub, write_gmem, st)) return jga_fail("huff: launch failed");
