@@ -162,6 +162,15 @@ typedef struct jpeg_decode_ctx_vtbl {
  * sets plane[i].packed / img->packed (src/xjpeg.c:484-496, 513-519, 531-535). */
 extern const jpeg_decode_ctx_vtbl HIPJPEG_DECODE_CTX_VTBL;
 
+/* The comparison backend: the platform's libjpeg behind the same table, as the
+ * reference's LIBJPEG_DECODE_CTX_VTBL (src/jpeg_wrap.c:56-252, jpeg_wrap.h:53).
+ * CPU only, stages QUANT / YUV / RGB (jpeg_wrap.c:134-228).  libjpeg.so.8 is bound
+ * at run time; decode_alloc returns NULL when it is not installed
+ * (jga_libjpeg_available() == 0).  Not on the hot path: bench.py times it beside the
+ * MI355X path and the harness offers it as `-i libjpeg`. */
+extern const jpeg_decode_ctx_vtbl LIBJPEG_DECODE_CTX_VTBL;
+int jga_libjpeg_available(void);
+
 /* ------------------------------------------------------------------------ */
 /* 3. jga_* C entry points                                                   */
 /* ------------------------------------------------------------------------ */

@@ -18,6 +18,7 @@
  * the reference ends by closing its window; --check prints a checksum of the RGB
  * left in HBM. */
 #include <getopt.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,70 +34,106 @@ static const char *OUT_NAMES[JPEG_DECODE_OUT_MAX] = {    /* src/jpeg_wrap.c:24-3
   "pack", "quant", "dct", "yuv", "rgb"
 };
 
-static const char *OPTSTRING = "hi:o:dH";
-static const struct option OPTIONS[] = {
-  { "help", no_argument, NULL, 'h' },
-  { "no-cpu", no_argument, NULL, 0 },
-  { "no-gpu", no_argument, NULL, 0 },
-  { "impl", required_argument, NULL, 'i' },
-  { "out", required_argument, NULL, 'o' },
-  { "dump", no_argument, NULL, 'd' },
-  { "header", no_argument, NULL, 'H' },
-  { "frames", required_argument, NULL, 0 },
-  { "seconds", required_argument, NULL, 0 },
-  { "check", no_argument, NULL, 0 },
-  { NULL, 0, NULL, 0 }
+/* ---- command line ---------------------------------------------------------------
+ * One table drives getopt_long, the help text and the dispatch.  The option NAMES and
+ * letters are the reference program's (src/jpeg_gpu.c:473-483), since scripts written for
+ * it must keep working; --frames / --seconds / --check are this program's own. */
+enum opt_id { OPT_HELP, OPT_NO_CPU, OPT_NO_GPU, OPT_IMPL, OPT_OUT, OPT_DUMP, OPT_HEADER,
+ OPT_FRAMES, OPT_SECONDS, OPT_CHECK, OPT_COUNT };
+
+typedef struct opt_spec {
+  const char *name;            /* long name */
+  char letter;                 /* short form, 0 if none */
+  const char *arg;             /* placeholder of its argument, NULL if it takes none */
+  const char *help;            /* '\n' separates lines; continuation lines are indented */
+} opt_spec;
+
+static const opt_spec SPECS[OPT_COUNT] = {
+  [OPT_HELP]    = { "help", 'h', NULL, "Show this text." },
+  [OPT_NO_CPU]  = { "no-cpu", 0, NULL, "Main loop: skip the host decode (the first frame is kept)." },
+  [OPT_NO_GPU]  = { "no-gpu", 0, NULL, "Main loop: skip the device stage." },
+  [OPT_IMPL]    = { "impl", 'i', "<decoder>", "Decoder plugin:\n"
+                    "hipjpeg (default) => MI355X plugin (HIP kernels)\n"
+                    "libjpeg => the platform's libjpeg, CPU only (quant, yuv, rgb)" },
+  [OPT_OUT]     = { "out", 'o', "<format>", "Stage at which the plugin stops; the device\n"
+                    " finishes the frame from there:\n"
+                    "pack => run/level words + per-block index\n"
+                    "quant => quantised levels, natural order\n"
+                    "dct => dequantised coefficients\n"
+                    "yuv (default) => component planes\n"
+                    "rgb => interleaved pixels" },
+  [OPT_DUMP]    = { "dump", 'd', NULL, "Print the first frame at the chosen stage and exit." },
+  [OPT_HEADER]  = { "header", 'H', NULL, "Print what the frame header says and exit." },
+  [OPT_FRAMES]  = { "frames", 0, "<n>", "Leave the main loop after n frames." },
+  [OPT_SECONDS] = { "seconds", 0, "<s>", "Leave the main loop after s seconds (default 3)." },
+  [OPT_CHECK]   = { "check", 0, NULL, "Print the Adler-32 of the last RGB frame in HBM." },
 };
 
 static void usage(void) {
-  fprintf(stderr,
-   "Usage: %s [options] jpeg_file\n\n"
-   "Options:\n\n"
-   "  -h --help                      Display this help and exit.\n"
-   "     --no-cpu                    Disable CPU decoding in main loop.\n"
-   "     --no-gpu                    Disable GPU decoding in main loop.\n"
-   "  -i --impl <decoder>            Software decoder to use.\n"
-   "                                 hipjpeg (default) => MI355X plugin\n"
-   "  -o --out <format>              Format software decoder should output\n"
-   "                                  and send to the GPU.\n"
-   "                                 pack => RLC zero packed and quantized.\n"
-   "                                 quant => quantized but de-zigzaged.\n"
-   "                                 dct => DCT (12-bit dequantized)\n"
-   "                                 yuv (default) => YUV (4:4:4 or 4:2:0)\n"
-   "                                 rgb => RGB (4:4:4)\n"
-   "  -d --dump                      Dump jpeg data in the output format.\n"
-   "  -H --header                    Print the jpeg header.\n"
-   "     --frames <n>                Stop the main loop after n frames.\n"
-   "     --seconds <s>               Stop the main loop after s seconds (default 3).\n"
-   "     --check                     Print the Adler-32 of the final RGB image.\n\n"
-   " %s accepts only 8-bit non-hierarchical JPEG files.\n\n", NAME, NAME);
+  int i;
+  fprintf(stderr, "Usage: %s [options] jpeg_file\n\nOptions:\n\n", NAME);
+  for (i = 0; i < OPT_COUNT; i++) {
+    const opt_spec *o = &SPECS[i];
+    const char *line = o->help;
+    char left[40];
+    if (o->letter) snprintf(left, sizeof(left), "-%c --%s %s", o->letter, o->name, o->arg ? o->arg : "");
+    else snprintf(left, sizeof(left), "   --%s %s", o->name, o->arg ? o->arg : "");
+    while (line) {
+      const char *nl = strchr(line, '\n');
+      const int n = nl ? (int)(nl - line) : (int)strlen(line);
+      fprintf(stderr, "  %-30s %.*s\n", line == o->help ? left : "", n, line);
+      line = nl ? nl + 1 : NULL;
+    }
+  }
+  fprintf(stderr, "\n %s reads 8-bit baseline (SOF0) JPEG files.\n\n", NAME);
 }
 
-static int read_file(jpeg_info *info, const char *name) {   /* src/jpeg_info.c:30-62 */
+/* getopt_long's view of SPECS: long options report their table index through `flag`-less
+ * val = 256 + index, short ones their letter. */
+static int next_option(int argc, char *argv[]) {
+  static struct option longs[OPT_COUNT + 1];
+  static char shorts[2*OPT_COUNT + 1];
+  int c, i;
+  if (!longs[0].name) {
+    char *s = shorts;
+    for (i = 0; i < OPT_COUNT; i++) {
+      longs[i].name = SPECS[i].name;
+      longs[i].has_arg = SPECS[i].arg ? required_argument : no_argument;
+      longs[i].val = 256 + i;
+      if (SPECS[i].letter) {
+        *s++ = SPECS[i].letter;
+        if (SPECS[i].arg) *s++ = ':';
+      }
+    }
+  }
+  c = getopt_long(argc, argv, shorts, longs, NULL);
+  if (c == -1) return -1;
+  if (c >= 256) return c - 256;
+  for (i = 0; i < OPT_COUNT; i++) if (SPECS[i].letter == c) return i;
+  return OPT_HELP;                                  /* '?': unknown option */
+}
+
+static int read_file(jpeg_info *info, const char *name) {   /* the job of src/jpeg_info.c:30-62 */
   FILE *fp = fopen(name, "rb");
-  int size;
+  long size;
+  unsigned char *buf = NULL;
   if (fp == NULL) {
     fprintf(stderr, "Error, could not open jpeg file %s\n", name);
     return EXIT_FAILURE;
   }
-  free(info->buf);
-  memset(info, 0, sizeof(*info));
-  fseek(fp, 0, SEEK_END);
-  info->size = (int)ftell(fp);
-  info->buf = malloc(info->size ? info->size : 1);
-  if (info->buf == NULL) {
-    fprintf(stderr, "Error, could not allocate %i bytes\n", info->size);
+  if (fseek(fp, 0, SEEK_END) == 0 && (size = ftell(fp)) >= 0 && size <= 0x7fffffffL
+   && fseek(fp, 0, SEEK_SET) == 0 && (buf = malloc(size ? (size_t)size : 1)) != NULL
+   && fread(buf, 1, (size_t)size, fp) == (size_t)size) {
     fclose(fp);
-    return EXIT_FAILURE;
+    free(info->buf);
+    info->buf = buf;
+    info->size = (int)size;
+    return EXIT_SUCCESS;
   }
-  fseek(fp, 0, SEEK_SET);
-  size = (int)fread(info->buf, 1, info->size, fp);
+  fprintf(stderr, "Error reading jpeg file %s\n", name);
+  free(buf);
   fclose(fp);
-  if (size != info->size) {
-    fprintf(stderr, "Error reading jpeg file, got %i of %i bytes\n", size, info->size);
-    return EXIT_FAILURE;
-  }
-  return EXIT_SUCCESS;
+  return EXIT_FAILURE;
 }
 
 static double now(void) {
@@ -105,79 +142,91 @@ static double now(void) {
   return (double)ts.tv_sec + 1e-9*(double)ts.tv_nsec;
 }
 
-static void print_header(const jpeg_header *h) {            /* src/jpeg_gpu.c:614-637 */
-  int i, j;
-  printf("Image Size         : %ix%i\n", h->width, h->height);
-  printf("Bits Per Pixel     : %i\n", h->bits);
-  printf("Components         : %i\n", h->ncomps);
-  printf("Chroma Subsampling : %s\n", SUBSAMP_NAMES[h->subsamp]);
-  printf("Minimum Coded Unit : ");
+/* ---- --header: the text of src/jpeg_gpu.c:614-637, byte for byte (tests/test_harness.py).
+ * Every line is "label, padded to 19 columns, colon, value". */
+static void field(const char *label, const char *fmt, ...) {
+  va_list ap;
+  printf("%-19s: ", label);
+  va_start(ap, fmt);
+  vprintf(fmt, ap);
+  va_end(ap);
+  putchar('\n');
+}
+
+static void print_header(const jpeg_header *h) {
+  char text[64];
+  int i, k, n = 0;
+  field("Image Size", "%ix%i", h->width, h->height);
+  field("Bits Per Pixel", "%i", h->bits);
+  field("Components", "%i", h->ncomps);
+  field("Chroma Subsampling", "%s", SUBSAMP_NAMES[h->subsamp]);
   for (i = 0; i < h->ncomps; i++) {
-    printf("%s%ix%i", i > 0 ? " " : "", h->comp[i].hsamp, h->comp[i].vsamp);
+    n += snprintf(text + n, sizeof(text) - n, "%s%ix%i", i ? " " : "", h->comp[i].hsamp, h->comp[i].vsamp);
   }
-  printf("\n");
-  printf("Restart Interval   : %i\n", h->restart_interval);
+  field("Minimum Coded Unit", "%s", text);
+  field("Restart Interval", "%i", h->restart_interval);
   for (i = 0; i < NQUANT_MAX; i++) {
-    if (h->quant[i].valid) {
-      printf("Quant Table %i Bits : %i\n", i, h->quant[i].bits);
-      for (j = 1; j <= 64; j++) {
-        printf("%4i%s", h->quant[i].tbl[j - 1], j & 0x7 ? "" : "\n");
-      }
-    }
+    const jpeg_quant *q = &h->quant[i];
+    if (!q->valid) continue;
+    snprintf(text, sizeof(text), "Quant Table %i Bits", i);
+    field(text, "%i", q->bits);
+    for (k = 0; k < 64; k++) printf((k & 7) == 7 ? "%4i\n" : "%4i", q->tbl[k]);
   }
 }
 
-/* src/jpeg_gpu.c:643-700.  QUANT/DCT print the plane's share of the coefficient
- * buffer as `height` rows of `width` shorts, exactly as the reference indexes it.
- * RGB prints component i of every pixel with the img->pixels pitch that its only
- * writer uses (width*3, src/jpeg_wrap.c:215-219); the reference's own loop
- * multiplies by the padded plane width there. */
+/* ---- --dump: the text of src/jpeg_gpu.c:643-700.  Every stage but PACK is "Plane i", a
+ * matrix of "%4i " cells, a blank line; what differs is where cell (row, col) comes from. */
+typedef struct cell_source {
+  const image *img;
+  const image_plane *plane;
+  int comp;
+} cell_source;
+
+/* QUANT/DCT: the plane's share of the coefficient buffer read as `height` rows of `width`
+ * shorts — how the reference indexes it, not block by block. */
+static int cell_coef(const cell_source *s, long row, long col) {
+  return s->plane->coef[row*s->plane->width + col];
+}
+static int cell_sample(const cell_source *s, long row, long col) {
+  return s->plane->data[row*s->plane->ystride + col];
+}
+/* RGB: component `comp` of every pixel, with the pitch the only writer of img->pixels uses
+ * (width*nplanes, src/jpeg_wrap.c:215-219; the reference's dump multiplies by the padded
+ * plane width here — SURVEY.md Appendix E). */
+static int cell_pixel(const cell_source *s, long row, long col) {
+  return s->img->pixels[(row*s->img->width + col)*s->img->nplanes + s->comp];
+}
+
 static int dump_image(const image *img, jpeg_decode_out out) {
-  int i, j, k;
+  int (*cell)(const cell_source *, long, long);
+  cell_source src;
+  long row, col, rows, cols;
   if (out == JPEG_DECODE_PACK) {
-    int packed = 0;
-    for (i = 0; i < img->nplanes; i++) {
-      printf("Plane %i Packed Data: %i\n", i, img->plane[i].packed);
-      packed += img->plane[i].packed;
+    int total = 0;
+    for (src.comp = 0; src.comp < img->nplanes; src.comp++) {
+      printf("Plane %i Packed Data: %i\n", src.comp, img->plane[src.comp].packed);
+      total += img->plane[src.comp].packed;
     }
-    printf("Packed Data : %i\n", packed);
+    printf("Packed Data : %i\n", total);
     return EXIT_SUCCESS;
   }
-  for (i = 0; i < img->nplanes; i++) {
-    const image_plane *plane = &img->plane[i];
-    printf("Plane %i\n", i);
-    switch (out) {
-      case JPEG_DECODE_QUANT :
-      case JPEG_DECODE_DCT : {
-        for (k = 0; k < plane->height; k++) {
-          for (j = 0; j < plane->width; j++) printf("%4i ", plane->coef[k*plane->width + j]);
-          printf("\n");
-        }
-        break;
-      }
-      case JPEG_DECODE_YUV : {
-        for (k = 0; k < plane->height; k++) {
-          for (j = 0; j < plane->width; j++) printf("%4i ", plane->data[k*plane->width + j]);
-          printf("\n");
-        }
-        break;
-      }
-      case JPEG_DECODE_RGB : {
-        for (k = 0; k < img->height; k++) {
-          for (j = 0; j < img->width; j++) {
-            printf("%4i ", img->pixels[((long)k*img->width + j)*img->nplanes + i]);
-          }
-          printf("\n");
-        }
-        break;
-      }
-      default : {
-        fprintf(stderr, "Unsupported output '%s'.\n",
-         (unsigned)out < JPEG_DECODE_OUT_MAX ? OUT_NAMES[out] : "?");
-        return EXIT_FAILURE;
-      }
+  cell = out == JPEG_DECODE_YUV ? cell_sample : out == JPEG_DECODE_RGB ? cell_pixel
+   : (out == JPEG_DECODE_QUANT || out == JPEG_DECODE_DCT) ? cell_coef : NULL;
+  if (!cell) {
+    fprintf(stderr, "Unsupported output '%s'.\n", (unsigned)out < JPEG_DECODE_OUT_MAX ? OUT_NAMES[out] : "?");
+    return EXIT_FAILURE;
+  }
+  src.img = img;
+  for (src.comp = 0; src.comp < img->nplanes; src.comp++) {
+    src.plane = &img->plane[src.comp];
+    rows = out == JPEG_DECODE_RGB ? img->height : src.plane->height;
+    cols = out == JPEG_DECODE_RGB ? img->width : src.plane->width;
+    printf("Plane %i\n", src.comp);
+    for (row = 0; row < rows; row++) {
+      for (col = 0; col < cols; col++) printf("%4i ", cell(&src, row, col));
+      putchar('\n');
     }
-    printf("\n");
+    putchar('\n');
   }
   return EXIT_SUCCESS;
 }
@@ -282,24 +331,23 @@ int main(int argc, char *argv[]) {
   jpeg_header header;
   image img;
   jpeg_decode_ctx *dec;
-  int c, loi;
+  int c;
   memset(&info, 0, sizeof(info));
   /* this program keeps one image for the life of each decoder context, so the plugin may
    * register its buffers and copy results straight into them */
   setenv("JGA_PLUGIN_REGISTER", "1", 0);
-  while ((c = getopt_long(argc, argv, OPTSTRING, OPTIONS, &loi)) != EOF) {
-    switch (c) {
-      case 0 : {
-        const char *n = OPTIONS[loi].name;
-        if (strcmp(n, "no-cpu") == 0) no_cpu = 1;
-        else if (strcmp(n, "no-gpu") == 0) no_gpu = 1;
-        else if (strcmp(n, "frames") == 0) max_frames = atol(optarg);
-        else if (strcmp(n, "seconds") == 0) max_seconds = atof(optarg);
-        else if (strcmp(n, "check") == 0) check = 1;
-        break;
-      }
-      case 'i' : {
-        if (strcmp("hipjpeg", optarg) == 0) vtbl = HIPJPEG_DECODE_CTX_VTBL;
+  while ((c = next_option(argc, argv)) >= 0) {
+    switch ((enum opt_id)c) {
+      case OPT_NO_CPU : no_cpu = 1; break;
+      case OPT_NO_GPU : no_gpu = 1; break;
+      case OPT_FRAMES : max_frames = atol(optarg); break;
+      case OPT_SECONDS : max_seconds = atof(optarg); break;
+      case OPT_CHECK : check = 1; break;
+      case OPT_DUMP : dump = 1; break;
+      case OPT_HEADER : head = 1; break;
+      case OPT_IMPL : {
+        if (strcmp(optarg, "hipjpeg") == 0) vtbl = HIPJPEG_DECODE_CTX_VTBL;
+        else if (strcmp(optarg, "libjpeg") == 0) vtbl = LIBJPEG_DECODE_CTX_VTBL;
         else {
           fprintf(stderr, "Invalid decoder implementation: %s\n", optarg);
           usage();
@@ -307,21 +355,17 @@ int main(int argc, char *argv[]) {
         }
         break;
       }
-      case 'o' : {
-        int k, found = 0;
-        for (k = 0; k < JPEG_DECODE_OUT_MAX; k++) {
-          if (strcmp(OUT_NAMES[k], optarg) == 0) { out = (jpeg_decode_out)k; found = 1; }
-        }
-        if (!found) {
+      case OPT_OUT : {
+        int k;
+        for (k = 0; k < JPEG_DECODE_OUT_MAX && strcmp(OUT_NAMES[k], optarg) != 0; k++) ;
+        if (k == JPEG_DECODE_OUT_MAX) {
           fprintf(stderr, "Invalid decoder output format: %s\n", optarg);
           usage();
           return EXIT_FAILURE;
         }
+        out = (jpeg_decode_out)k;
         break;
       }
-      case 'd' : dump = 1; break;
-      case 'H' : head = 1; break;
-      case 'h' :
       default : usage(); return EXIT_FAILURE;
     }
   }

@@ -54,7 +54,10 @@ int jga_fail(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(jga_err, sizeof(jga_err), fmt, ap);
   va_end(ap);
-  if (!getenv("JGA_QUIET")) fprintf(stderr, "%s\n", jga_err);
+  {
+    const char *quiet = getenv("JGA_QUIET");          /* unset, empty or "0": speak */
+    if (!quiet || !*quiet || *quiet == '0') fprintf(stderr, "%s\n", jga_err);
+  }
   return EXIT_FAILURE;
 }
 

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("JGA_LIB_PATH") or os.path.join(_HERE, "libjpeg_gpu_am
 
 # Symbols include/jpeg_gpu_amd.h declares (checked by tests/test_layout_abi.py).
 EXPORTED = [
-    "HIPJPEG_DECODE_CTX_VTBL", "jga_version", "jga_last_error", "jga_image_init",
+    "HIPJPEG_DECODE_CTX_VTBL", "LIBJPEG_DECODE_CTX_VTBL", "jga_libjpeg_available", "jga_version", "jga_last_error", "jga_image_init",
     "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",
     "jga_parse_header", "jga_entropy_decode", "jga_entropy_decode_pack",
     "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_kernel_name",
@@ -112,6 +112,7 @@ L.jga_huff_qtabs.argtypes = [_vp]
 L.jga_huff_qtabs.restype = C.POINTER(C.c_ushort)
 
 VTBL = abi.jpeg_decode_ctx_vtbl.in_dll(L, "HIPJPEG_DECODE_CTX_VTBL")
+LIBJPEG_VTBL = abi.jpeg_decode_ctx_vtbl.in_dll(L, "LIBJPEG_DECODE_CTX_VTBL")
 
 
 def check(rc):
@@ -267,20 +268,21 @@ def split_planes(g, yuv):
 # ---- plugin (vtable) ------------------------------------------------------------
 
 class Decoder:
-    """Drives HIPJPEG_DECODE_CTX_VTBL exactly as the reference's main() drives a
+    """Drives a plugin table (default HIPJPEG_DECODE_CTX_VTBL) exactly as the reference's main() drives a
     decoder (src/jpeg_gpu.c:612-613, 637, 701-704, 1215, 1231-1237)."""
 
-    def __init__(self, data):
+    def __init__(self, data, vtbl=None):
+        self.vtbl = VTBL if vtbl is None else vtbl      # (LIBJPEG_VTBL: the comparison backend)
         self._data = np.frombuffer(bytes(data), np.uint8).copy()
         self._info = abi.jpeg_info(len(self._data), self._data.ctypes.data)
-        self.ctx = VTBL.decode_alloc(C.byref(self._info))
+        self.ctx = self.vtbl.decode_alloc(C.byref(self._info))
         if not self.ctx:
-            raise MemoryError("decode_alloc failed")
+            raise MemoryError("decode_alloc failed: " + (L.jga_last_error() or b"").decode())
         self.header = abi.jpeg_header()
         self.img = None
 
     def read_header(self):
-        check(VTBL.decode_header(self.ctx, C.byref(self.header)))
+        check(self.vtbl.decode_header(self.ctx, C.byref(self.header)))
         return self.header
 
     def init_image(self):
@@ -290,13 +292,13 @@ class Decoder:
         return self.img
 
     def decode(self, out):
-        check(VTBL.decode_image(self.ctx, C.byref(self.img), out))
+        check(self.vtbl.decode_image(self.ctx, C.byref(self.img), out))
 
     def reset(self, data=None):
         if data is not None:
             self._data = np.frombuffer(bytes(data), np.uint8).copy()
             self._info = abi.jpeg_info(len(self._data), self._data.ctypes.data)
-        VTBL.decode_reset(self.ctx, C.byref(self._info))
+        self.vtbl.decode_reset(self.ctx, C.byref(self._info))
 
     # views into the image buffers
     def planes(self):
@@ -323,7 +325,7 @@ class Decoder:
 
     def close(self):
         if self.ctx:                       # the reference's order: decode_free, then image_clear
-            VTBL.decode_free(self.ctx)
+            self.vtbl.decode_free(self.ctx)
             self.ctx = None
         if self.img is not None:
             L.jga_image_clear(C.byref(self.img))

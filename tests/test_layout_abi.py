@@ -97,7 +97,8 @@ def test_exports_every_declared_symbol(lib):
     """Every function/variable include/jpeg_gpu_amd.h declares is exported."""
     hdr = open(os.path.join(ROOT, "include", "jpeg_gpu_amd.h")).read()
     declared = set(re.findall(r"\b(jga_[a-z0-9_]+)\s*\(", hdr))
-    declared |= {"HIPJPEG_DECODE_CTX_VTBL"}
+    declared |= set(re.findall(r"extern const jpeg_decode_ctx_vtbl (\w+);", hdr))
+    assert {"HIPJPEG_DECODE_CTX_VTBL", "LIBJPEG_DECODE_CTX_VTBL"} <= declared
     declared -= {"jga_plane_geom", "jga_geom", "jga_pipeline_config", "jga_job"}
     assert declared == set(lib.EXPORTED)
     for name in sorted(declared):
