@@ -316,7 +316,8 @@ typedef struct jga_pipeline jga_pipeline;
 typedef struct jga_pipeline_config {
   int device;                  /* HIP device ordinal */
   int nthreads;                /* host entropy threads (0 = hardware default) */
-  int depth;                   /* pinned slots in flight (0 = 2*nthreads) */
+  int depth;                   /* transport 2: lanes (groups in flight), 0 = 6.  Transports 0/1
+                                * always run two pinned slots per thread; depth is ignored */
   int out;                     /* JPEG_DECODE_YUV or JPEG_DECODE_RGB */
   int copy_back;               /* 1: D2H into caller's host buffers */
   long long max_coef_shorts;   /* slot capacity (0 = sized on first submit) */
@@ -360,6 +361,11 @@ int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *jpegs,
  const int *sizes, int n, jga_geom *geom, void *stream);
 int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  void *stream);
+/* Per-image outcome of the last jga_huff_prepare (also after it failed): 0 usable, 1 not
+ * (damaged or unsupported file), 2 a valid file the device format cannot hold — Huffman
+ * tables with too many long-code groups, or a frame beyond the kernels' 32-bit bit
+ * positions / plane offsets (>= 4 GiB of planes): decode that one with jga_entropy_decode. */
+int jga_huff_prepare_verdict(const jga_huff_batch *b, int i);
 long long jga_huff_upload_bytes(const jga_huff_batch *b);
 int jga_huff_last_rounds(const jga_huff_batch *b);
 /* Subsequences the HOST walked in the last decode because the stream did not fall into step

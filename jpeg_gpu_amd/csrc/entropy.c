@@ -53,17 +53,18 @@ typedef struct parser {
   uint8_t dht_vals[8][256];
 } parser;
 
-static int DEZZ[64];   /* zig-zag position -> natural index (T.81 Fig. A.6) */
-static void init_dezz(void) {
-  int k = 0, s, i;
-  if (DEZZ[63] == 63) return;
-  for (s = 0; s < 15; s++) {
-    for (i = 0; i <= s; i++) {
-      int r = (s & 1) ? i : s - i, c = s - r;
-      if (r < 8 && c < 8) DEZZ[k++] = r*8 + c;
-    }
-  }
-}
+/* zig-zag position -> natural index (T.81 Fig. A.6); a constant, so the parsing threads of
+ * the pipeline and of jga_huff_prepare share it without initialisation order */
+static const int DEZZ[64] = {
+   0,  1,  8, 16,  9,  2,  3, 10,
+  17, 24, 32, 25, 18, 11,  4,  5,
+  12, 19, 26, 33, 40, 48, 41, 34,
+  27, 20, 13,  6,  7, 14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36,
+  29, 22, 15, 23, 30, 37, 44, 51,
+  58, 59, 52, 45, 38, 31, 39, 46,
+  53, 60, 61, 54, 47, 55, 62, 63
+};
 
 /* ---- segment parsing ---------------------------------------------------- */
 
@@ -76,7 +77,6 @@ static int rd16(parser *ps) {
 }
 
 static int parse_dqt(parser *ps, long end) {
-  init_dezz();
   while (ps->pos < end) {
     int b, pq, tq, k;
     b = rd8(ps);
@@ -554,7 +554,6 @@ static int decode_scan(parser *ps, const jga_geom *g, scan_out *so,
   long mcus = 0, total = (long)g->nhmb*g->nvmb;
   int rst = 0;
   long long index_base[3];
-  init_dezz();
   memset(&br, 0, sizeof(br));
   br.p = ps->buf + ps->pos;
   br.end = ps->buf + ps->size;

@@ -51,8 +51,29 @@ struct jga_huff_batch {
   int prepare_threads;
   jga_geom geom;
   std::vector<unsigned short> qtab;
+  std::vector<unsigned char> verdict;   // last prepare(), per image: 0 ok, 1 unusable, 2 host entropy stage
   int last_rounds;
 };
+
+// Same frame as far as every kernel is concerned: everything in a jga_geom but the restart
+// interval (which only shapes the segments).  Two samplings can agree in size, subsamp class
+// and plane total and still differ per plane (Y 4x2 / C 1x1 vs Y 2x4 / C 1x1).
+static bool same_geometry(const jga_geom &a, const jga_geom &b) {
+  if (a.width != b.width || a.height != b.height || a.nplanes != b.nplanes || a.subsamp != b.subsamp
+   || a.w0 != b.w0 || a.nhmb != b.nhmb || a.nvmb != b.nvmb || a.coef_shorts != b.coef_shorts
+   || a.coef_blocks != b.coef_blocks || a.yuv_bytes != b.yuv_bytes || a.rgb_bytes != b.rgb_bytes) {
+    return false;
+  }
+  for (int p = 0; p < a.nplanes; p++) {
+    const jga_plane_geom &x = a.plane[p], &y = b.plane[p];
+    if (x.hblocks != y.hblocks || x.vblocks != y.vblocks || x.xdec != y.xdec || x.ydec != y.ydec
+     || x.cstride != y.cstride || x.qidx != y.qidx || x.coef_off != y.coef_off
+     || x.data_off != y.data_off) {
+      return false;
+    }
+  }
+  return true;
+}
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1)/a*a; }
 
@@ -189,6 +210,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   if (nt > n) nt = n;
   bar.n = nt;
   b->qtab.assign((size_t)n*192, 0);
+  b->verdict.assign((size_t)n, 0);
   auto work = [&](int tid) {
     // phase A: headers, tables
     for (;;) {
@@ -197,21 +219,18 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
       if (rc != EXIT_SUCCESS) failed.fetch_add(1);
       if (rc == HJ_PREPARE_IRREGULAR) irregular.fetch_add(1);
+      b->verdict[i] = (unsigned char)(rc == EXIT_SUCCESS ? 0 : rc == HJ_PREPARE_IRREGULAR ? 2 : 1);
     }
     bar.wait();
     if (tid == 0 && failed.load()) stop.store(1);
     if (tid == 0 && !failed.load()) {
       size_t o = 0;
       for (int i = 0; i < n; i++) {
-        if (i && (prep[i].geom.coef_shorts != prep[0].geom.coef_shorts
-         || prep[i].geom.width != prep[0].geom.width || prep[i].geom.height != prep[0].geom.height
-         || prep[i].geom.subsamp != prep[0].geom.subsamp)) {
-          fatal.store(1);
-        }
+        if (i && !same_geometry(prep[i].geom, prep[0].geom)) fatal.store(1);
         scan_off[i] = (uint32_t)o;
         o += align_up((size_t)prep[i].avail + 16, 16);
       }
-      if ((long long)o > b->max_scan + 64ll*n) fatal.store(2);
+      if ((long long)o > b->max_scan + 64ll*n || o >= ((size_t)1 << 32)) fatal.store(2);   // (hj_image::scan_off is 32 bits)
       // subsequence length of this batch (the stuffed length is close enough to the clean one)
       b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o);
       for (int i = 0; i < n; i++) prep[i].sub_log2 = b->sub_log2;
@@ -227,6 +246,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       if (i >= n) break;
       if (hj_prepare_scan(jpegs[i], sizes[i], &prep[i], b->h_blob + scan_off[i]) != EXIT_SUCCESS) {
         failed.fetch_add(1);
+        b->verdict[i] = 1;
       }
     }
     bar.wait();
@@ -286,8 +306,8 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   }
   b->nimages = 0;
   if (irregular.load()) {
-    return jga_fail("huff: %d image(s) of the batch have Huffman tables too irregular for the GPU "
-     "entropy stage", irregular.load());
+    return jga_fail("huff: %d image(s) of the batch have Huffman tables too irregular (or a frame too "
+     "large) for the GPU entropy stage", irregular.load());
   }
   if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
   if (fatal.load() == 1) return jga_fail("huff: images of one batch must share a geometry");
@@ -305,6 +325,12 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   }
   if (geom) *geom = b->geom;
   return EXIT_SUCCESS;
+}
+
+// Per-image outcome of the last prepare(): 0 usable, 1 not (damaged / unsupported file), 2 a
+// valid file the device format cannot hold — its caller should take the host entropy stage.
+JGA_EXPORT int jga_huff_prepare_verdict(const jga_huff_batch *b, int i) {
+  return (i >= 0 && (size_t)i < b->verdict.size()) ? (int)b->verdict[(size_t)i] : -1;
 }
 
 // Host threads prepare() may use (0 = up to 64, one per image).
@@ -366,11 +392,25 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
   return EXIT_SUCCESS;
 }
 
+static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, hipStream_t st);
+
 JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  void *stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!b->nimages) return jga_fail("huff: nothing prepared");
   if (coef_stride < b->geom.coef_shorts) return jga_fail("huff: coef_stride too small");
+  const int rc = decode_batch(b, d_coef, coef_stride, st);
+  if (rc != EXIT_SUCCESS && !b->image_errors) {
+    // a launch or copy failed part-way: the plane clear on the side stream (and whatever
+    // rounds were queued) may still be running — the caller is free to reuse or release
+    // d_coef the moment this returns, so wait them out first
+    (void)hipStreamSynchronize(b->side);
+    (void)hipStreamSynchronize(st);
+  }
+  return rc;
+}
+
+static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, hipStream_t st) {
   hj_args A;
   memset(&A, 0, sizeof(A));
   A.images = (const hj_image *)(b->d_blob + b->off_images);

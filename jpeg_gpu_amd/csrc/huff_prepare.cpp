@@ -98,6 +98,15 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
   const jga_geom &g = out->geom;
   hj_image &im = out->im;
   memset(&im, 0, sizeof(im));
+  // The device stage keeps a bit position within one scan and a byte offset within one
+  // image's coefficient planes in 32 bits each (hj_reader::p, hj_block_out::offset): frames
+  // beyond that (a 40000 x 40000 4:2:0 frame has 4.8 GB of planes) are valid JPEG but not
+  // for it — the host entropy stage takes them, like tables outside the lookup format.
+  if (g.coef_shorts*2 >= (1ll << 32) || (long long)(size - d->scan_off)*8 >= (1ll << 32)) {
+    jga_fail("Frame too large for the GPU entropy stage (%lld bytes of planes, %d of scan)",
+     g.coef_shorts*2, size - d->scan_off);
+    return HJ_PREPARE_IRREGULAR;
+  }
   int slot = 0, l2_used = 0;
   memset(&out->tabs, 0, sizeof(out->tabs));
   for (int c = 0; c < g.nplanes; c++) {

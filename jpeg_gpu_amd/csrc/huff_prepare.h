@@ -30,8 +30,9 @@ struct hj_prepared {
 //   hj_prepare_scan  entropy-coded bytes -> clean stream written to `dst` (capacity >=
 //                    avail + 16; 16 pad bytes of 0xFF follow the stream) + restart segments
 // Both return EXIT_SUCCESS / EXIT_FAILURE (message via jga_fail); hj_prepare_head returns
-// HJ_PREPARE_IRREGULAR for a valid file whose Huffman tables need more level-2 blocks than
-// hj_tables has (the caller may then use the host entropy stage).
+// HJ_PREPARE_IRREGULAR for a valid file the device format cannot hold — Huffman tables that
+// need more level-2 blocks than hj_tables has, or a frame beyond the 32-bit bit positions /
+// plane offsets of the kernels (the caller may then use the host entropy stage).
 #define HJ_PREPARE_IRREGULAR 2
 int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out);
 int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsigned char *dst);

@@ -196,31 +196,39 @@ void run_worker(jga_pipeline *pl, worker *w, jga_job *jobs, int n,
     }
     unsigned char *dst = job->dev_out ? job->dev_out : s.d_out;
     const long long dst_cap = job->dev_out ? want_out : s.cap_out;
-    if (!HOK(hipMemcpyAsync(s.d_q, s.h_q, 3*64*sizeof(unsigned short), hipMemcpyHostToDevice, w->stream))) continue;
-    if (packed) {
-      const long long even = (nwords + 1) & ~1ll;
-      if (!HOK(hipMemcpyAsync(s.d_pack, s.h_pack, even*sizeof(short), hipMemcpyHostToDevice, w->stream))) continue;
-      if (!HOK(hipMemcpyAsync(s.d_index, s.h_index, nindex*sizeof(int), hipMemcpyHostToDevice, w->stream))) continue;
-      if (jga_unpack_batch(&g, 1, (const unsigned short *)s.d_pack, even, nwords, s.d_index, nindex,
-       s.d_coef, g.coef_shorts, w->stream) != EXIT_SUCCESS) {
-        continue;
+    // From here on asynchronous work reads the slot's pinned buffers: a failure part-way must
+    // drain the stream before the loop comes round and the host writes into them again.
+    auto queue_frame = [&]() -> bool {
+      if (!HOK(hipMemcpyAsync(s.d_q, s.h_q, 3*64*sizeof(unsigned short), hipMemcpyHostToDevice, w->stream))) return false;
+      if (packed) {
+        const long long even = (nwords + 1) & ~1ll;
+        if (!HOK(hipMemcpyAsync(s.d_pack, s.h_pack, even*sizeof(short), hipMemcpyHostToDevice, w->stream))) return false;
+        if (!HOK(hipMemcpyAsync(s.d_index, s.h_index, nindex*sizeof(int), hipMemcpyHostToDevice, w->stream))) return false;
+        if (jga_unpack_batch(&g, 1, (const unsigned short *)s.d_pack, even, nwords, s.d_index, nindex,
+         s.d_coef, g.coef_shorts, w->stream) != EXIT_SUCCESS) {
+          return false;
+        }
+        job->h2d_bytes = even*(long long)sizeof(short) + nindex*(long long)sizeof(int);
       }
-      job->h2d_bytes = even*(long long)sizeof(short) + nindex*(long long)sizeof(int);
-    }
-    else {
-      if (!HOK(hipMemcpyAsync(s.d_coef, s.h_coef, g.coef_shorts*sizeof(short), hipMemcpyHostToDevice, w->stream))) continue;
-      job->h2d_bytes = g.coef_shorts*(long long)sizeof(short);
-    }
-    if ((rgb ? jga_idct_rgb_batch(&g, 1, s.d_coef, g.coef_shorts, s.d_q, 1, dst, dst_cap, w->stream)
-     : jga_idct_yuv_batch(&g, 1, s.d_coef, g.coef_shorts, s.d_q, 1, dst, dst_cap, w->stream))
-     != EXIT_SUCCESS) {
+      else {
+        if (!HOK(hipMemcpyAsync(s.d_coef, s.h_coef, g.coef_shorts*sizeof(short), hipMemcpyHostToDevice, w->stream))) return false;
+        job->h2d_bytes = g.coef_shorts*(long long)sizeof(short);
+      }
+      if ((rgb ? jga_idct_rgb_batch(&g, 1, s.d_coef, g.coef_shorts, s.d_q, 1, dst, dst_cap, w->stream)
+       : jga_idct_yuv_batch(&g, 1, s.d_coef, g.coef_shorts, s.d_q, 1, dst, dst_cap, w->stream))
+       != EXIT_SUCCESS) {
+        return false;
+      }
+      if (copy_back && job->host_out
+       && !HOK(hipMemcpyAsync(s.h_out, dst, out_bytes, hipMemcpyDeviceToHost, w->stream))) {
+        return false;
+      }
+      return HOK(hipEventRecord(s.done, w->stream));
+    };
+    if (!queue_frame()) {
+      (void)hipStreamSynchronize(w->stream);
       continue;
     }
-    if (copy_back && job->host_out
-     && !HOK(hipMemcpyAsync(s.h_out, dst, out_bytes, hipMemcpyDeviceToHost, w->stream))) {
-      continue;
-    }
-    if (!HOK(hipEventRecord(s.done, w->stream))) continue;
     job->status = EXIT_SUCCESS;               // provisional; retire() may fail it
     s.job = job;
     s.out_bytes = out_bytes;
@@ -273,7 +281,9 @@ struct device_turn {                 // one of jga_pipeline::dev_slots, held for
 };
 
 // Decode jobs[0..m) as ONE batch of the GPU entropy stage.  Fails as a whole (mixed
-// geometry, a corrupt member, ...); the caller then retries the members one by one.
+// geometry, an unparsable member, ...): GROUP_REJECTED when prepare() turned the group down
+// (its per-member verdicts then say who is to blame), EXIT_FAILURE for anything else.
+enum { GROUP_REJECTED = 2 };
 int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads) {
   const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
   const bool copy_back = pl->cfg.copy_back != 0;
@@ -301,7 +311,8 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   bool host_entropy = false, damaged = false;
   jpeg_header hdr;
   if (jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream) != EXIT_SUCCESS) {
-    if (m != 1 || !strstr(jga_last_error(), "too irregular")) return EXIT_FAILURE;
+    if (m != 1) return GROUP_REJECTED;              // run_lane looks at the per-member verdicts
+    if (jga_huff_prepare_verdict(l.hb, 0) != 2) return EXIT_FAILURE;
     if (jga_parse_header(jobv[0]->jpeg, jobv[0]->size, &hdr) != EXIT_SUCCESS
      || jga_geom_from_header(&g, &hdr) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
@@ -432,9 +443,22 @@ void run_lane(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *g
     if (gi >= (int)groups->size()) break;
     std::vector<jga_job *> &grp = (*groups)[gi];
     const int m = (int)grp.size();
-    if (lane_group(pl, *l, grp.data(), m, threads) == EXIT_SUCCESS) continue;
-    if (m == 1) continue;
-    for (int i = 0; i < m; i++) (void)lane_group(pl, *l, &grp[i], 1, 1);   // isolate the bad one(s)
+    const int rc = lane_group(pl, *l, grp.data(), m, threads);
+    if (rc == EXIT_SUCCESS || m == 1) continue;
+    // One member with an unparsable header, or with Huffman tables outside the device lookup
+    // format, must not cost the other 47 their batch: the members prepare() found usable go
+    // again as one group, only the others are taken singly (a lone member with verdict 2
+    // gets the host entropy stage inside lane_group).
+    std::vector<jga_job *> good, rest;
+    for (int i = 0; i < m; i++) {
+      (rc == GROUP_REJECTED && jga_huff_prepare_verdict(l->hb, i) == 0 ? good : rest).push_back(grp[i]);
+    }
+    if (!rest.empty() && good.size() > 1
+     && lane_group(pl, *l, good.data(), (int)good.size(), threads) == EXIT_SUCCESS) {
+      good.clear();
+    }
+    for (jga_job *j : good) (void)lane_group(pl, *l, &j, 1, 1);
+    for (jga_job *j : rest) (void)lane_group(pl, *l, &j, 1, 1);
   }
 }
 

@@ -221,8 +221,8 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
         jga_huff_set_threads(c->hb, 1);
       }
       if (jga_huff_prepare(c->hb, &c->buf, &c->size, 1, &g2, c->stream) != EXIT_SUCCESS) {
-        if (!strstr(jga_last_error(), "too irregular")) return EXIT_FAILURE;
-        on_gpu = 0;                        // tables outside the device lookup format
+        if (jga_huff_prepare_verdict(c->hb, 0) != 2) return EXIT_FAILURE;
+        on_gpu = 0;                        // tables / frame size outside the device format
       }
       else if (jga_huff_decode(c->hb, c->d_coef, g->coef_shorts, c->stream) != EXIT_SUCCESS) {
         return EXIT_FAILURE;

@@ -22,7 +22,7 @@ EXPORTED = [
     "jga_stream_sync", "jga_set_device", "jga_stream_create", "jga_stream_destroy",
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
-    "jga_huff_decode", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
+    "jga_huff_decode", "jga_huff_prepare_verdict", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
     "jga_huff_set_threads",
 ]
 
@@ -100,6 +100,7 @@ L.jga_huff_destroy.argtypes = [_vp]
 L.jga_huff_destroy.restype = None
 L.jga_huff_prepare.argtypes = [_vp, C.POINTER(C.c_char_p), C.POINTER(_i), _i, _G, _vp]
 L.jga_huff_decode.argtypes = [_vp, _vp, _ll, _vp]
+L.jga_huff_prepare_verdict.argtypes = [_vp, _i]
 L.jga_huff_upload_bytes.argtypes = [_vp]
 L.jga_huff_upload_bytes.restype = _ll
 L.jga_huff_last_rounds.argtypes = [_vp]

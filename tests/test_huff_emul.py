@@ -119,3 +119,19 @@ def test_streams_that_never_fall_into_step_and_the_host_walk(emul, lib, synth, s
         assert rc == 0 and emul.huff_emul_walked() == 0
     finally:
         emul.huff_emul_set_assist(0)
+
+
+def test_frames_beyond_32_bit_offsets_are_handed_to_the_host_stage(emul, synth):
+    """The kernels keep plane byte offsets and scan bit positions in 32 bits; prepare() must
+    turn away (verdict 2 = "host entropy stage") a frame whose planes reach 4 GiB instead of
+    letting the offsets wrap.  Only the header is looked at, so a small file with
+    its SOF0 dimensions patched will do."""
+    emul.huff_emul_prepare_head.argtypes = [C.c_char_p, C.c_int]
+    data = bytearray(synth.synthetic_jpeg(64, 48, "444", seed=3))
+    assert emul.huff_emul_prepare_head(bytes(data), len(data)) == 0
+    sof = data.index(b"\xff\xc0")
+    for dims, want in (((30000, 23000), 0),          # 30000 x 23000 4:4:4: 4.14e9 B < 2^32
+                       ((30000, 24000), 2),          # 4.32e9 B >= 2^32
+                       ((65500, 65500), 2)):
+        data[sof + 5:sof + 9] = bytes([dims[1] >> 8, dims[1] & 255, dims[0] >> 8, dims[0] & 255])
+        assert emul.huff_emul_prepare_head(bytes(data), len(data)) == want, dims

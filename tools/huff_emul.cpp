@@ -49,6 +49,14 @@ int huff_emul_set_sub(int bytes) {
   return 0;
 }
 
+// hj_prepare_head's verdict on a file (0 usable, 1 not, 2 = HJ_PREPARE_IRREGULAR: valid, but
+// the device format cannot hold it — the host entropy stage takes it).
+extern "C" __attribute__((visibility("default")))
+int huff_emul_prepare_head(const unsigned char *jpeg, int size) {
+  hj_prepared P;
+  return hj_prepare_head(jpeg, size, &P);
+}
+
 static int g_assist_after = 0;
 // After this many rounds without settling, the host walk of huff_api.cpp's assist_chains()
 // (hj_walk_unsettled) is applied once per further round; 0 = never.  Returns walked
