@@ -2,28 +2,43 @@
 """bench.py — headline benchmark of the JPEG block-decode path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE pass of the hot path (fused dequantise + 2x1-D IDCT + chroma
-upsample + YCbCr->RGB kernel) over one batch of synthetic 3840x2160 4:2:0 q90
-baseline JPEGs whose packed coefficient planes are ALREADY RESIDENT IN HBM when
-the timed region starts; the RGB8 output stays in HBM.  Images are independent:
-each rank (one per GPU) owns its own batch, there is no data-path collective
-(weak scaling); the only cross-rank traffic is the timing barrier / max.
+With N > 1 and no torchrun environment this program starts its own N ranks (one process per
+GPU, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` of itself on
+127.0.0.1); started under torchrun by somebody else it simply is one of the ranks.
 
-Rank 0 prints ONE JSON line: BASELINE.json's metric (Mpixel/s) as `value`, plus
-  roofline      achieved algorithmic HBM GB/s of the fused kernel, measured live
-                with HIP events on the launch stream over the timed region
-  cpu_baseline  the CPU port of the same path (oracle/, whole decode to RGB) timed
-                on this box's host cores on a bounded sample (rank 0, N=1 only)
-  e2e           supplementary: JPEG bytes in host RAM -> RGB, through the
-                pipelined decoder (host Huffman threads + pinned H2D + kernel);
-                PCIe/host-inclusive, never `value`.
+The metric is BASELINE.json's: Mpixel/s END-TO-END — from JPEG file bytes in host RAM to RGB8
+pixels in HBM (what a frame is in the reference: src/jpeg_gpu.c:1231-1237,
+its cpu/gpu split 1437-1458) — on 3840x2160 4:2:0 q90 baseline files.  A "step" is ONE
+batch of `--batch` (48) images per GPU through the pipelined decoder (jga_pipeline,
+transport 2): host threads parse markers and unstuff the scans into pinned memory, the
+compressed bytes cross PCIe, the GPU does the Huffman decode and the fused dequantise + IDCT
++ upsample + RGB kernel.  The timed region is exactly K such batches per rank, streamed
+through the rank's lanes, bracketed by barrier + device synchronise; `value` = pixels of
+all ranks / max-over-ranks wall time.  Images are independent: each rank owns its own
+images, its own share of the host cores (those of its GPU's NUMA node) and there is no
+data-path collective (weak scaling); RCCL carries the barrier and the MAX only.
+
+Rank 0 prints ONE JSON line.  Beside the contract keys:
+  roofline      the fused IDCT+RGB kernel alone on coefficient planes resident in HBM:
+                algorithmic bytes / launch time from HIP events on the launch stream
+                (`kernel_Mpixel_s` is that kernel's pixel rate — NOT the end-to-end value)
+  e2e           the same end-to-end measurement with the other transports: the north-star
+                design (host Huffman threads + pinned hipMemcpyAsync + kernel), with the pixels
+                copied back to host RAM, PACK words over PCIe
+  cpu_baseline  (N = 1) the CPU paths timed on this box's host cores in the same run, warm,
+                best of several rounds, one frame loop per core: the reference's own
+                xjpeg + dct.c compiled from its sources (oracle/_ref, YUV stage — it has no
+                CPU RGB stage), libjpeg-turbo through LIBJPEG_DECODE_CTX_VTBL (RGB), and the
+                oracle port of the whole path (RGB)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -33,36 +48,85 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 W, H, SAMPLING, QUALITY = 3840, 2160, "420", 90
+METRIC = "Mpixel/s end-to-end decode, 4K 4:2:0 baseline JPEG, at 1/2/4/8 MI355X"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=48, help="images per GPU per step")
-    ap.add_argument("--distinct", type=int, default=6, help="distinct synthetic images")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic images per rank")
+    ap.add_argument("--lanes", type=int, default=6, help="batches in flight per GPU")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="host threads per rank (0 = this rank's share of the cores)")
+    ap.add_argument("--no-pin", action="store_true", help="leave the ranks' CPU affinity alone")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the supplementary e2e leg")
-    ap.add_argument("--prewarm", type=float, default=0.5,
-                    help="seconds of untimed launches before warm-up (GPU clock ramp)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the other-transports leg")
     ap.add_argument("--no-pack", action="store_true", help="skip the PACK expansion leg")
     ap.add_argument("--no-other", action="store_true", help="skip the other-kernels leg")
-    ap.add_argument("--e2e-images", type=int, default=96)
-    ap.add_argument("--e2e-threads", type=int, default=0, help="0 = min(cores, 48)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-gpu-entropy", action="store_true",
-                    help="skip the supplementary all-on-GPU leg (Huffman on the GPU)")
-    return ap.parse_args()
+    ap.add_argument("--no-gpu-entropy", action="store_true", help="skip the device-only breakdown leg")
+    ap.add_argument("--prewarm", type=float, default=0.5,
+                    help="seconds of untimed kernel launches before the roofline leg (clock ramp)")
+    ap.add_argument("--kernel-reps", type=int, default=50, help="launches timed in the roofline leg")
+    ap.add_argument("--cpu-rounds", type=int, default=5, help="cpu_baseline: best of this many rounds")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="cpu_baseline: frames per core per round")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="collect roofline.traffic now (rocprofv3 --pmc child passes) instead of "
+                         "quoting profiles/pmc_latest.json")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, report who they are and which CPUs they own, exit "
+                         "(gloo; needs no GPU)")
+    return ap.parse_args(argv)
 
 
-def make_inputs(synth, n, rank):
+# ---- launcher ---------------------------------------------------------------------------------
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` run plainly: become the launcher of N ranks of this same file."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:9])))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(args, rank, local_rank, world):
+    """Who am I, which CPUs are mine — the launch path without the GPU work (CPU test)."""
+    import torch.distributed as dist
+    from jpeg_gpu_amd import shard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    pin = {} if args.no_pin else shard.pin_rank_to_gpu_node(local_rank, world)
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
+          "cpus": sorted(os.sched_getaffinity(0)), "pin": pin}
+    everyone = [me]
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": everyone}), flush=True)
+    return 0
+
+
+# ---- inputs -----------------------------------------------------------------------------------
+
+def make_inputs(synth, n, rank, threads):
     seeds = [1234 + rank * 1000 + i for i in range(n)]
-    with ThreadPoolExecutor(max_workers=min(n, 8)) as ex:
+    with ThreadPoolExecutor(max_workers=max(1, min(n, threads))) as ex:
         return list(ex.map(lambda s: synth.synthetic_jpeg(W, H, SAMPLING, QUALITY, seed=s),
                            seeds))
 
@@ -74,79 +138,197 @@ def device_facts(torch, dev):
             "clock_MHz": getattr(p, "clock_rate", 0) // 1000 or None}
 
 
-def cpu_baseline(jpegs, seconds):
-    """The CPU port of the whole path (oracle.orc_decode_rgb: Huffman + float IDCT
-    + clamp + upsample + RGB), one image per thread on the host cores; bounded."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "?"
+
+
+# ---- CPU baselines ----------------------------------------------------------------------------
+
+def all_core_rate(make_worker, threads, frames, rounds):
+    """`threads` frame loops side by side, each `frames` frames per round, started together;
+    best round of `rounds` (the first one also warms caches and buffers).  make_worker(i)
+    returns the loop of thread i as a callable taking the frame count."""
+    loops = [make_worker(i) for i in range(threads)]
+    closers = [getattr(l, "close", None) for l in loops]
+    best = None
+    for _ in range(rounds):
+        gate = threading.Barrier(threads + 1)
+        done = []
+
+        def body(loop):
+            gate.wait()
+            loop(frames)
+            done.append(time.perf_counter())
+        ts = [threading.Thread(target=body, args=(l,)) for l in loops]
+        for t in ts:
+            t.start()
+        gate.wait()
+        t0 = time.perf_counter()
+        for t in ts:
+            t.join()
+        dt = max(done) - t0
+        best = dt if best is None or dt < best else best
+    for c in closers:
+        if c:
+            c()
+    return threads * frames * W * H / best / 1e6, best
+
+
+def cpu_baseline(jpegs, rounds, frames):
+    """north_star: "the xjpeg/libjpeg-turbo CPU path timed on the same box's host cores in the
+    same run (core count stated)".  One frame loop per logical CPU this process may use, every
+    loop on its own image; warm; best of `rounds`."""
     import numpy as np
     import oracle
-    orc = oracle.Oracle()
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    threads = max(1, min(ncpu, 64))
-    # single core first: calibrates the sample size
-    info = orc.parse(jpegs[0])
-    scratch = np.empty(info.hblocks[0] * info.vblocks[0] * 64 * 3, np.uint8)
-    rgb = np.empty((H, W, 3), np.uint8)
-    t0 = time.perf_counter()
-    orc.decode_rgb(jpegs[0], scratch, rgb)
-    t1 = time.perf_counter() - t0
-    # ~`seconds` of total CPU work, spread over the threads
-    per_thread = max(1, min(16, int(round(seconds / max(t1, 1e-3) / threads))))
+    from jpeg_gpu_amd import abi, lib
+    cpus = len(os.sched_getaffinity(0))
+    threads = max(1, cpus)
+    res = {"unit": "Mpixel/s", "cores": threads, "cpu_model": cpu_model(),
+           "method": "one frame loop per logical CPU (reset -> header -> decode, as "
+                     "src/jpeg_gpu.c:1231-1237), %d frames per loop per round, best of %d rounds, "
+                     "each loop on its own 3840x2160 4:2:0 q90 file" % (frames, rounds)}
+    t_all = time.perf_counter()
 
-    def work(i):
-        sc = np.empty_like(scratch)
-        out = np.empty_like(rgb)
-        for k in range(per_thread):
-            orc.decode_rgb(jpegs[(i + k) % len(jpegs)], sc, out)
-        return per_thread
-
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        done = sum(ex.map(work, range(threads)))
-    dt = time.perf_counter() - t0
-    res = {
-        "value": round(done * W * H / dt / 1e6, 1), "unit": "Mpixel/s", "cores": threads,
-        "kind": "port",
-        "sample": "%d decodes of %dx%d 4:2:0 q90 JPEGs to RGB on %d threads "
-                  "(oracle.orc_decode_rgb, %.1f s)" % (done, W, H, threads, dt),
-        "single_core_value": round(W * H / t1 / 1e6, 1),
-    }
-    # libjpeg-turbo where the box has it (Pillow's bundled copy): a sanity line, not the oracle —
-    # its integer IDCT differs from src/dct.c by +-1 on ~2 % of samples (SURVEY.md 8c)
-    try:
-        import io
-        from PIL import Image, features
-        best = 1e9
-        for _ in range(5):
-            t0 = time.perf_counter()
-            Image.open(io.BytesIO(jpegs[0])).convert("RGB").load()
-            best = min(best, time.perf_counter() - t0)
-        res["libjpeg_turbo_single_core"] = {
-            "value": round(W * H / best / 1e6, 1), "unit": "Mpixel/s",
-            "note": "Pillow %s (libjpeg-turbo %s), full RGB decode, best of 5" % (
-                Image.__version__, features.version("libjpeg_turbo") or "?")}
-    except Exception as e:  # not importable on this box
-        res["libjpeg_turbo_single_core"] = {"value": None, "note": "not available (%s)" % type(e).__name__}
-    if oracle.Reference.available():
+    # (1) the reference's own code, compiled from its sources: xjpeg + dct.c, YUV stage
+    if oracle.Reference.available() and hasattr(oracle.Reference().lib, "ref_frames_yuv"):
         ref = oracle.Reference()
+        rate, dt = all_core_rate(lambda i: (lambda n, d=jpegs[i % len(jpegs)]: ref.frames_yuv(d, n)),
+                                 threads, frames, rounds)
         t0 = time.perf_counter()
-        ref.decode(jpegs[0], oracle.YUV)
-        res["reference_yuv_single_core"] = {
-            "value": round(W * H / (time.perf_counter() - t0) / 1e6, 1), "unit": "Mpixel/s",
-            "note": "the reference's own xjpeg+dct.c compiled (oracle/_ref), YUV stage "
-                    "(it has no CPU RGB stage), 1 decode incl. image_init"}
+        ref.frames_yuv(jpegs[0], 2)
+        one = 2 * W * H / (time.perf_counter() - t0) / 1e6
+        res["reference_xjpeg_yuv"] = {
+            "value": round(rate, 1), "single_core_value": round(one, 1), "seconds": round(dt, 3),
+            "note": "the reference's xjpeg.c + dct.c compiled unmodified (oracle/_ref): Huffman + "
+                    "dequantise + float IDCT + clamp into Y/Cb/Cr planes (it has no CPU RGB stage)"}
+    # (2) libjpeg-turbo behind the reference's other plugin table, RGB stage
+    if lib.L.jga_libjpeg_available():
+        def lj_worker(i):
+            d = lib.Decoder(jpegs[i % len(jpegs)], lib.LIBJPEG_VTBL)
+            d.read_header()
+            d.init_image()
+
+            def loop(n):
+                for _ in range(n):
+                    d.reset()
+                    d.read_header()
+                    d.decode(abi.JPEG_DECODE_RGB)
+            loop.close = d.close                    # 62 MB of image buffers per loop
+            return loop
+        rate, dt = all_core_rate(lj_worker, threads, frames, rounds)
+        d1 = lj_worker(0)
+        d1(1)
+        t0 = time.perf_counter()
+        d1(2)
+        one = 2 * W * H / (time.perf_counter() - t0) / 1e6
+        d1.close()
+        res["libjpeg_turbo_rgb"] = {
+            "value": round(rate, 1), "single_core_value": round(one, 1), "seconds": round(dt, 3),
+            "note": "system libjpeg.so.8 (libjpeg-turbo) through LIBJPEG_DECODE_CTX_VTBL: ISLOW "
+                    "IDCT, plain upsampling, RGB out (src/jpeg_wrap.c:196-222); a different "
+                    "integer IDCT, so a speed reference, not the parity oracle"}
+    else:
+        res["libjpeg_turbo_rgb"] = {"value": None, "note": "libjpeg.so.8 not installed on this box"}
+    # (3) the oracle port of the whole path (Huffman + float IDCT + clamp + upsample + RGB)
+    orc = oracle.Oracle()
+    info = orc.parse(jpegs[0])
+    need = sum(info.hblocks[i] * info.vblocks[i] * 64 for i in range(info.ncomps))
+
+    def port_worker(i):
+        sc, out = np.empty(need, np.uint8), np.empty((H, W, 3), np.uint8)
+        d = jpegs[i % len(jpegs)]
+
+        def loop(n):
+            for _ in range(n):
+                orc.decode_rgb(d, sc, out)
+        return loop
+    rate, dt = all_core_rate(port_worker, threads, frames, rounds)
+    p1 = port_worker(0)
+    t0 = time.perf_counter()
+    p1(2)
+    one = 2 * W * H / (time.perf_counter() - t0) / 1e6
+    res["oracle_port_rgb"] = {
+        "value": round(rate, 1), "single_core_value": round(one, 1), "seconds": round(dt, 3),
+        "note": "oracle/oracle.c restatement of the whole path incl. upsample + RGB"}
+    # the headline CPU number: the reference's own path where its build is here, else the port
+    if "reference_xjpeg_yuv" in res:
+        res["kind"], res["value"] = "reference", res["reference_xjpeg_yuv"]["value"]
+        what = "reference xjpeg YUV stage"
+    else:
+        res["kind"], res["value"] = "port", res["oracle_port_rgb"]["value"]
+        what = "oracle port, RGB"
+    res["sample"] = "%s: %d loops x %d frames of %dx%d per round, %d rounds, %.1f s in all " \
+                    "three CPU paths" % (what, threads, frames, W, H, rounds,
+                                         time.perf_counter() - t_all)
     return res
 
 
+# ---- HBM traffic of the fused kernel (PMC) ------------------------------------------------------
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                              timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def measure_traffic(batch):
+    """rocprofv3 --pmc passes over a child that launches the fused kernel on a resident batch
+    (tools/pmc_traffic.py; counters and corrections as MI355X_MICROARCH.md prescribes).  Writes
+    profiles/pmc_latest.json and returns it, or None when the tool is not on the box."""
+    tool = os.path.join(ROOT, "tools", "pmc_traffic.py")
+    try:
+        r = subprocess.run([sys.executable, tool, "--batch", str(batch)], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+        line = [l for l in r.stdout.splitlines() if l.startswith("PMC ")]
+        if r.returncode == 0 and line:
+            return json.loads(line[0][4:])
+        log("bench.py: traffic measurement failed:\n" + r.stderr[-1500:])
+    except Exception as e:           # no rocprofv3, timeout, ...
+        log("bench.py: traffic measurement unavailable (%s)" % e)
+    return None
+
+
+def quoted_traffic(batch):
+    """roofline.traffic from the committed PMC summary, with where and when it was taken."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return None, {}
+    if pmc.get("batch") != batch or pmc.get("workload") != "%dx%d %s" % (W, H, SAMPLING):
+        return None, {}
+    prov = {"source": "profiles/pmc_latest.json", "measured_in_this_run": False,
+            "taken_at_head": pmc.get("head"), "taken_on": pmc.get("date"),
+            "from": pmc.get("source")}
+    valu = {k: pmc[k] for k in ("valu_insts_per_wave", "valu_busy_4clk") if k in pmc}
+    return pmc.get("hbm_bytes_per_launch"), dict(provenance=prov, valu=valu)
+
+
+# ---- main -------------------------------------------------------------------------------------
+
 def main():
-    args = parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            log("bench.py: --gpus %d needs torch.distributed.run with %d ranks; "
-                "running rank-local only" % (args.gpus, args.gpus))
+        log("bench.py: --gpus %d but the launcher made %d rank(s); reporting n_gpus = %d"
+            % (args.gpus, world, world))
         args.gpus = world
+    if args.dry_launch:
+        sys.exit(dry_launch(args, rank, local_rank, world))
 
     import torch                      # first: its bundled HIP runtime must be THE runtime
     import torch.distributed as dist
@@ -156,8 +338,15 @@ def main():
     __graft_entry__.build()
     from jpeg_gpu_amd import abi, lib, shard, synth
 
-    if not torch.cuda.is_available() or lib.device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible (no CPU fallback exists)")
+    if not torch.cuda.is_available() or lib.device_count() < world:
+        raise SystemExit("bench.py: %d HIP device(s) visible, %d needed (no CPU fallback exists)"
+                         % (lib.device_count() if torch.cuda.is_available() else 0, world))
+    # this rank's host cores: those of its GPU's NUMA node, shared with the ranks next door
+    pin = None
+    if not args.no_pin:
+        ids = [lib.device_pci_bus_id(i) for i in range(world)]
+        pin = shard.pin_rank_to_gpu_node(local_rank, world, ids)
+    my_cpus = len(os.sched_getaffinity(0))
     torch.cuda.set_device(local_rank)
     lib.check(lib.L.jga_set_device(local_rank))
     if world > 1:
@@ -165,107 +354,167 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
-    # ---- inputs: synthetic JPEGs -> host entropy stage -> coefficient planes in HBM
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lib.check(lib.L.jga_stream_sync(None))
+
+    # ---- inputs: distinct synthetic files in host RAM (214 MB per rank at the defaults: they
+    # do not fit any cache level, so the host side reads them from DRAM like real traffic)
     t_setup = time.perf_counter()
-    jpegs = make_inputs(synth, args.distinct, rank)
+    jpegs = make_inputs(synth, args.distinct, rank, min(my_cpus, 64))
     hdr, g = lib.geom_of(jpegs[0])
-    B = args.batch
+    B, K, Wm = args.batch, args.steps, args.warmup
+    nthreads = args.host_threads or max(1, min(my_cpus, 96))
+    log("rank %d: %d files (%.1f MB) in %.1f s; %d host threads%s" % (
+        rank, len(jpegs), sum(map(len, jpegs)) / 1e6, time.perf_counter() - t_setup, nthreads,
+        ", cpus %s of node %s" % (pin["cpu_list"], pin["numa_node"]) if pin else ""))
+
+    # ---- headline: JPEG bytes in host RAM -> RGB8 in HBM, K batches of B images per rank ----
+    pl = lib.Pipeline(device=local_rank, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
+                      copy_back=False, transport=2, batch=B, depth=args.lanes)
+    cyc = lambda n, o=0: [jpegs[(o + i) % len(jpegs)] for i in range(n)]
+    setup_jobs = lib.Pipeline.make_jobs(cyc(args.lanes * B))          # lanes allocate their buffers
+    warm_jobs = lib.Pipeline.make_jobs(cyc(Wm * B, 7)) if Wm > 0 else None
+    timed_jobs = lib.Pipeline.make_jobs(cyc(K * B, 13))
+    if pl.run_jobs(setup_jobs) != 0:
+        raise SystemExit("bench.py: pipeline failed: " + lib.L.jga_last_error().decode())
+    if warm_jobs is not None:
+        pl.run_jobs(warm_jobs)                                       # W untimed steps
+    fence()
+    t0 = time.perf_counter()
+    rc = pl.run_jobs(timed_jobs)                                     # exactly K steps; returns when
+    fence()                                                          # every output is complete
+    dt = time.perf_counter() - t0
+    if rc != 0 or any(j.status != 0 for j in timed_jobs):
+        raise SystemExit("bench.py: a job of the timed region failed: " + lib.L.jga_last_error().decode())
+    h2d_per_image = sum(j.h2d_bytes for j in timed_jobs) // len(timed_jobs)
+    rate, _, dt = shard.aggregate_throughput(K * B * W * H, dt, dist if world > 1 else None,
+                                             device="cuda")
+    # the pixels it produces, against the oracle (outside the timed region): two files, decoded
+    # by the same pipeline into buffers of ours
+    ok = True
+    if rank == 0:
+        import oracle
+        orc = oracle.Oracle()
+        bufs = [lib.DeviceBuffer(g.rgb_bytes) for _ in range(2)]
+        chk = lib.Pipeline.make_jobs(cyc(2, 5), dev_outs=[b.ptr for b in bufs])
+        ok = pl.run_jobs(chk) == 0
+        for i, b in enumerate(bufs):
+            want = orc.decode_rgb(jpegs[(5 + i) % len(jpegs)])[1].reshape(-1)
+            ok = ok and bool(np.array_equal(b.download(g.rgb_bytes), want))
+            b.free()
+        if not ok:
+            raise SystemExit("bench.py: pipeline output differs from the oracle")
+    pl.close()
+
+    # ---- roofline: the fused kernel alone, coefficient planes resident in HBM ----
     cstride = (g.coef_shorts * 2 + 255) // 256 * 128          # shorts, 256-B aligned
     ostride = (g.rgb_bytes + 255) // 256 * 256
     d_coef = lib.DeviceBuffer(cstride * 2 * B)
     d_q = lib.DeviceBuffer(3 * 64 * 2 * B)
     d_out = lib.DeviceBuffer(ostride * B)
-    coefs = [lib.entropy_decode(j, g) for j in jpegs]
+    ncoef = min(len(jpegs), 6)
+    coefs = [lib.entropy_decode(j, g) for j in jpegs[:ncoef]]
     qt = np.zeros((B, 3, 64), np.uint16)
     for i in range(B):
-        d_coef.upload(coefs[i % len(coefs)], offset=i * cstride * 2)
-        qt[i] = lib.qtab_of(lib.parse_header(jpegs[i % len(jpegs)]))
+        d_coef.upload(coefs[i % ncoef], offset=i * cstride * 2)
+        qt[i] = lib.qtab_of(lib.parse_header(jpegs[i % ncoef]))
     d_q.upload(qt)
     stream = lib.L.jga_stream_create()
-    log("rank %d: setup %.1f s, batch %d x %dx%d, coef %.1f MB + rgb %.1f MB per image"
-        % (rank, time.perf_counter() - t_setup, B, W, H, g.coef_shorts * 2 / 1e6,
-           g.rgb_bytes / 1e6))
 
     def launch(reps):
         ms = C.c_float()
         lib.check(lib.L.jga_time_idct_batch(C.byref(g), B, d_coef.ptr, cstride, d_q.ptr, 1,
                                             d_out.ptr, ostride, 1, reps, stream, C.byref(ms)))
         return ms.value
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # power state: a cold GPU needs a few hundred ms of work before its clocks settle (part of
-    # setup, like uploading the inputs; the W warm-up steps and the K timed steps follow)
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm:
+    while time.perf_counter() - t_pre < args.prewarm:     # clocks settle (a cold GPU reads ~5 % low)
         launch(20)
-    if args.warmup > 0:
-        launch(args.warmup)
-    fence()
-    t0 = time.perf_counter()
-    ev_ms = launch(args.steps)            # K launches, HIP events on `stream`
-    fence()
-    dt = time.perf_counter() - t0
-    # whole-job rate = pixels of all ranks / max time over ranks (no data-path collective)
-    rate, _, dt = shard.aggregate_throughput(args.batch * W * H * args.steps, dt,
-                                              dist if world > 1 else None, device="cuda")
+    launch(5)
+    ev_ms = launch(args.kernel_reps)                      # HIP events on `stream` around the launches
     if world > 1:
         e = torch.tensor([ev_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         ev_ms = float(e.item())
-
-    # spot-check the last step's output against the oracle (outside the timed region)
-    ok = True
     if rank == 0:
         import oracle
         want = oracle.Oracle().decode_rgb(jpegs[0])[1].reshape(-1)
-        got = d_out.download(g.rgb_bytes, offset=0)
-        ok = bool(np.array_equal(got, want))
-        if not ok:
-            raise SystemExit("bench.py: device output differs from the oracle")
-
-    value = rate / 1e6
+        if not np.array_equal(d_out.download(g.rgb_bytes, offset=0), want):
+            raise SystemExit("bench.py: kernel output differs from the oracle")
     alg_bytes = B * (g.coef_blocks * 128 + g.rgb_bytes)
     achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
-    traffic, valu = None, {}
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path))
-            if pmc.get("batch") == B and pmc.get("workload") == "%dx%d %s" % (W, H, SAMPLING):
-                traffic = pmc.get("hbm_bytes_per_launch")
-                valu = {k: pmc[k] for k in ("valu_insts_per_wave", "valu_busy_4clk") if k in pmc}
-        except Exception:
-            traffic = None
+    traffic, extra = quoted_traffic(B)
+    if args.measure_traffic and rank == 0 and world == 1:
+        pmc = measure_traffic(B)
+        if pmc:
+            traffic = pmc.get("hbm_bytes_per_launch")
+            extra = dict(provenance={"source": "rocprofv3 --pmc child passes of this run "
+                                               "(tools/pmc_traffic.py)", "measured_in_this_run": True,
+                                     "taken_at_head": pmc.get("head")},
+                         valu={k: pmc[k] for k in ("valu_insts_per_wave", "valu_busy_4clk") if k in pmc})
+
+    # ---- the north-star transport at every N: host Huffman threads -> pinned hipMemcpyAsync ->
+    # fused kernel (entropy.c on this rank's cores; 24.9 MB of planes per image over PCIe)
+    e2e = {}
+    if not args.no_e2e:
+        nthr = max(1, min(my_cpus, 128))       # ~94 threads fill the PCIe link (195 Mpixel/s each)
+        n0 = max(96, 4 * nthr)
+        pl0 = lib.Pipeline(device=local_rank, nthreads=nthr, out=abi.JPEG_DECODE_RGB,
+                           copy_back=False, transport=0)
+        j_warm, j_run = lib.Pipeline.make_jobs(cyc(2 * nthr)), lib.Pipeline.make_jobs(cyc(n0, 3))
+        pl0.run_jobs(j_warm)
+        fence()
+        t0 = time.perf_counter()
+        rc0 = pl0.run_jobs(j_run)
+        fence()
+        r0, _, t_ns = shard.aggregate_throughput(n0 * W * H, time.perf_counter() - t0,
+                                                 dist if world > 1 else None, device="cuda")
+        pl0.close()
+        e2e["north_star_host_huffman_to_rgb_hbm"] = {
+            "value": round(r0 / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": n0,
+            "host_threads_per_gpu": nthr, "ok": rc0 == 0,
+            "h2d_bytes_per_image": int(g.coef_shorts * 2),
+            "note": "north_star's design: Huffman on the host (csrc/entropy.c), dense coefficient "
+                    "planes over PCIe, fused kernel; aggregated over ranks like `value`"}
+
     out = {
-        "metric": "Mpixel/s end-to-end decode, 4K 4:2:0 baseline JPEG",
-        "value": round(value, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "metric": METRIC,
+        "value": round(rate / 1e6, 1), "unit": "Mpixel/s", "n_gpus": world, "steps": K,
+        "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "3840x2160 4:2:0 q90 baseline JPEG; step = fused dequant+IDCT+"
-                        "upsample+RGB over a batch of %d images per GPU, packed int16 "
-                        "coefficient planes resident in HBM -> RGB8 in HBM" % B,
-            "batch_per_gpu": B, "distinct_images": len(jpegs),
-            "parallelism": "image-sharded x%d, no collectives" % world,
-            "kernel": lib.L.jga_kernel_name(C.byref(g), 1).decode(),
+            "workload": "3840x2160 4:2:0 q90 baseline JPEG files in host RAM -> RGB8 in HBM "
+                        "(end to end); step = one batch of %d images per GPU through the pipelined "
+                        "decoder: host marker parse + unstuffing into pinned memory, compressed "
+                        "bytes over PCIe, GPU Huffman decode + fused dequant/IDCT/upsample/RGB "
+                        "kernel; %d steps streamed through %d lanes per GPU" % (B, K, args.lanes),
+            "batch_per_gpu": B, "distinct_images_per_gpu": len(jpegs),
+            "images_timed_per_gpu": K * B, "h2d_bytes_per_image": int(h2d_per_image),
+            "parallelism": "image-sharded x%d, one process per GPU, no data-path collective" % world,
+            "host_threads_per_gpu": nthreads, "cpu_pinning": pin,
             "bit_exact_vs_oracle": ok,
             "device": device_facts(torch, local_rank),
         },
         "roofline": {
+            "kernel": lib.L.jga_kernel_name(C.byref(g), 1).decode(),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms_per_launch": round(ev_ms, 4),
-            # the other roof, from the same PMC passes as `traffic` (profiles/): the kernel is
-            # co-limited by vector-ALU issue
-            **({"valu": dict(valu, source="profiles/pmc_latest.json")} if valu else {}),
+            "kernel_Mpixel_s": round(B * W * H / ev_ms / 1e3, 1),
+            "launches_timed": args.kernel_reps,
+            "note": "the fused dequant+IDCT+upsample+RGB kernel on %d images whose coefficient "
+                    "planes are resident in HBM; HIP events on the launch stream; NOT the "
+                    "end-to-end value" % B,
+            **({"traffic_provenance": extra["provenance"]} if extra.get("provenance") else {}),
+            **({"valu": extra["valu"]} if extra.get("valu") else {}),
         },
     }
+    if e2e:
+        out["e2e"] = e2e
 
     if rank == 0:
         # what a plain device-to-device copy of the same volume reaches on this box (SURVEY.md
@@ -283,10 +532,38 @@ def main():
         out["roofline"]["device_copy_GBps"] = round(2 * src.numel() * 10 / e0.elapsed_time(e1) / 1e6, 1)
         del src, dst
 
-    if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_seconds)
+    solo = rank == 0 and world == 1
+    if solo and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_rounds, args.cpu_frames)
 
-    if rank == 0 and world == 1 and not args.no_other:
+    if solo and not args.no_e2e:
+        # the other ends and transports, same measurement (JPEG bytes in host RAM -> pixels)
+        nthr = max(1, min(my_cpus, 128))
+        for key, copy_back, transport in (("north_star_host_huffman_to_rgb_host", True, 0),
+                                          ("pack_transport_to_rgb_hbm", False, 1),
+                                          ("gpu_entropy_to_rgb_host", True, 2)):
+            nt = nthreads if transport == 2 else nthr
+            p2 = lib.Pipeline(device=local_rank, nthreads=nt, out=abi.JPEG_DECODE_RGB,
+                              copy_back=copy_back, transport=transport, batch=B, depth=args.lanes)
+            n = 24 * B if transport == 2 else max(96, 4 * nthr)
+            if copy_back:
+                n = min(n, 288)                   # 25 MB of host pixels per image
+            outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
+            nw = min(n, args.lanes * B if transport == 2 else 2 * nthr)
+            p2.run_jobs(lib.Pipeline.make_jobs(cyc(nw), host_outs=outs[:nw] if outs else None))
+            jr = lib.Pipeline.make_jobs(cyc(n, 3), host_outs=outs)
+            t0 = time.perf_counter()
+            rc2 = p2.run_jobs(jr)
+            te = time.perf_counter() - t0
+            p2.close()
+            e2e[key] = {"value": round(n * W * H / te / 1e6, 1), "unit": "Mpixel/s", "images": n,
+                        "ok": rc2 == 0, "host_threads": nt,
+                        "h2d_bytes_per_image": int(sum(j.h2d_bytes for j in jr) // n)}
+            del outs
+        e2e["note"] = "all PCIe- and host-inclusive; *_to_rgb_host also copies the pixels back into " \
+                      "the callers' host buffers (the plugin's decode_image semantics)"
+
+    if solo and not args.no_other:
         # Supplementary: the other device stages, each against its own algorithmic bytes
         # (128 B per coded block in, output bytes out), HIP-event timed.
         others = {}
@@ -304,8 +581,7 @@ def main():
         ab = B * (g.coef_blocks * 128 + g.yuv_bytes)
         others["yuv_stage_420"] = {"kernel": "jga_idct_yuv_kernel", "ms": round(t, 4),
                                    "GBps": round(ab / t / 1e6, 1), "images": B}
-        # pass 3 alone on those planes (wall-clock over 10 launches)
-        for rep in range(2):
+        for rep in range(2):                                  # pass 3 alone on those planes
             t0 = time.perf_counter()
             for _ in range(10):
                 lib.check(lib.L.jga_yuv_rgb_batch(C.byref(g), B, d_yuv.ptr, ys, d_out.ptr, ostride,
@@ -334,45 +610,11 @@ def main():
             dc2.free(); do2.free(); dq2.free()
         out["other_kernels"] = others
 
-    if rank == 0 and world == 1 and not args.no_e2e:
-        n = args.e2e_images
-        e2e = {}
-        nthr = args.e2e_threads or max(1, min(os.cpu_count() or 1, 48))
-        for copy_back, transport in ((False, 0), (True, 0), (False, 1), (False, 2), (True, 2)):
-            nt = max(1, min(os.cpu_count() or 1, 96)) if transport == 2 else nthr
-            pl = lib.Pipeline(device=local_rank, nthreads=nt, out=abi.JPEG_DECODE_RGB,
-                              copy_back=copy_back, transport=transport, batch=48, depth=6)
-            # enough images for every worker to reach steady state (its two slots allocated in the
-            # warm-up, then several images each); the fast path needs more to ramp
-            n = args.e2e_images*24 if transport == 2 else max(args.e2e_images, 4*nthr)
-            if copy_back:
-                n = min(n, 288)                   # 25 MB of host pixels per image
-            jobs = [jpegs[i % len(jpegs)] for i in range(n)]
-            # the caller's pixel buffers exist before the clock starts (zeros: pages touched)
-            outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
-            nw = 288 if transport == 2 else 2*nthr                     # warm: slots/lanes, pages
-            pl.run(jobs[:nw], host_outs=outs[:nw] if outs else None)
-            t0 = time.perf_counter()
-            rc, done = pl.run(jobs, host_outs=outs)
-            te = time.perf_counter() - t0
-            pl.close()
-            key = "jpeg_host_to_rgb_host" if copy_back else "jpeg_host_to_rgb_hbm"
-            if transport:
-                key += ("", "_pack_transport", "_gpu_entropy")[transport]
-            e2e[key] = {"value": round(n * W * H / te / 1e6, 1), "unit": "Mpixel/s",
-                        "images": n, "ok": rc == 0,
-                        "h2d_bytes_per_image": int(sum(j.h2d_bytes for j in done) // n)}
-        e2e["host_threads"] = nthr
-        e2e["note"] = "JPEG bytes in host RAM -> RGB; PCIe- and host-inclusive, not `value`. " \
-                      "Default/pack transports: host Huffman threads + pinned hipMemcpyAsync + " \
-                      "fused kernel; gpu_entropy: host only unstuffs, 6 lanes x 48 images, 3 with kernels queued at a time"
-        out["e2e"] = e2e
-
-    if rank == 0 and world == 1 and not args.no_pack:
+    if solo and not args.no_pack:
         # Supplementary: PACK words + block index resident in HBM ->
         # jga_unpack_kernel -> QUANT planes.  Algorithmic bytes: 2 B/word + 4 B/block read,
         # 128 B/block written.
-        pw = [lib.entropy_decode_pack(j, g)[:2] for j in jpegs]
+        pw = [lib.entropy_decode_pack(j, g)[:2] for j in jpegs[:ncoef]]
         nidx = int(lib.L.jga_index_count(C.byref(g)))
         pstride = (max(len(p) for p, _ in pw) + 127) // 128 * 128
         hp = np.zeros((B, pstride), np.uint16)
@@ -395,23 +637,23 @@ def main():
         nblk = sum(g.plane[p].hblocks * g.plane[p].vblocks for p in range(g.nplanes))
         words = sum(len(pw[i % len(pw)][0]) for i in range(B))
         ub = words * 2 + B * nblk * (4 + 128)
+        import oracle as _o
         same = bool(np.array_equal(d_coef.download(g.coef_shorts * 2, dtype=np.int16),
-                                   lib.entropy_decode(jpegs[0], g)))
+                                   _o.Oracle().decode(jpegs[0], _o.QUANT)[1]))
         out["pack_stage"] = {
             "kernel": "jga_unpack_kernel", "ms_per_launch": round(tu * 1e3, 4),
             "achieved_GBps": round(ub / tu / 1e9, 1), "algorithmic_bytes_per_launch": ub,
             "words_per_block": round(words / (B * nblk), 2),
             "pcie_bytes_vs_dense": round((words * 2 + B * nidx * 4) / (B * g.coef_shorts * 2), 3),
-            "equals_host_quant_stage": same,
+            "equals_oracle_quant_stage": same,
         }
         d_pack.free()
         d_idx.free()
 
-    if rank == 0 and world == 1 and not args.no_gpu_entropy:
-        # Supplementary: the whole decode on the GPU.  Entropy-coded
-        # bytes resident in HBM -> self-synchronising parallel Huffman decode -> the same
-        # fused kernel -> RGB in HBM.  No host Huffman, 8x fewer PCIe bytes.
-        jobs = [jpegs[i % len(jpegs)] for i in range(B)]
+    if solo and not args.no_gpu_entropy:
+        # Supplementary: the device side of `value` on its own.  Entropy-coded bytes resident in
+        # HBM -> self-synchronising parallel Huffman decode -> the fused kernel -> RGB in HBM.
+        jobs = cyc(B)
         hb = lib.HuffBatch(B, sum(map(len, jobs)) + 4096 * B)
         t0 = time.perf_counter()
         hb.prepare(jobs)
@@ -438,7 +680,7 @@ def main():
         out["gpu_entropy"] = {
             "value": round(B * W * H * reps / (th + ti) / 1e6, 1), "unit": "Mpixel/s",
             "note": "JPEG entropy-coded bytes resident in HBM -> GPU Huffman -> fused kernel "
-                    "-> RGB in HBM (device-only timed region, batch of %d)" % B,
+                    "-> RGB in HBM (device-only timed region, one batch of %d, no overlap)" % B,
             "huffman_ms": round(th / reps * 1e3, 3), "idct_rgb_ms": round(ti / reps * 1e3, 3),
             "sync_rounds": rounds, "bit_exact_vs_oracle": same,
             "prepare_ms_host_parse_unstuff_h2d": round(t_prep * 1e3, 2),

@@ -298,6 +298,9 @@ int   jga_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int   jga_device_memset(void *dst, int value, size_t bytes, void *stream);
 int   jga_stream_sync(void *stream);
 int   jga_set_device(int dev);
+/* "dddd:bb:dd.f" of device `dev` (len >= 13): a launcher that runs one process per GPU
+ * finds the GPU's NUMA node and local CPUs under /sys/bus/pci/devices/<id>/ with it. */
+int   jga_device_pci_bus_id(int dev, char *buf, int len);
 void *jga_stream_create(void);
 void  jga_stream_destroy(void *stream);
 /* Time `reps` back-to-back launches of the rgb (or yuv) batch kernel with HIP

@@ -318,6 +318,11 @@ JGA_EXPORT int jga_set_device(int dev) {
   HIP_TRY(hipSetDevice(dev));
   return EXIT_SUCCESS;
 }
+JGA_EXPORT int jga_device_pci_bus_id(int dev, char *buf, int len) {
+  if (!buf || len < 13) return jga_fail("jga_device_pci_bus_id: buffer too small");
+  HIP_TRY(hipDeviceGetPCIBusId(buf, len, dev));
+  return EXIT_SUCCESS;
+}
 JGA_EXPORT void *jga_stream_create(void) {
   hipStream_t s = NULL;
   if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {

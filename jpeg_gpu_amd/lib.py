@@ -19,7 +19,7 @@ EXPORTED = [
     "jga_index_count", "jga_unpack_batch", "jga_yuv_rgb_batch",
     "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
     "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
-    "jga_stream_sync", "jga_set_device", "jga_stream_create", "jga_stream_destroy",
+    "jga_stream_sync", "jga_set_device", "jga_device_pci_bus_id", "jga_stream_create", "jga_stream_destroy",
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
     "jga_huff_decode", "jga_huff_prepare_verdict", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
@@ -85,6 +85,7 @@ L.jga_memcpy_d2h.argtypes = [_vp, _vp, C.c_size_t, _vp]
 L.jga_device_memset.argtypes = [_vp, _i, C.c_size_t, _vp]
 L.jga_stream_sync.argtypes = [_vp]
 L.jga_set_device.argtypes = [_i]
+L.jga_device_pci_bus_id.argtypes = [_i, C.c_char_p, _i]
 L.jga_stream_create.restype = _vp
 L.jga_stream_destroy.argtypes = [_vp]
 L.jga_stream_destroy.restype = None
@@ -127,6 +128,12 @@ def version():
 
 def device_count():
     return L.jga_device_count()
+
+
+def device_pci_bus_id(dev):
+    buf = C.create_string_buffer(32)
+    check(L.jga_device_pci_bus_id(dev, buf, len(buf)))
+    return buf.value.decode().lower()
 
 
 # ---- host stage ---------------------------------------------------------------
@@ -351,17 +358,30 @@ class Pipeline:
             raise JgaError((L.jga_last_error() or b"pipeline_create failed").decode())
         self.copy_back = copy_back
 
-    def run(self, jpegs, host_outs=None, dev_outs=None):
+    @staticmethod
+    def make_jobs(jpegs, host_outs=None, dev_outs=None):
+        """The jga_job array for a run (built outside any timed region).  The returned object
+        keeps the input buffers alive."""
         n = len(jpegs)
-        keep = [np.frombuffer(bytes(j), np.uint8) for j in jpegs]
+        views = {}
         jobs = (abi.jga_job * n)()
-        for i in range(n):
-            jobs[i].jpeg = keep[i].ctypes.data
-            jobs[i].size = keep[i].size
+        for i, j in enumerate(jpegs):
+            v = views.get(id(j))
+            if v is None:
+                v = views[id(j)] = np.frombuffer(bytes(j), np.uint8)
+            jobs[i].jpeg = v.ctypes.data
+            jobs[i].size = v.size
             jobs[i].host_out = host_outs[i].ctypes.data if host_outs is not None else None
             jobs[i].dev_out = dev_outs[i] if dev_outs is not None else None
-        rc = L.jga_pipeline_run(self.ptr, jobs, n)
-        return rc, jobs
+        jobs._keep = (list(views.values()), list(jpegs), host_outs)
+        return jobs
+
+    def run_jobs(self, jobs):
+        return L.jga_pipeline_run(self.ptr, jobs, len(jobs))
+
+    def run(self, jpegs, host_outs=None, dev_outs=None):
+        jobs = self.make_jobs(jpegs, host_outs, dev_outs)
+        return self.run_jobs(jobs), jobs
 
     def close(self):
         if self.ptr:

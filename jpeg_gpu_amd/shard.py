@@ -29,3 +29,94 @@ def aggregate_throughput(local_units, local_seconds, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return u.item() / t.item(), u.item(), t.item()
+
+
+# ---- one process per GPU: which host CPUs belong to which rank -----------------------------
+# A node has two sockets; a GPU's PCIe root hangs off one of them, and the pipeline's host
+# threads (marker parse + unstuffing, or the host Huffman threads of the north-star
+# transport) read the JPEG bytes and write pinned memory the GPU then pulls: they should run
+# on the GPU's socket (86-106 vs 108-117 Gpixel/s), and N ranks must share
+# the cores, not each start one thread per core of the box.
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def device_numa_node(pci_bus_id, sysfs="/sys/bus/pci/devices"):
+    """NUMA node of a PCI device ('0000:c1:00.0'), -1 if the kernel does not say."""
+    try:
+        with open("%s/%s/numa_node" % (sysfs, pci_bus_id.lower())) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return -1
+
+
+def numa_node_cpus(node, sysfs="/sys/devices/system/node"):
+    try:
+        with open("%s/node%d/cpulist" % (sysfs, node)) as f:
+            return parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return []
+
+
+def cpu_cores(cpus, sysfs="/sys/devices/system/cpu"):
+    """Group logical CPUs into physical cores (SMT siblings together), in CPU order."""
+    cpus = sorted(cpus)
+    have, cores, seen = set(cpus), [], set()
+    for c in cpus:
+        if c in seen:
+            continue
+        try:
+            with open("%s/cpu%d/topology/thread_siblings_list" % (sysfs, c)) as f:
+                sib = [x for x in parse_cpulist(f.read()) if x in have]
+        except (OSError, ValueError):
+            sib = []
+        core = sorted(set(sib) | {c})
+        seen.update(core)
+        cores.append(core)
+    return cores
+
+
+def rank_cpu_share(local_rank, gpu_nodes, allowed, node_cpus, cores_of=None):
+    """CPUs for the rank that drives GPU `local_rank`.
+
+    gpu_nodes[i] = NUMA node of GPU i (-1 unknown), one entry per local rank;
+    allowed      = CPUs this job may use (os.sched_getaffinity);
+    node_cpus    = {node: [cpus]};
+    cores_of     = function grouping a CPU list into physical cores (default: one CPU each).
+    Ranks whose GPUs sit on the same node split that node's allowed cores into equal
+    contiguous shares, SMT siblings staying together.  With no topology information every
+    rank gets an equal share of `allowed`.  Never returns an empty list."""
+    allowed = sorted(allowed)
+    node = gpu_nodes[local_rank]
+    mates = [r for r, nd in enumerate(gpu_nodes) if nd == node]
+    pool = [c for c in node_cpus.get(node, []) if c in set(allowed)] if node >= 0 else []
+    if not pool:                                  # unknown topology: even split of everything
+        pool, mates = allowed, list(range(len(gpu_nodes)))
+    cores = cores_of(pool) if cores_of else [[c] for c in pool]
+    k, m = mates.index(local_rank), len(mates)
+    mine = cores[k * len(cores) // m:(k + 1) * len(cores) // m] or [cores[k % len(cores)]]
+    return sorted(c for core in mine for c in core)
+
+
+def pin_rank_to_gpu_node(local_rank, nlocal, pci_bus_ids=None):
+    """Restrict the calling thread (and every thread it creates from now on) to this rank's
+    share of the host CPUs.  Returns a description for the bench line."""
+    import os
+    allowed = os.sched_getaffinity(0)
+    ids = list(pci_bus_ids or [])
+    gpu_nodes = [device_numa_node(ids[i]) if i < len(ids) else -1 for i in range(nlocal)]
+    cpus = {nd: numa_node_cpus(nd) for nd in set(gpu_nodes) if nd >= 0}
+    share = rank_cpu_share(local_rank, gpu_nodes, allowed, cpus, cpu_cores)
+    os.sched_setaffinity(0, share)
+    return {"numa_node": gpu_nodes[local_rank], "cpus": len(share),
+            "cpu_list": "%d-%d%s" % (share[0], share[-1], "" if share[-1] - share[0] + 1 == len(share)
+                                      else " (%d of them)" % len(share))}

@@ -203,6 +203,13 @@ class Reference(_Lib):
                                  C.POINTER(C.c_longlong), C.POINTER(Info)]
         L.ref_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                  C.POINTER(C.c_int), C.POINTER(Info)]
+        if hasattr(L, "ref_frames_yuv"):          # (a _ref built before this entry existed)
+            L.ref_frames_yuv.argtypes = [C.c_char_p, C.c_int, C.c_int]
+
+    def frames_yuv(self, data, frames):
+        """`frames` passes of the reference's own per-frame loop (reset -> header -> YUV)."""
+        if self.lib.ref_frames_yuv(bytes(data), len(data), int(frames)):
+            raise ValueError("reference decode failed")
 
     def idct_blocks(self, blocks):
         blocks = np.ascontiguousarray(blocks, dtype=np.int16).reshape(-1, 64)

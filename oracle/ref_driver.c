@@ -123,6 +123,33 @@ REF_API int ref_decode(const unsigned char *buf, int size, int out,
   return i;
 }
 
+/* The reference's steady-state loop for `-i xjpeg -o yuv` (src/jpeg_gpu.c:1215-1237 with
+ * XJPEG_DECODE_CTX_VTBL, src/jpeg_wrap.c:321-358): buffers made once, then per frame
+ * decode_reset (= xjpeg_init) -> decode_header (xjpeg_decode_header + the header copy-out)
+ * -> decode_image(YUV).  bench.py's cpu_baseline leg runs one of these per host core. */
+REF_API int ref_frames_yuv(const unsigned char *buf, int size, int frames) {
+  xjpeg_decode_ctx ctx;
+  jpeg_header h;
+  image img;
+  int f, bad = 0;
+  xjpeg_init(&ctx, buf, size);
+  xjpeg_decode_header(&ctx);
+  if (fill_header(&ctx, &h)) return 1;
+  if (image_init(&img, &h) != EXIT_SUCCESS) return 1;
+  image_zero(&img);
+  for (f = 0; f < frames && !bad; f++) {
+    xjpeg_init(&ctx, buf, size);
+    xjpeg_decode_header(&ctx);
+    bad = fill_header(&ctx, &h);
+    if (!bad) {
+      xjpeg_decode_image(&ctx, &img, XJPEG_DECODE_YUV);
+      bad = ctx.error != NULL;
+    }
+  }
+  image_clear(&img);
+  return bad;
+}
+
 /* image_init on a synthetic header (test/image.c:21-55 style). */
 REF_API int ref_layout(int width, int height, int ncomps, const int *hsamp,
  const int *vsamp, ref_info *o) {

@@ -11,33 +11,87 @@ import pytest
 from conftest import ROOT
 
 
+def run_bench(*flags, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items()
+                            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_n_run_plainly_starts_n_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it must itself become 2 ranks (VERDICT r1:
+    it used to fall back to one).  --dry-launch stops after the launch path: rendezvous on
+    127.0.0.1, one process per rank, each with its own share of the host CPUs."""
+    d = run_bench("--gpus", "2", "--dry-launch", timeout=300)
+    assert d["dry_launch"] is True and d["n_gpus"] == 2
+    ranks = d["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["local_rank"] for r in ranks] == [0, 1]
+    assert ranks[0]["pid"] != ranks[1]["pid"]
+    a, b = set(ranks[0]["cpus"]), set(ranks[1]["cpus"])
+    assert a and b
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert not (a & b)                      # the ranks do not share host cores
+        assert a | b <= set(os.sched_getaffinity(0))
+    one = run_bench("--dry-launch", timeout=120)
+    assert one["n_gpus"] == 1 and len(one["ranks"]) == 1
+
+
+def test_rank_cpu_shares():
+    """Ranks on one NUMA node split that node's cores, SMT siblings together; without topology
+    information they split everything evenly."""
+    from jpeg_gpu_amd.shard import parse_cpulist, rank_cpu_share
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)),
+                 1: list(range(64, 128)) + list(range(192, 256))}
+    cores = lambda pool: [[c, c + 128] for c in pool if c < 128]
+    gpu_nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    shares = [rank_cpu_share(r, gpu_nodes, range(256), node_cpus, cores) for r in range(8)]
+    assert all(len(s) == 32 for s in shares)
+    assert sorted(sum(shares, [])) == list(range(256))                 # a partition of the box
+    for r, s in enumerate(shares):
+        assert set(s) <= set(node_cpus[gpu_nodes[r]])                  # on the GPU's own socket
+        assert all((c + 128) in s for c in s if c < 128)               # both halves of each core
+    assert rank_cpu_share(0, [0], range(256), node_cpus, cores) == sorted(node_cpus[0])
+    # no topology (numa_node = -1), or a cpuset that excludes the GPU's node: even split of what we may use
+    assert rank_cpu_share(1, [-1, -1], range(8), {}) == [4, 5, 6, 7]
+    assert rank_cpu_share(1, [0, 0], [200, 201, 202, 203], {0: list(range(64))}) == [202, 203]
+    assert rank_cpu_share(3, [0, 0, 0, 0], [5], {0: [5]}) == [5]       # never empty
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
-                        "--prewarm", "0", "--batch", "4", "--cpu-seconds", "1", "--no-e2e", "--no-pack",
-                        "--no-other", "--no-gpu-entropy"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    d = run_bench("--steps", "2", "--warmup", "1", "--batch", "4", "--distinct", "4", "--lanes", "2",
+                  "--prewarm", "0", "--kernel-reps", "3", "--cpu-rounds", "1", "--cpu-frames", "1",
+                  "--no-e2e", "--no-pack", "--no-other", "--no-gpu-entropy")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
               "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "Mpixel/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
-    assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["bit_exact_vs_oracle"] is True
+    assert d["metric"].startswith("Mpixel/s end-to-end decode, 4K 4:2:0 baseline JPEG")
+    cfg = d["config"]
+    assert "host RAM -> RGB8 in HBM" in cfg["workload"] and "model" not in cfg
+    assert cfg["bit_exact_vs_oracle"] is True and cfg["images_timed_per_gpu"] == 8
+    # value = pixels of the timed region / its wall time
+    assert abs(d["value"] - 8 * 3840 * 2160 / (d["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.01 * d["value"]
+    # compressed bytes crossed PCIe, not 24.9 MB of planes
+    assert 0 < cfg["h2d_bytes_per_image"] < 8_000_000
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     # achieved = algorithmic bytes per launch / measured launch time
     want = rf["algorithmic_bytes_per_launch"] / rf["kernel_ms_per_launch"] / 1e6
     assert abs(rf["achieved"] - want) < 0.005 * want          # (the JSON rounds the milliseconds)
+    assert rf["kernel_Mpixel_s"] > d["value"]                 # the kernel alone outruns the whole path
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["oracle_port_rgb"]["value"] > 0 and "libjpeg_turbo_rgb" in cb
     assert d["value"] > 0 and d["ms_per_step"] > 0
 
 
