@@ -75,7 +75,7 @@ def parse_args(argv=None):
                     help="seconds of untimed kernel launches before the roofline leg (clock ramp)")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launches timed in the roofline leg")
     ap.add_argument("--cpu-rounds", type=int, default=5, help="cpu_baseline: best of this many rounds")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="cpu_baseline: frames per core per round")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="cpu_baseline: frames per core per round")
     ap.add_argument("--measure-traffic", action="store_true",
                     help="collect roofline.traffic now (rocprofv3 --pmc child passes) instead of "
                          "quoting profiles/pmc_latest.json")
@@ -180,17 +180,24 @@ def all_core_rate(make_worker, threads, frames, rounds):
     return threads * frames * W * H / best / 1e6, best
 
 
-def cpu_baseline(jpegs, rounds, frames):
+def cpu_baseline(jpegs, rounds, frames, cpus=None, quota=None):
     """north_star: "the xjpeg/libjpeg-turbo CPU path timed on the same box's host cores in the
-    same run (core count stated)".  One frame loop per logical CPU this process may use, every
-    loop on its own image; warm; best of `rounds`."""
+    same run (core count stated)".  One frame loop per CPU the box really grants — all of
+    `cpus` (the whole box, not one rank's NUMA share), or the cgroup's cpu.max grant when that
+    is smaller: more loops than granted CPUs only get the group throttled (measured: 16 loops
+    2.0 Gpixel/s, 64 loops 1.6, 256 loops 1.5 on a 16-CPU grant) — every loop on its own
+    image; warm; best of `rounds`."""
     import numpy as np
     import oracle
     from jpeg_gpu_amd import abi, lib
-    cpus = len(os.sched_getaffinity(0))
-    threads = max(1, cpus)
+    mine = os.sched_getaffinity(0)
+    if cpus:
+        os.sched_setaffinity(0, cpus)            # the loops' threads inherit it
+    ncpu = len(os.sched_getaffinity(0))
+    threads = max(1, min(ncpu, int(quota + 0.5))) if quota else ncpu
     res = {"unit": "Mpixel/s", "cores": threads, "cpu_model": cpu_model(),
-           "method": "one frame loop per logical CPU (reset -> header -> decode, as "
+           "visible_cpus": ncpu, "cgroup_cpu_quota": quota,
+           "method": "one frame loop per granted CPU (reset -> header -> decode, as "
                      "src/jpeg_gpu.c:1231-1237), %d frames per loop per round, best of %d rounds, "
                      "each loop on its own 3840x2160 4:2:0 q90 file" % (frames, rounds)}
     t_all = time.perf_counter()
@@ -266,6 +273,7 @@ def cpu_baseline(jpegs, rounds, frames):
     res["sample"] = "%s: %d loops x %d frames of %dx%d per round, %d rounds, %.1f s in all " \
                     "three CPU paths" % (what, threads, frames, W, H, rounds,
                                          time.perf_counter() - t_all)
+    os.sched_setaffinity(0, mine)
     return res
 
 
@@ -343,10 +351,15 @@ def main():
                          % (lib.device_count() if torch.cuda.is_available() else 0, world))
     # this rank's host cores: those of its GPU's NUMA node, shared with the ranks next door
     pin = None
+    orig_cpus = os.sched_getaffinity(0)
     if not args.no_pin:
         ids = [lib.device_pci_bus_id(i) for i in range(world)]
         pin = shard.pin_rank_to_gpu_node(local_rank, world, ids)
     my_cpus = len(os.sched_getaffinity(0))
+    # ... of which the container may be granted fewer (cgroup cpu.max: the GPU boxes show 256
+    # CPUs and grant 16); threads beyond the grant get everybody throttled
+    quota = shard.cpu_quota()
+    budget = shard.rank_cpu_budget(my_cpus, world, quota)
     torch.cuda.set_device(local_rank)
     lib.check(lib.L.jga_set_device(local_rank))
     if world > 1:
@@ -366,10 +379,14 @@ def main():
     jpegs = make_inputs(synth, args.distinct, rank, min(my_cpus, 64))
     hdr, g = lib.geom_of(jpegs[0])
     B, K, Wm = args.batch, args.steps, args.warmup
-    nthreads = args.host_threads or max(1, min(my_cpus, 96))
-    log("rank %d: %d files (%.1f MB) in %.1f s; %d host threads%s" % (
+    # transport 2's host threads parse + unstuff and then wait for the device: 1.5 per granted
+    # CPU measured best (profiles/r2_e2e_sweep.txt); with no grant to respect, up to 96
+    nthreads = args.host_threads or (min(my_cpus, max(args.lanes, budget + budget // 2)) if quota
+                                     else max(1, min(my_cpus, 96)))
+    log("rank %d: %d files (%.1f MB) in %.1f s; %d host threads%s%s" % (
         rank, len(jpegs), sum(map(len, jpegs)) / 1e6, time.perf_counter() - t_setup, nthreads,
-        ", cpus %s of node %s" % (pin["cpu_list"], pin["numa_node"]) if pin else ""))
+        ", cpus %s of node %s" % (pin["cpu_list"], pin["numa_node"]) if pin else "",
+        ", cgroup grants %.1f CPUs" % quota if quota else ""))
 
     # ---- headline: JPEG bytes in host RAM -> RGB8 in HBM, K batches of B images per rank ----
     pl = lib.Pipeline(device=local_rank, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
@@ -459,7 +476,9 @@ def main():
     # fused kernel (entropy.c on this rank's cores; 24.9 MB of planes per image over PCIe)
     e2e = {}
     if not args.no_e2e:
-        nthr = max(1, min(my_cpus, 128))       # ~94 threads fill the PCIe link (195 Mpixel/s each)
+        # Huffman threads also block on their slot's event: ~3 per granted CPU measured best
+        # (profiles/r2_t0_sweep.txt: 32-48 threads on a 16-CPU grant, fewer AND more are slower)
+        nthr = min(my_cpus, 3 * budget) if quota else max(1, min(my_cpus, 96))
         n0 = max(96, 4 * nthr)
         pl0 = lib.Pipeline(device=local_rank, nthreads=nthr, out=abi.JPEG_DECODE_RGB,
                            copy_back=False, transport=0)
@@ -495,6 +514,8 @@ def main():
             "images_timed_per_gpu": K * B, "h2d_bytes_per_image": int(h2d_per_image),
             "parallelism": "image-sharded x%d, one process per GPU, no data-path collective" % world,
             "host_threads_per_gpu": nthreads, "cpu_pinning": pin,
+            "host_cpus": {"visible_to_rank": my_cpus, "cgroup_cpu_quota": quota,
+                          "budget_per_rank": budget},
             "bit_exact_vs_oracle": ok,
             "device": device_facts(torch, local_rank),
         },
@@ -534,11 +555,11 @@ def main():
 
     solo = rank == 0 and world == 1
     if solo and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_rounds, args.cpu_frames)
+        out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_rounds, args.cpu_frames, orig_cpus, quota)
 
     if solo and not args.no_e2e:
         # the other ends and transports, same measurement (JPEG bytes in host RAM -> pixels)
-        nthr = max(1, min(my_cpus, 128))
+        nthr = min(my_cpus, 3 * budget) if quota else max(1, min(my_cpus, 96))
         for key, copy_back, transport in (("north_star_host_huffman_to_rgb_host", True, 0),
                                           ("pack_transport_to_rgb_hbm", False, 1),
                                           ("gpu_entropy_to_rgb_host", True, 2)):

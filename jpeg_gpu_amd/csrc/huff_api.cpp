@@ -203,8 +203,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   phase_barrier bar;
   int nt = b->prepare_threads;
   if (nt <= 0) {
-    unsigned hw = std::thread::hardware_concurrency();
-    nt = (int)(hw ? hw : 4);
+    nt = jga_cpu_budget();
     if (nt > 64) nt = 64;
   }
   if (nt > n) nt = n;

@@ -14,6 +14,7 @@ extern "C" {
  * return EXIT_FAILURE. */
 int jga_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 int jga_ilog(unsigned v);
+int jga_cpu_budget(void);        /* affinity mask cut down to the cgroup's cpu.max grant */
 int jga_subsamp_of(int xdec, int ydec, int ncomps);
 
 /* Entropy decode with an explicit stage (entropy.c). */

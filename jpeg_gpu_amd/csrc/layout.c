@@ -1,3 +1,4 @@
+#define _GNU_SOURCE
 /* layout.c — frame geometry and `image` buffers for the decode path.
  *
  * Host-side mirror of the reference's data model:
@@ -11,7 +12,9 @@
  */
 #include <stdarg.h>
 #include <stdio.h>
+#include <sched.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 #include "jga_internal.h"
 
@@ -63,6 +66,29 @@ int jga_fail(const char *fmt, ...) {
 
 const char *jga_last_error(void) { return jga_err; }
 const char *jga_version(void) { return "jpeg_gpu_amd 0.1 (gfx950)"; }
+
+/* CPUs this process can really keep busy: the affinity mask, cut down to the container's
+ * cgroup grant (cpu.max = "quota period"; a box may show 256 CPUs and grant 16, and threads
+ * beyond the grant only get the whole group throttled).  Default thread counts come from
+ * here, never from the raw CPU count. */
+int jga_cpu_budget(void) {
+  cpu_set_t set;
+  int n = 0;
+  FILE *f;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n < 1) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
+  if (n < 1) n = 1;
+  f = fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (f) {
+    double quota = 0, period = 0;
+    if (fscanf(f, "%lf %lf", &quota, &period) == 2 && quota > 0 && period > 0) {
+      const int grant = (int)(quota/period + 0.5);
+      if (grant >= 1 && grant < n) n = grant;
+    }
+    fclose(f);
+  }
+  return n;
+}
 
 /* number of bits needed to represent v (glj_ilog semantics) */
 int jga_ilog(unsigned v) {

@@ -480,8 +480,11 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     return nullptr;
   }
   if (pl->cfg.nthreads <= 0) {
-    unsigned hc = std::thread::hardware_concurrency();
-    pl->cfg.nthreads = hc ? (int)hc : 4;
+    // the workers also wait (for their slot's event, for a device turn): a few more of them
+    // than CPUs we can keep busy, but nowhere near one per visible CPU of a throttled box
+    const int cpus = jga_cpu_budget();
+    pl->cfg.nthreads = pl->cfg.transport == 2 ? cpus + cpus/2 : 3*cpus;
+    if (pl->cfg.nthreads > 96) pl->cfg.nthreads = 96;
   }
   if (!hip_ok(hipSetDevice(pl->cfg.device), "hipSetDevice")) {
     delete pl;

@@ -107,6 +107,34 @@ def rank_cpu_share(local_rank, gpu_nodes, allowed, node_cpus, cores_of=None):
     return sorted(c for core in mine for c in core)
 
 
+def cpu_quota(cgroup="/sys/fs/cgroup"):
+    """CPUs' worth of run time the container may use per unit of wall time (cgroup v2 cpu.max
+    = "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us), or None when unlimited.  A box can
+    show 256 CPUs and grant 16: threads beyond the grant only get the whole group throttled,
+    so thread counts have to be sized by this, not by the CPU count."""
+    try:
+        with open(cgroup + "/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open(cgroup + "/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open(cgroup + "/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+def rank_cpu_budget(ncpus, world, quota="auto"):
+    """How many CPUs' worth of work one of `world` ranks can count on: its share of the
+    affinity mask, cut down to its share of the cgroup grant."""
+    q = cpu_quota() if quota == "auto" else quota
+    return max(1, min(int(ncpus), int(q / world + 0.5))) if q else max(1, int(ncpus))
+
+
 def pin_rank_to_gpu_node(local_rank, nlocal, pci_bus_ids=None):
     """Restrict the calling thread (and every thread it creates from now on) to this rank's
     share of the host CPUs.  Returns a description for the bench line."""

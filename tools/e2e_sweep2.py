@@ -1,0 +1,23 @@
+"""transport 2 end to end (JPEG bytes in host RAM -> RGB in HBM) over host threads and lanes,
+64 distinct files.  Usage: python tools/e2e_sweep2.py [nimages]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from concurrent.futures import ThreadPoolExecutor
+from jpeg_gpu_amd import abi, lib, synth
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
+W, H = 3840, 2160
+with ThreadPoolExecutor(16) as ex:
+    distinct = list(ex.map(lambda s: synth.synthetic_jpeg(W, H, "420", 90, seed=1234 + s), range(64)))
+cfgs = [(48, 6, t) for t in (6, 12, 24, 48, 96, 192)] + [(48, 4, 24), (48, 8, 48), (24, 8, 48), (32, 6, 48), (64, 6, 48), (96, 4, 48)]
+for batch, depth, nthr in cfgs:
+    pl = lib.Pipeline(device=0, nthreads=nthr, out=abi.JPEG_DECODE_RGB, transport=2, batch=batch, depth=depth)
+    cyc = lambda k, o=0: [distinct[(o + i) % 64] for i in range(k)]
+    pl.run_jobs(lib.Pipeline.make_jobs(cyc(batch * depth)))
+    jobs = lib.Pipeline.make_jobs(cyc(n, 3))
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); rc = pl.run_jobs(jobs); best = min(best, time.perf_counter() - t0)
+    pl.close()
+    print("batch %2d lanes %d threads %3d: %6.1f ms for %d images = %6.1f Gpixel/s (rc %d)" % (
+        batch, depth, nthr, best * 1e3, n, n * W * H / best / 1e9, rc), flush=True)
