@@ -10,7 +10,7 @@ GPU, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` of itse
 The metric is BASELINE.json's: Mpixel/s END-TO-END — from JPEG file bytes in host RAM to RGB8
 pixels in HBM (what a frame is in the reference: src/jpeg_gpu.c:1231-1237,
 its cpu/gpu split 1437-1458) — on 3840x2160 4:2:0 q90 baseline files.  A "step" is ONE
-batch of `--batch` (48) images per GPU through the pipelined decoder (jga_pipeline,
+batch of `--batch` (32) images per GPU through the pipelined decoder (jga_pipeline,
 transport 2): host threads parse markers and unstuff the scans into pinned memory, the
 compressed bytes cross PCIe, the GPU does the Huffman decode and the fused dequantise + IDCT
 + upsample + RGB kernel.  The timed region is exactly K such batches per rank, streamed
@@ -58,11 +58,12 @@ def log(*a):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=48, help="images per GPU per step")
+    ap.add_argument("--steps", type=int, default=72)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--kernel-batch", type=int, default=48, help="images per launch in the roofline leg")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic images per rank")
-    ap.add_argument("--lanes", type=int, default=6, help="batches in flight per GPU")
+    ap.add_argument("--lanes", type=int, default=8, help="batches in flight per GPU")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="host threads per rank (0 = this rank's share of the cores)")
     ap.add_argument("--no-pin", action="store_true", help="leave the ranks' CPU affinity alone")
@@ -425,6 +426,7 @@ def main():
         if not ok:
             raise SystemExit("bench.py: pipeline output differs from the oracle")
     pl.close()
+    PB, B = B, args.kernel_batch       # from here on B = images per launch of the stand-alone kernel legs
 
     # ---- roofline: the fused kernel alone, coefficient planes resident in HBM ----
     cstride = (g.coef_shorts * 2 + 255) // 256 * 128          # shorts, 256-B aligned
@@ -509,9 +511,9 @@ def main():
                         "(end to end); step = one batch of %d images per GPU through the pipelined "
                         "decoder: host marker parse + unstuffing into pinned memory, compressed "
                         "bytes over PCIe, GPU Huffman decode + fused dequant/IDCT/upsample/RGB "
-                        "kernel; %d steps streamed through %d lanes per GPU" % (B, K, args.lanes),
-            "batch_per_gpu": B, "distinct_images_per_gpu": len(jpegs),
-            "images_timed_per_gpu": K * B, "h2d_bytes_per_image": int(h2d_per_image),
+                        "kernel; %d steps streamed through %d lanes per GPU" % (PB, K, args.lanes),
+            "batch_per_gpu": PB, "distinct_images_per_gpu": len(jpegs),
+            "images_timed_per_gpu": K * PB, "h2d_bytes_per_image": int(h2d_per_image),
             "parallelism": "image-sharded x%d, one process per GPU, no data-path collective" % world,
             "host_threads_per_gpu": nthreads, "cpu_pinning": pin,
             "host_cpus": {"visible_to_rank": my_cpus, "cgroup_cpu_quota": quota,
@@ -565,12 +567,12 @@ def main():
                                           ("gpu_entropy_to_rgb_host", True, 2)):
             nt = nthreads if transport == 2 else nthr
             p2 = lib.Pipeline(device=local_rank, nthreads=nt, out=abi.JPEG_DECODE_RGB,
-                              copy_back=copy_back, transport=transport, batch=B, depth=args.lanes)
-            n = 24 * B if transport == 2 else max(96, 4 * nthr)
+                              copy_back=copy_back, transport=transport, batch=PB, depth=args.lanes)
+            n = 24 * PB if transport == 2 else max(96, 4 * nthr)
             if copy_back:
                 n = min(n, 288)                   # 25 MB of host pixels per image
             outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
-            nw = min(n, args.lanes * B if transport == 2 else 2 * nthr)
+            nw = min(n, args.lanes * PB if transport == 2 else 2 * nthr)
             p2.run_jobs(lib.Pipeline.make_jobs(cyc(nw), host_outs=outs[:nw] if outs else None))
             jr = lib.Pipeline.make_jobs(cyc(n, 3), host_outs=outs)
             t0 = time.perf_counter()
@@ -589,9 +591,9 @@ def main():
         # (128 B per coded block in, output bytes out), HIP-event timed.
         others = {}
 
-        def time_stage(gg, n, dc, cs, dq, do, os_, rgb, reps=10):
+        def time_stage(gg, n, dc, cs, dq, do, os_, rgb, reps=30):
             ms = C.c_float()
-            for r in (2, reps):
+            for r in (10, reps):                     # (fresh buffers: the first launches map pages)
                 lib.check(lib.L.jga_time_idct_batch(C.byref(gg), n, dc, cs, dq, 1, do, os_, rgb, r,
                                                     stream, C.byref(ms)))
             return ms.value
@@ -604,11 +606,11 @@ def main():
                                    "GBps": round(ab / t / 1e6, 1), "images": B}
         for rep in range(2):                                  # pass 3 alone on those planes
             t0 = time.perf_counter()
-            for _ in range(10):
+            for _ in range(10 + 20*rep):
                 lib.check(lib.L.jga_yuv_rgb_batch(C.byref(g), B, d_yuv.ptr, ys, d_out.ptr, ostride,
                                                   stream))
             lib.check(lib.L.jga_stream_sync(stream))
-            t = (time.perf_counter() - t0) / 10 * 1e3
+            t = (time.perf_counter() - t0) / (10 + 20*rep) * 1e3
         ab = B * (g.yuv_bytes + g.rgb_bytes)
         others["yuv_to_rgb_420"] = {"kernel": "jga_yuv_rgb_kernel", "ms": round(t, 4),
                                     "GBps": round(ab / t / 1e6, 1), "images": B}

@@ -183,7 +183,10 @@ HJ_HD int hj_value(uint32_t w, int len, int s) {
 // segment's data ends.  A symbol that reaches past it borrows bits of the next segment (or the
 // pad): a block it would complete does not count — the data ended early, as the host stage says
 // of such a stream (entropy.c, xjpeg.c:593-629).
-template <class Src>
+// LITE: only the end state is wanted (r.nblocks / r.dcsum are left 0) — the very first run of
+// a subsequence starts from a GUESS (bit 0 of the subsequence, slot 0), so everything but
+// where it ends is meaningless, and a third of the per-symbol instructions serve the counts.
+template <class Src, bool LITE = false>
 HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables *T,
  uint64_t start, uint64_t stop_bit, bool last = false) {
   uint32_t slot_comp_bits = 0;
@@ -202,7 +205,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
     const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
     const int len = HJ_E_LEN(e), s = HJ_E_S(e);
     br.skip(len + s);
-    if (isdc) {                                            // DC difference, extended
+    if (!LITE && isdc) {                                   // DC difference, extended
       const int v = hj_value(w, len, s);
       dcall += v;
       dc1 += comp == 1 ? v : 0;
@@ -210,7 +213,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
     }
     const int kn = k + HJ_E_ADV1(e) + 1;                   // DC: 1; AC: past the run; EOB: >= 64
     const int done = kn >= 64;
-    nblocks += (uint32_t)done;
+    if (!LITE) nblocks += (uint32_t)done;
     c = done ? (c + 1 == nslots ? 0 : c + 1) : c;
     comp = (int)((slot_comp_bits >> (2*c)) & 3u);
     k = done ? 0 : kn;

@@ -31,6 +31,8 @@
 // (6 B/px in+out) with ~37 VALU lane-ops/px next to it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 #include "kernel_params.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -649,6 +651,107 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// 4:4:4 (BASELINE config 3, "exercises the no-upsample path"): every pixel has its own Cb and
+// Cr sample, so a luma lane of the generic kernel above needs all 128 chroma floats of its MCU
+// — a 32 KB hand-off per 64 MCUs that pins the kernel at 4 workgroups (12 waves) per CU, leaves
+// no LDS for the wave-staged stores, and gives the luma wave 40 % more work than the chroma
+// waves.  This kernel keeps the block-per-lane IDCT (wave w = component w of 64 adjacent MCUs)
+// but runs the colour stage ROW-PARALLEL: in three phases the three waves publish pixel rows
+// [3p, 3p+3) of their blocks (clamped, 18 KB in all), and wave w then converts row 3p+w of all
+// 64 MCUs — one (MCU, row) unit per lane, its 1536 output bytes contiguous, so every store is
+// wave-staged.  Same arithmetic per pixel (rgb_row / chroma_row, CW = 8), 23 KB of LDS
+// (5-6 workgroups per CU), and the three waves carry equal work.
+// ---------------------------------------------------------------------------
+template <bool DEQUANT>
+__global__ __launch_bounds__(192) void jga_idct_rgb444_kernel(const jga_kparams P) {
+  constexpr int TILE = 64, PR = 3;                   // MCUs per tile, pixel rows per phase
+  __shared__ __attribute__((aligned(16))) float pub[3*PR*TILE*8];   // [comp][row in phase][MCU][8]
+  __shared__ uint4 qlds[24];
+  __shared__ __attribute__((aligned(16))) uint32_t stage_mem[3][384];
+  const int lane = threadIdx.x & 63;
+  const int comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t *wstage = stage_mem[comp];
+  const int tx = blockIdx.x, mrow = blockIdx.y, img = blockIdx.z;
+  const int bx = tx*TILE + lane;
+  const int hblocks = P.plane_hblocks[0];
+  const bool valid = bx < hblocks;
+  const int bxl = valid ? bx : hblocks - 1;          // tail lanes reload a real block
+  const long long rs = (long long)P.w0_blocks*64;
+  const int16_t *src = P.coef + (long long)img*P.coef_stride + P.plane_coef_off[comp]
+   + rs*mrow + (long long)bxl*64;
+  uint4 rows[8];
+  load_block_direct(src, rows);                      // in flight across the barrier below
+  if (DEQUANT) {
+    if (threadIdx.x < 24) {
+      qlds[threadIdx.x] = reinterpret_cast<const uint4 *>(P.qtab + (long long)img*192)[threadIdx.x];
+    }
+    __syncthreads();
+  }
+  float z[64], t[64];
+  row_pass_ldsq<DEQUANT>(rows, qlds + comp*8, z);
+  const float tmax = col_pass(z, t);
+  const bool clip = __builtin_amdgcn_ballot_w64(tmax > 127.0f) != 0ull;
+
+  const long long pitch = (long long)P.width*3;
+  uint8_t *img_out = P.out + (long long)img*P.out_stride;
+  const int x0 = bx*8;
+  const unsigned long long inside = __builtin_amdgcn_ballot_w64(valid && x0 + 8 <= P.width);
+  const int nin = (int)__builtin_popcountll(inside);
+  const bool wfast = P.out_aligned && (pitch & 15) == 0 && nin >= 2 && (nin & 1) == 0
+   && inside == (nin == 64 ? ~0ull : (1ull << nin) - 1ull)
+   && (((uintptr_t)img_out + (unsigned long long)__builtin_amdgcn_readfirstlane(x0)*3u) & 15u) == 0;
+  const bool fast = P.out_aligned && x0 + 8 <= P.width;
+
+#pragma unroll
+  for (int p0 = 0; p0 < 8; p0 += PR) {
+    // publish rows [p0, p0+PR) of this lane's block, clamped like clamp255(s+128)-128
+#pragma unroll
+    for (int rr = 0; rr < PR; rr++) {
+      if (p0 + rr < 8) {
+        float *dst = pub + ((comp*PR + rr)*TILE + lane)*8;
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+          v4f v;
+          v.x = t[(p0 + rr)*8 + h]; v.y = t[(p0 + rr)*8 + h + 1];
+          v.z = t[(p0 + rr)*8 + h + 2]; v.w = t[(p0 + rr)*8 + h + 3];
+          if (clip) {
+            v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
+            v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
+            v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
+            v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
+          }
+          *reinterpret_cast<v4f *>(dst + h) = v;
+        }
+      }
+    }
+    __syncthreads();
+    // wave `comp` converts pixel row p0 + comp of the tile's 64 MCUs
+    const int k = p0 + comp;
+    if (k < 8) {                                     // (wave-uniform)
+      const v4f *ys = reinterpret_cast<const v4f *>(pub + ((0*PR + comp)*TILE + lane)*8);
+      const v4f *us = reinterpret_cast<const v4f *>(pub + ((1*PR + comp)*TILE + lane)*8);
+      const v4f *vs = reinterpret_cast<const v4f *>(pub + ((2*PR + comp)*TILE + lane)*8);
+      const v4f y0 = ys[0], y1 = ys[1], u0 = us[0], u1 = us[1], v0 = vs[0], v1 = vs[1];
+      const float y8[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+      const float u8[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+      const float v8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      chroma_row<8> cr;
+      cr.set(u8, v8);
+      uint4 a;
+      uint2 b;
+      rgb_row<0, 8, false>(y8, cr, a, b);            // published values are clamped already
+      const int yy = mrow*8 + k;
+      uint8_t *o = img_out + (long long)yy*pitch + (long long)x0*3;
+      if (yy < P.height) {
+        if (wfast) store_rgb_row_wave(wstage, lane, o - lane*24, a, b, nin*3/2);
+        else if (valid) store_rgb_row(o, a, b, fast, x0, P.width);
+      }
+    }
+    if (p0 + PR < 8) __syncthreads();                // the next phase overwrites `pub`
+  }
+}
+
 // Grey: one plane, img->pixels is 1 B/px at the true size (ungrey.fs.glsl:18;
 // pixel layout src/jpeg_wrap.c:215-219).  Flat over the luma raster.
 template <bool DEQUANT, bool STAGED>
@@ -707,13 +810,21 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
 // `-o yuv`).  SURVEY.md A.5 arithmetic, evaluated literally.  One thread = 8 pixels
 // of one row; HBM-bound: reads 1 + 2/(LW*LH) bytes, writes 3 bytes per pixel.
 __global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, int xdec, int ydec) {
-  // 8 pixels per thread: Y as one 8-byte load, chroma as 8 >> xdec bytes, 24 output bytes
+  // 8 pixels per thread: Y as one 8-byte load, chroma as 8 >> xdec bytes, 24 output bytes.  A
+  // wave's 64 threads cover 512 consecutive pixels of one row = 1536 contiguous output bytes,
+  // which leave through the wave's LDS line as 16 bytes per lane (store_rgb_row_wave) when the
+  // row is 16-byte aligned: 24-byte pieces at a 24-byte stride cost the memory pipeline far more.
+  __shared__ __attribute__((aligned(16))) uint32_t stage_mem[4][384];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x0 = (blockIdx.x*256 + threadIdx.x)*8;
   const int y = blockIdx.y, img = blockIdx.z;
-  if (x0 >= P.width) return;
+  const bool live = x0 < P.width;
+  if (__builtin_amdgcn_ballot_w64(live) == 0ull) return;
+  const int xl = live ? x0 : 0;                      // (idle lanes of a live wave read pixel 0)
   const uint8_t *base = reinterpret_cast<const uint8_t *>(P.coef) + (long long)img*P.coef_stride;
-  const uint8_t *py = base + P.plane_data_off[0] + (long long)y*(P.plane_hblocks[0]*8) + x0;
-  const int n = P.width - x0 < 8 ? P.width - x0 : 8;
+  const uint8_t *py = base + P.plane_data_off[0] + (long long)y*(P.plane_hblocks[0]*8) + xl;
+  const int n = !live ? 0 : P.width - x0 < 8 ? P.width - x0 : 8;
   const uint2 yy = *reinterpret_cast<const uint2 *>(py);          // plane rows are whole blocks
   if (P.nplanes == 1) {
     uint8_t *o = P.out + (long long)img*P.out_stride + (long long)y*P.width + x0;
@@ -726,9 +837,9 @@ __global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, i
     return;
   }
   const uint8_t *pu = base + P.plane_data_off[1] + (long long)(y >> ydec)*(P.plane_hblocks[1]*8)
-   + (x0 >> xdec);
+   + (xl >> xdec);
   const uint8_t *pv = base + P.plane_data_off[2] + (long long)(y >> ydec)*(P.plane_hblocks[2]*8)
-   + (x0 >> xdec);
+   + (xl >> xdec);
   uint32_t ub[2] = {0, 0}, vb[2] = {0, 0};                         // 8 >> xdec chroma bytes
   if (xdec == 0) {
     const uint2 a = *reinterpret_cast<const uint2 *>(pu), b = *reinterpret_cast<const uint2 *>(pv);
@@ -764,7 +875,16 @@ __global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, i
   b2.x = pack_u8x4(rgb[16], rgb[17], rgb[18], rgb[19]);
   b2.y = pack_u8x4(rgb[20], rgb[21], rgb[22], rgb[23]);
   uint8_t *o = P.out + (long long)img*P.out_stride + ((long long)y*P.width + x0)*3;
-  store_rgb_row(o, a, b2, P.out_aligned && n == 8, x0, P.width);
+  // staged when the wave's first `nin` lanes (an even number) hold 8 whole pixels each and the
+  // others nothing at all, and lane 0's address is 16-byte aligned
+  const unsigned long long whole = __builtin_amdgcn_ballot_w64(n == 8);
+  const unsigned long long some = __builtin_amdgcn_ballot_w64(n > 0);
+  const int nin = (int)__builtin_popcountll(whole);
+  const bool wfast = P.out_aligned && whole == some && nin >= 2 && (nin & 1) == 0
+   && whole == (nin == 64 ? ~0ull : (1ull << nin) - 1ull)
+   && (((uintptr_t)o - (uintptr_t)lane*24u) & 15u) == 0;
+  if (__builtin_amdgcn_readfirstlane((int)wfast)) store_rgb_row_wave(stage_mem[wave], lane, o - lane*24, a, b2, nin*3/2);
+  else if (live) store_rgb_row(o, a, b2, P.out_aligned && n == 8, x0, P.width);
 }
 
 // ---------------------------------------------------------------------------
@@ -793,7 +913,15 @@ extern "C" int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec,
     e = hipGetLastError();
   }
   else {
-    if (xdec == 0 && ydec == 0) e = launch_rgb_t<0, 0>(*P, st);
+    // 4:4:4: the row-parallel kernel (JGA_RGB444=tile selects the generic tile kernel, for A/B)
+    static const bool generic444 = getenv("JGA_RGB444") && !strcmp(getenv("JGA_RGB444"), "tile");
+    if (xdec == 0 && ydec == 0 && !generic444) {
+      dim3 grid((P->nhmb + 63)/64, P->nvmb, P->nimages), block(192);
+      if (P->dequant) hipLaunchKernelGGL(jga_idct_rgb444_kernel<true>, grid, block, 0, st, *P);
+      else hipLaunchKernelGGL(jga_idct_rgb444_kernel<false>, grid, block, 0, st, *P);
+      e = hipGetLastError();
+    }
+    else if (xdec == 0 && ydec == 0) e = launch_rgb_t<0, 0>(*P, st);
     else if (xdec == 1 && ydec == 0) e = launch_rgb_t<1, 0>(*P, st);
     else if (xdec == 1 && ydec == 1) e = launch_rgb_t<1, 1>(*P, st);
     else if (xdec == 0 && ydec == 1) e = launch_rgb_t<0, 1>(*P, st);

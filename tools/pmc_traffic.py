@@ -54,7 +54,7 @@ def main():
             sys.stderr.write(r.stderr[-2000:])
             sys.exit("rocprofv3 pass '%s' failed" % name)
         vals = collections.defaultdict(list)
-        for fn in glob.glob(os.path.join(args.out, "**", name + "_counter_collection.csv"), recursive=True):
+        for fn in glob.glob(os.path.join(args.out, "**", "*" + name + "_counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(fn)):
                 if KERNEL in row["Kernel_Name"]:
                     vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
