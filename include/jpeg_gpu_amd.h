@@ -293,6 +293,10 @@ void *jga_device_malloc(size_t bytes);
 void  jga_device_free(void *p);
 void *jga_host_malloc_pinned(size_t bytes);
 void  jga_host_free_pinned(void *p);
+/* Pin memory the caller already owns (hipHostRegister): ingest buffers a pipeline may DMA from
+ * directly (jga_job.pinned).  Returns EXIT_SUCCESS / EXIT_FAILURE. */
+int   jga_host_register(void *p, size_t bytes);
+int   jga_host_unregister(void *p);
 int   jga_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int   jga_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
 int   jga_device_memset(void *dst, int value, size_t bytes, void *stream);
@@ -332,6 +336,10 @@ typedef struct jga_pipeline_config {
   int batch;                   /* transport 2: 4K frames per GPU entropy batch (0 = 48); smaller
                                 * frames fill a group to about the same pixel count (up to 16x
                                 * as many); jobs are grouped by geometry in arrival order */
+  int unstuff;                 /* transport 2, where stuffing and RSTn markers are removed: 0 = auto (on
+                                * the GPU for groups whose jobs are all `pinned`, else on the host:
+                                * one core unstuffs ~12 GB/s, as fast as it could copy), 1 = host,
+                                * 2 = GPU (jga_huff_set_device_unstuff) */
 } jga_pipeline_config;
 
 typedef struct jga_job {
@@ -342,6 +350,8 @@ typedef struct jga_job {
   int status;                  /* out: 0 ok, 1 failed */
   int width, height, nplanes;  /* out */
   long long h2d_bytes;         /* out: coefficient bytes this image sent over PCIe */
+  int pinned;                  /* in : `jpeg` lies in pinned memory (transport 2 with on-device
+                                * unstuffing then uploads the scan straight from it) */
 } jga_job;
 
 jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);
@@ -381,6 +391,21 @@ int jga_huff_last_assisted(const jga_huff_batch *b);
 int jga_huff_image_errors(const jga_huff_batch *b);
 int jga_huff_image_error(const jga_huff_batch *b, int i);
 const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
+/* Where the scan's byte-level clean-up happens (stuffed zeros, fill bytes, RSTn markers ->
+ * restart segments; T.81 B.1.1.5, the reference's bit reader src/xjpeg.c:113-127, 593-629):
+ * 0 = on the host inside jga_huff_prepare (one core unstuffs ~3 GB/s), 1 = on the GPU — prepare
+ * then only parses the marker segments and copies the raw scans into pinned memory.  Same
+ * planes either way; with 1 a damaged restart structure is reported by jga_huff_decode
+ * (per-image verdicts) instead of jga_huff_prepare.  Default 0, or JGA_HUFF_DEVICE_UNSTUFF. */
+void jga_huff_set_device_unstuff(jga_huff_batch *b, int on);
+/* The JPEG buffers given to jga_huff_prepare are pinned (jga_host_malloc_pinned /
+ * jga_host_register): with on-device unstuffing their scans are copied by the DMA engine
+ * straight from where they lie and the host touches no entropy-coded byte at all.  The buffers
+ * must stay unchanged until the stream has executed prepare()'s copies. */
+void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on);
+/* 1: the host waits inside jga_huff_decode sleep on a blocking event instead of spinning in
+ * hipStreamSynchronize — for pipelines whose lanes outnumber the CPUs they may use. */
+void jga_huff_set_blocking_waits(jga_huff_batch *b, int on);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);
 

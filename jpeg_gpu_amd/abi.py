@@ -82,13 +82,14 @@ class jga_pipeline_config(C.Structure):
     _fields_ = [("device", C.c_int), ("nthreads", C.c_int), ("depth", C.c_int),
                 ("out", C.c_int), ("copy_back", C.c_int),
                 ("max_coef_shorts", C.c_longlong), ("max_out_bytes", C.c_longlong),
-                ("transport", C.c_int), ("batch", C.c_int)]
+                ("transport", C.c_int), ("batch", C.c_int), ("unstuff", C.c_int)]
 
 
 class jga_job(C.Structure):
     _fields_ = [("jpeg", C.c_void_p), ("size", C.c_int), ("host_out", C.c_void_p),
                 ("dev_out", C.c_void_p), ("status", C.c_int), ("width", C.c_int),
-                ("height", C.c_int), ("nplanes", C.c_int), ("h2d_bytes", C.c_longlong)]
+                ("height", C.c_int), ("nplanes", C.c_int), ("h2d_bytes", C.c_longlong),
+                ("pinned", C.c_int)]
 
 
 # SURVEY.md §8b ABI numbers (x86-64 SysV)

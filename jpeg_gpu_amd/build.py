@@ -23,7 +23,7 @@ OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
 C_SOURCES = ["layout.c", "entropy.c", "libjpeg_vtbl.c"]
-HIP_SOURCES = ["idct_kernels.hip", "huff_kernels.hip", "pack_kernels.hip"]   # device code: hipcc
+HIP_SOURCES = ["idct_kernels.hip", "huff_kernels.hip", "pack_kernels.hip", "unstuff_kernels.hip"]   # device code: hipcc
 CXX_SOURCES = ["device_api.cpp", "vtbl.cpp", "pipeline.cpp", "huff_prepare.cpp",
                "huff_api.cpp"]                           # host only: g++ + HIP API
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -83,7 +83,7 @@ def build(force=False, verbose=False):
 def _build_locked(force, verbose):
     headers = [os.path.join(CSRC, h) for h in ("jga_internal.h", "kernel_params.h", "huff_common.h",
                                                "huff_kernels.h", "huff_prepare.h", "pack_params.h",
-                                               "libjpeg8_abi.h")]
+                                               "libjpeg8_abi.h", "unstuff_kernels.h")]
     headers.append(os.path.join(HERE, "..", "include", "jpeg_gpu_amd.h"))
     all_src = [os.path.join(CSRC, s) for s in C_SOURCES + HIP_SOURCES + CXX_SOURCES] + headers
 

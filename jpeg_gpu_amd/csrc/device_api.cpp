@@ -318,6 +318,14 @@ JGA_EXPORT int jga_set_device(int dev) {
   HIP_TRY(hipSetDevice(dev));
   return EXIT_SUCCESS;
 }
+JGA_EXPORT int jga_host_register(void *p, size_t bytes) {
+  HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_host_unregister(void *p) {
+  HIP_TRY(hipHostUnregister(p));
+  return EXIT_SUCCESS;
+}
 JGA_EXPORT int jga_device_pci_bus_id(int dev, char *buf, int len) {
   if (!buf || len < 13) return jga_fail("jga_device_pci_bus_id: buffer too small");
   HIP_TRY(hipDeviceGetPCIBusId(buf, len, dev));

@@ -16,6 +16,7 @@
 #include <vector>
 #include "huff_kernels.h"
 #include "huff_prepare.h"
+#include "unstuff_kernels.h"
 
 #define HOK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return jga_fail("huff: HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #call); } while (0)
@@ -43,15 +44,24 @@ struct jga_huff_batch {
   int assist_hint;             // the previous decode needed the host walk
   hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
+  hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
+  int blocking_waits;
   size_t sub_cap;
   // current batch
   int nimages;
   uint32_t total_sub, total_seg, max_nsub;
   size_t off_images, off_segs, off_subseg, off_tables, off_S, off_scan, blob_size, upload_size, scan_bytes;
   int prepare_threads;
+  // on-device unstuffing (unstuff_kernels.hip): the raw scans go up, the clean streams and the
+  // segment tables are made in HBM; the host-side copies assist_chains() needs are fetched lazily
+  int device_unstuff, unstuffed_on_device;
+  int inputs_pinned;           // callers' JPEG buffers are pinned/registered: DMA the scans straight from them
+  size_t off_raw, off_uimg, off_part, off_bnd, off_info, off_perr;
+  int max_chunks;
   jga_geom geom;
   std::vector<unsigned short> qtab;
   std::vector<unsigned char> verdict;   // last prepare(), per image: 0 ok, 1 unusable, 2 host entropy stage
+  std::vector<unsigned char> shadow;    // device unstuffing: images | segs | clean scans read back (blob offsets)
   int last_rounds;
 };
 
@@ -90,6 +100,7 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
     const int v = atoi(e);
     b->force_sub_log2 = v == 32 ? 5 : v == 64 ? 6 : v == 128 ? 7 : 0;
   }
+  if (const char *e = getenv("JGA_HUFF_DEVICE_UNSTUFF")) b->device_unstuff = atoi(e) != 0;
   const size_t seg_cap = b->sub_cap;   // worst case one segment per subsequence
   b->blob_cap = align_up(sizeof(hj_image)*max_images, 256) + align_up(sizeof(hj_segment)*seg_cap, 256)
    + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_tables)*max_images, 256)
@@ -106,7 +117,8 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess
    && hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming) == hipSuccess
-   && hipEventCreateWithFlags(&b->ev_zeroed, hipEventDisableTiming) == hipSuccess;
+   && hipEventCreateWithFlags(&b->ev_zeroed, hipEventDisableTiming) == hipSuccess
+   && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
   if (!ok) {
     jga_fail("huff: allocation failed (%d images, %lld scan bytes)", max_images, max_scan_bytes);
     jga_huff_destroy(b);
@@ -131,6 +143,7 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->side) (void)hipStreamDestroy(b->side);
   if (b->ev_begin) (void)hipEventDestroy(b->ev_begin);
   if (b->ev_zeroed) (void)hipEventDestroy(b->ev_zeroed);
+  if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
   delete b;
 }
 
@@ -188,12 +201,169 @@ struct phase_barrier {
 };
 }  // namespace
 
+
+// prepare() with the unstuffing left to the device: the host parses the marker segments
+// (phase A, as below), copies the RAW entropy-coded bytes of every image into the pinned blob,
+// uploads, and queues unstuff_kernels.hip behind the copy.  Per-lane arrays are sized by what
+// the raw lengths allow (a clean stream is never longer than the raw one): image i may own up
+// to ceil(avail/sub) + nseg subsequences; how many it really has is known on the device only.
+static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, const int *sizes, int n,
+ jga_geom *geom, void *stream) {
+  std::vector<hj_prepared> prep((size_t)n);
+  std::atomic<int> next_a(0), next_b(0), failed(0), irregular(0);
+  int nt = b->prepare_threads;
+  if (nt <= 0) {
+    nt = jga_cpu_budget();
+    if (nt > 64) nt = 64;
+  }
+  if (nt > n) nt = n;
+  b->qtab.assign((size_t)n*192, 0);
+  b->verdict.assign((size_t)n, 0);
+  b->nimages = 0;
+  auto heads = [&]() {
+    for (int i = next_a.fetch_add(1); i < n; i = next_a.fetch_add(1)) {
+      const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
+      if (rc != EXIT_SUCCESS) failed.fetch_add(1);
+      if (rc == HJ_PREPARE_IRREGULAR) irregular.fetch_add(1);
+      b->verdict[i] = (unsigned char)(rc == EXIT_SUCCESS ? 0 : rc == HJ_PREPARE_IRREGULAR ? 2 : 1);
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(heads);
+    heads();
+    for (auto &th : pool) th.join();
+  }
+  if (irregular.load()) {
+    return jga_fail("huff: %d image(s) of the batch have Huffman tables too irregular (or a frame too "
+     "large) for the GPU entropy stage", irregular.load());
+  }
+  if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
+  b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(0);
+  std::vector<hj_unstuff_image> uimg((size_t)n);
+  std::vector<uint32_t> sub0v((size_t)n), seg0v((size_t)n);
+  size_t o = 0, total_sub = 0, total_seg = 0, total_chunks = 0;
+  uint32_t max_nsub = 0, max_chunks = 0;
+  for (int i = 0; i < n; i++) {
+    if (i && !same_geometry(prep[i].geom, prep[0].geom)) return jga_fail("huff: images of one batch must share a geometry");
+    const jga_geom &g = prep[i].geom;
+    hj_unstuff_image &u = uimg[(size_t)i];
+    u.raw_off = (uint32_t)o;
+    u.avail = prep[i].avail;
+    u.ri = (uint32_t)g.restart_interval;
+    u.total_mcus = (uint32_t)g.nhmb*(uint32_t)g.nvmb;
+    u.nseg = u.ri ? (u.total_mcus + u.ri - 1)/u.ri : 1u;
+    u.nchunks = (u.avail + HJ_UNSTUFF_CHUNK - 1)/HJ_UNSTUFF_CHUNK;
+    if (u.nchunks == 0) u.nchunks = 1;
+    u.chunk0 = (uint32_t)total_chunks;
+    u.pad_ = 0;
+    const uint32_t bound = ((u.avail + (1u << b->sub_log2) - 1) >> b->sub_log2) + u.nseg;
+    sub0v[(size_t)i] = (uint32_t)total_sub;
+    seg0v[(size_t)i] = (uint32_t)total_seg;
+    total_sub += bound;
+    total_seg += u.nseg;
+    total_chunks += u.nchunks;
+    if (bound > max_nsub) max_nsub = bound;
+    if (u.nchunks > max_chunks) max_chunks = u.nchunks;
+    o += align_up((size_t)u.avail + 16, 16);
+  }
+  if ((long long)o > b->max_scan + 64ll*n || o >= ((size_t)1 << 32)) {
+    return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
+  }
+  b->scan_bytes = 0;                                         // (nothing to carry over if the blob grows)
+  const size_t raw_bytes = align_up(o, 256);
+  size_t q = 0;
+  b->off_raw = q; q += raw_bytes;
+  b->off_images = q; q += align_up(sizeof(hj_image)*n, 256);
+  b->off_tables = q; q += align_up(sizeof(hj_tables)*n, 256);
+  b->off_uimg = q; q += align_up(sizeof(hj_unstuff_image)*n, 256);
+  b->upload_size = q;                                        // what crosses PCIe
+  b->off_scan = q; q += raw_bytes;                           // the clean streams, same offsets as the raw ones
+  b->off_segs = q; q += align_up(sizeof(hj_segment)*total_seg, 256);
+  b->off_subseg = q; q += align_up(4*total_sub, 256);
+  b->off_S = q; q += align_up(8*(total_sub + total_seg), 256);
+  b->off_part = q; q += align_up(8*total_chunks, 256);
+  b->off_bnd = q; q += align_up(4*total_seg, 256);
+  b->off_info = q; q += align_up(sizeof(hj_unstuff_info)*n, 256);
+  b->off_perr = q; q += align_up(4*(size_t)n, 256);
+  b->blob_size = q;
+  const size_t need_sub = total_sub > total_seg ? total_sub : total_seg;
+  if ((need_sub > b->sub_cap || q > b->blob_cap) && !grow_batch(b, need_sub, q)) {
+    return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
+  }
+  hj_image *images = (hj_image *)(b->h_blob + b->off_images);
+  hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
+  memcpy(b->h_blob + b->off_uimg, uimg.data(), sizeof(hj_unstuff_image)*(size_t)n);
+  const bool zero_copy = b->inputs_pinned != 0;
+  auto copies = [&]() {
+    for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
+      hj_prepared &p = prep[i];
+      if (!zero_copy) memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + p.desc->scan_off, p.avail);
+      p.im.sub0 = sub0v[(size_t)i];
+      p.im.seg0 = seg0v[(size_t)i];
+      p.im.scan_off = uimg[(size_t)i].raw_off;
+      p.im.nseg = uimg[(size_t)i].nseg;
+      p.im.nsub = 0;                                         // (the device fills these two in)
+      p.im.scan_len = 0;
+      images[i] = p.im;
+      tables[i] = p.tabs;
+      memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(copies);
+    copies();
+    for (auto &th : pool) th.join();
+  }
+  b->nimages = n;
+  b->total_sub = (uint32_t)total_sub;
+  b->total_seg = (uint32_t)total_seg;
+  b->max_nsub = max_nsub;
+  b->max_chunks = (int)max_chunks;
+  b->geom = prep[0].geom;
+  b->unstuffed_on_device = 1;
+  b->shadow.clear();
+  hipStream_t st = (hipStream_t)stream;
+  if (zero_copy) {
+    // the files lie in pinned memory: the DMA engine reads the scans where they are (the host
+    // never touches an entropy-coded byte); descriptors + tables go up from the blob as usual
+    for (int i = 0; i < n; i++) {
+      HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
+       prep[i].avail, hipMemcpyHostToDevice, st));
+    }
+    HOK(hipMemcpyAsync(b->d_blob + b->off_images, b->h_blob + b->off_images, b->upload_size - b->off_images,
+     hipMemcpyHostToDevice, st));
+  }
+  else HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, st));
+  HOK(hipMemsetAsync(b->d_blob + b->off_info, 0xFF, sizeof(hj_unstuff_info)*(size_t)n, st));
+  HOK(hipMemsetAsync(b->d_blob + b->off_perr, 0, 4*(size_t)n, st));
+  hj_unstuff_args U;
+  memset(&U, 0, sizeof(U));
+  U.raw = b->d_blob + b->off_raw;
+  U.clean = b->d_blob + b->off_scan;
+  U.images = (hj_image *)(b->d_blob + b->off_images);
+  U.segs = (hj_segment *)(b->d_blob + b->off_segs);
+  U.uimg = (const hj_unstuff_image *)(b->d_blob + b->off_uimg);
+  U.part = (uint32_t *)(b->d_blob + b->off_part);
+  U.bnd = (uint32_t *)(b->d_blob + b->off_bnd);
+  U.info = (hj_unstuff_info *)(b->d_blob + b->off_info);
+  U.errors = (uint32_t *)(b->d_blob + b->off_perr);
+  U.nimages = n;
+  U.sub_log2 = b->sub_log2;
+  if (hj_launch_unstuff(&U, b->max_chunks, st)) return jga_fail("huff: launch failed");
+  if (geom) *geom = b->geom;
+  return EXIT_SUCCESS;
+}
+
 // Parse + stage a batch.  All images must share one geometry (returned in *geom).
 // Host work per image (marker parse, table build, unstuffing straight into the pinned
 // upload buffer, lane start states) is independent and fanned out over a thread team.
 JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *jpegs,
  const int *sizes, int n, jga_geom *geom, void *stream) {
   if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
+  if (b->device_unstuff) return prepare_raw(b, jpegs, sizes, n, geom, stream);
+  b->unstuffed_on_device = 0;
   const auto t_p0 = std::chrono::steady_clock::now();
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
@@ -332,6 +502,16 @@ JGA_EXPORT int jga_huff_prepare_verdict(const jga_huff_batch *b, int i) {
   return (i >= 0 && (size_t)i < b->verdict.size()) ? (int)b->verdict[(size_t)i] : -1;
 }
 
+// 1: prepare() uploads the raw scans and the device removes stuffing / RSTn markers and builds the
+// restart segments (unstuff_kernels.hip); 0: the host does (hj_prepare_scan).  Same results.
+JGA_EXPORT void jga_huff_set_device_unstuff(jga_huff_batch *b, int on) { b->device_unstuff = on != 0; }
+// The buffers handed to prepare() are pinned (hipHostMalloc / hipHostRegister, e.g. jga_host_register):
+// with on-device unstuffing the scans are then DMA'd straight out of them.  The caller keeps them
+// unchanged until the stream has passed the copies (any later jga_huff_decode has).
+JGA_EXPORT void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on) { b->inputs_pinned = on != 0; }
+// 1: jga_huff_decode's host waits sleep (blocking event) instead of spinning on a core.
+JGA_EXPORT void jga_huff_set_blocking_waits(jga_huff_batch *b, int on) { b->blocking_waits = on != 0; }
+
 // Host threads prepare() may use (0 = up to 64, one per image).
 JGA_EXPORT void jga_huff_set_threads(jga_huff_batch *b, int nthreads) { b->prepare_threads = nthreads; }
 
@@ -367,14 +547,26 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
   HOK(hipMemcpyAsync(S, b->d_blob + b->off_S, 8*ns, hipMemcpyDeviceToHost, st));
   HOK(hipMemcpyAsync(last_in, b->d_last_in, 8*nl, hipMemcpyDeviceToHost, st));
   HOK(hipStreamSynchronize(st));
-  const hj_image *images = (const hj_image *)(b->h_blob + b->off_images);
-  const hj_segment *segs = (const hj_segment *)(b->h_blob + b->off_segs);
+  const unsigned char *host = b->h_blob;
+  if (b->unstuffed_on_device) {
+    // the descriptors, segment tables and clean streams exist in HBM only: fetch them once
+    // (a rare path: streams that never fall into step)
+    if (b->shadow.empty()) {
+      b->shadow.resize(b->off_segs + align_up(sizeof(hj_segment)*b->total_seg, 256));
+      HOK(hipMemcpy(b->shadow.data() + b->off_images, b->d_blob + b->off_images, sizeof(hj_image)*(size_t)b->nimages, hipMemcpyDeviceToHost));
+      HOK(hipMemcpy(b->shadow.data() + b->off_scan, b->d_blob + b->off_scan,
+       b->off_segs - b->off_scan + sizeof(hj_segment)*(size_t)b->total_seg, hipMemcpyDeviceToHost));
+    }
+    host = b->shadow.data();
+  }
+  const hj_image *images = (const hj_image *)(host + b->off_images);
+  const hj_segment *segs = (const hj_segment *)(host + b->off_segs);
   const hj_tables *tables = (const hj_tables *)(b->h_blob + b->off_tables);
   std::atomic<int> next(0), walked(0);
   auto work = [&]() {
     for (int i = next.fetch_add(1); i < b->nimages; i = next.fetch_add(1)) {
       const hj_image &im = images[i];
-      walked.fetch_add(hj_walk_unsettled(im, segs + im.seg0, &tables[i], b->h_blob + b->off_scan + im.scan_off,
+      walked.fetch_add(hj_walk_unsettled(im, segs + im.seg0, &tables[i], host + b->off_scan + im.scan_off,
        S + im.sub0 + im.seg0, last_in + im.sub0, b->sub_log2), std::memory_order_relaxed);
     }
   };
@@ -392,6 +584,16 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
 }
 
 static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, hipStream_t st);
+
+// Wait for everything queued on `st`.  hipStreamSynchronize spins on a host core — the right
+// thing for one frame's latency, the wrong one for a pipeline whose lanes outnumber the CPUs
+// the container grants: there the waiting lane sleeps on a blocking event and leaves the core
+// to the lanes that are parsing headers.
+static hipError_t wait_stream(jga_huff_batch *b, hipStream_t st) {
+  if (!b->blocking_waits) return hipStreamSynchronize(st);
+  const hipError_t e = hipEventRecord(b->ev_wait, st);
+  return e != hipSuccess ? e : hipEventSynchronize(b->ev_wait);
+}
 
 JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  void *stream) {
@@ -432,7 +634,11 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   A.sub_log2 = b->sub_log2;
   if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
   HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));
-  HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
+  // (on-device unstuffing has already had its say about every image: early end, RSTn counters)
+  if (b->unstuffed_on_device) {
+    HOK(hipMemcpyAsync(b->d_errors, b->d_blob + b->off_perr, 4*(size_t)b->nimages, hipMemcpyDeviceToDevice, st));
+  }
+  else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
   // the planes are only touched by the write pass: zero them on the side stream, behind
   // whatever the caller's stream has queued so far, while the rounds run
   HOK(hipEventRecord(b->ev_begin, st));
@@ -475,7 +681,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
       }
     }
     HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
-    HOK(hipStreamSynchronize(st));
+    HOK(wait_stream(b, st));
     if (b->h_ran[round - 1] == 0) break;                   // a round in which nothing moved
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
     // (a batch object whose previous decode needed the walk — the same camera, the same
@@ -489,7 +695,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
   if (hj_launch_write(&A, (int)b->max_nsub, write_gmem, st)) return jga_fail("huff: launch failed");
   HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
-  HOK(hipStreamSynchronize(st));
+  HOK(wait_stream(b, st));
   // per-image verdicts stay readable (jga_huff_image_error): the other images of the batch
   // are decoded correctly whatever one damaged member did
   b->image_errors = 0;

@@ -57,6 +57,7 @@ struct worker {
 // transport 2: one GPU-entropy lane
 struct hlane {
   hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;        // blocking: a lane waiting for its group sleeps
   jga_huff_batch *hb = nullptr;
   int hb_images = 0;
   long long hb_scan = 0;
@@ -81,6 +82,9 @@ struct jga_pipeline {
   std::mutex dev_mutex;
   std::condition_variable dev_cv;
   int dev_slots = 3;
+  // Lanes wait for the device several times per group; spinning in hipStreamSynchronize would
+  // hold a core each, and a container may grant fewer cores than there are lanes.
+  int blocking = 1;
 };
 
 namespace {
@@ -248,6 +252,7 @@ void free_lane(hlane &l) {
   if (l.d_out) (void)hipFree(l.d_out);
   if (l.h_out) (void)hipHostFree(l.h_out);
   if (l.h_coef) (void)hipHostFree(l.h_coef);
+  if (l.done) (void)hipEventDestroy(l.done);
   if (l.stream) (void)hipStreamDestroy(l.stream);
   l = hlane();
 }
@@ -302,10 +307,19 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     l.hb_scan = total + total/4 > l.hb_scan ? total + total/4 : l.hb_scan;
     l.hb = jga_huff_create(l.hb_images, l.hb_scan);
     if (!l.hb) { l.hb_images = 0; l.hb_scan = 0; return EXIT_FAILURE; }
+
   }
   const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
   const auto t_a = std::chrono::steady_clock::now();
   jga_huff_set_threads(l.hb, threads);
+  {
+    bool pinned = true;
+    for (int i = 0; i < m; i++) pinned = pinned && jobv[i]->pinned != 0;
+    const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pinned);
+    jga_huff_set_device_unstuff(l.hb, on_device);
+    jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
+    jga_huff_set_blocking_waits(l.hb, pl->blocking);
+  }
   // A lone image whose Huffman tables do not fit the device lookup format takes the host
   // entropy stage (csrc/entropy.c) instead; everything after it is the same.
   bool host_entropy = false, damaged = false;
@@ -377,7 +391,10 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
       if (!HOK(hipMemcpyAsync(l.h_out + ostride*i, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return EXIT_FAILURE;
     }
   }
-  if (!HOK(hipStreamSynchronize(l.stream))) return EXIT_FAILURE;
+  if (pl->blocking ? !(HOK(hipEventRecord(l.done, l.stream)) && HOK(hipEventSynchronize(l.done)))
+   : !HOK(hipStreamSynchronize(l.stream))) {
+    return EXIT_FAILURE;
+  }
   turn.give();
   if (trace) {
     const auto t_d = std::chrono::steady_clock::now();
@@ -494,8 +511,10 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->lanes.resize(pl->cfg.depth > 0 ? pl->cfg.depth : 6);
     if (const char *e = getenv("JGA_PIPE_DEVICE_SLOTS")) pl->dev_slots = atoi(e) > 0 ? atoi(e) : 1;   // tuning knob
     if (pl->dev_slots > (int)pl->lanes.size()) pl->dev_slots = (int)pl->lanes.size();
+    if (const char *e = getenv("JGA_PIPE_SPIN")) pl->blocking = atoi(e) == 0;         // tuning knob
     for (auto &l : pl->lanes) {
-      if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")) {
+      if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")
+       || !hip_ok(hipEventCreateWithFlags(&l.done, hipEventDisableTiming | hipEventBlockingSync), "hipEventCreate")) {
         jga_pipeline_destroy(pl);
         return nullptr;
       }

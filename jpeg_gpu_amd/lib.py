@@ -23,7 +23,8 @@ EXPORTED = [
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
     "jga_huff_decode", "jga_huff_prepare_verdict", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
-    "jga_huff_set_threads",
+    "jga_huff_set_threads", "jga_huff_set_device_unstuff", "jga_huff_set_inputs_pinned", "jga_huff_set_blocking_waits",
+    "jga_host_register", "jga_host_unregister",
 ]
 
 
@@ -110,6 +111,14 @@ L.jga_huff_image_errors.argtypes = [_vp]
 L.jga_huff_image_error.argtypes = [_vp, C.c_int]
 L.jga_huff_set_threads.argtypes = [_vp, _i]
 L.jga_huff_set_threads.restype = None
+L.jga_huff_set_device_unstuff.argtypes = [_vp, _i]
+L.jga_huff_set_device_unstuff.restype = None
+L.jga_huff_set_inputs_pinned.argtypes = [_vp, _i]
+L.jga_huff_set_inputs_pinned.restype = None
+L.jga_huff_set_blocking_waits.argtypes = [_vp, _i]
+L.jga_huff_set_blocking_waits.restype = None
+L.jga_host_register.argtypes = [_vp, C.c_size_t]
+L.jga_host_unregister.argtypes = [_vp]
 L.jga_huff_qtabs.argtypes = [_vp]
 L.jga_huff_qtabs.restype = C.POINTER(C.c_ushort)
 
@@ -346,20 +355,40 @@ class Decoder:
         self.close()
 
 
+class PinnedBytes:
+    """A copy of `data` in pinned host memory (hipHostMalloc), as a uint8 numpy view: an ingest
+    buffer the DMA engine can read directly."""
+
+    def __init__(self, data):
+        n = len(data)
+        self.ptr = L.jga_host_malloc_pinned(max(n, 1))
+        if not self.ptr:
+            raise JgaError((L.jga_last_error() or b"hipHostMalloc failed").decode())
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_ubyte)), (n,))
+        self.array[:] = np.frombuffer(bytes(data), np.uint8)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            L.jga_host_free_pinned(self.ptr)
+            self.ptr = None
+
+
 # ---- pipeline -------------------------------------------------------------------
 
 class Pipeline:
     def __init__(self, device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
-                 max_coef_shorts=0, max_out_bytes=0, transport=0, batch=0, depth=0):
+                 max_coef_shorts=0, max_out_bytes=0, transport=0, batch=0, depth=0, unstuff=0):
         cfg = abi.jga_pipeline_config(device, nthreads, depth, out, int(copy_back),
-                                      max_coef_shorts, max_out_bytes, int(transport), int(batch))
+                                      max_coef_shorts, max_out_bytes, int(transport), int(batch),
+                                      int(unstuff))
         self.ptr = L.jga_pipeline_create(C.byref(cfg))
         if not self.ptr:
             raise JgaError((L.jga_last_error() or b"pipeline_create failed").decode())
         self.copy_back = copy_back
 
     @staticmethod
-    def make_jobs(jpegs, host_outs=None, dev_outs=None):
+    def make_jobs(jpegs, host_outs=None, dev_outs=None, pinned=False):
         """The jga_job array for a run (built outside any timed region).  The returned object
         keeps the input buffers alive."""
         n = len(jpegs)
@@ -368,11 +397,13 @@ class Pipeline:
         for i, j in enumerate(jpegs):
             v = views.get(id(j))
             if v is None:
-                v = views[id(j)] = np.frombuffer(bytes(j), np.uint8)
+                # (a numpy array is used where it lies — e.g. a PinnedBytes buffer; bytes are viewed)
+                v = views[id(j)] = j if isinstance(j, np.ndarray) else np.frombuffer(bytes(j), np.uint8)
             jobs[i].jpeg = v.ctypes.data
             jobs[i].size = v.size
             jobs[i].host_out = host_outs[i].ctypes.data if host_outs is not None else None
             jobs[i].dev_out = dev_outs[i] if dev_outs is not None else None
+            jobs[i].pinned = int(pinned)
         jobs._keep = (list(views.values()), list(jpegs), host_outs)
         return jobs
 
@@ -394,10 +425,12 @@ class Pipeline:
 class HuffBatch:
     """jga_huff_*: Huffman decode of a same-geometry batch on the GPU."""
 
-    def __init__(self, max_images, max_scan_bytes):
+    def __init__(self, max_images, max_scan_bytes, device_unstuff=None):
         self.ptr = L.jga_huff_create(max_images, max_scan_bytes)
         if not self.ptr:
             raise JgaError((L.jga_last_error() or b"jga_huff_create failed").decode())
+        if device_unstuff is not None:
+            L.jga_huff_set_device_unstuff(self.ptr, int(device_unstuff))
         self.n = 0
         self.geom = None
 
@@ -481,9 +514,9 @@ def gpu_unpack(g, packs, indexes, pack_words=None):
         d_pack.free(); d_idx.free(); d_coef.free()
 
 
-def gpu_entropy_decode(jpegs):
+def gpu_entropy_decode(jpegs, device_unstuff=None):
     """Decode the scans of same-geometry JPEGs on the GPU -> (geom, (n, coef_shorts) int16, rounds)."""
-    hb = HuffBatch(len(jpegs), sum(len(j) for j in jpegs) + 4096)
+    hb = HuffBatch(len(jpegs), sum(len(j) for j in jpegs) + 4096, device_unstuff)
     try:
         g = hb.prepare(jpegs)
         stride = _align(g.coef_shorts * 2) // 2

@@ -340,6 +340,41 @@ def oracle_quant(orc, data):
     return orc.decode(data, oracle.QUANT)[1]
 
 
+@pytest.mark.parametrize("mode", ["pinned", "device", "host", "mixed"])
+def test_pipeline_unstuff_modes_and_pinned_inputs(gpu, orc, synth, mode):
+    """transport 2 with the scan clean-up on the host, on the GPU, and — for jobs whose files lie
+    in pinned memory — on the GPU with the scans DMA'd straight out of the callers' buffers
+    (no host copy); a group that mixes pinned and pageable files takes the host route.  Same
+    pixels every way, damaged member reported alone."""
+    from jpeg_gpu_amd import abi
+    datas = [synth.synthetic_jpeg(640, 360, "420", quality=60 + i, seed=i, restart_interval=(i % 3) * 20)
+             for i in range(20)]
+    bad = bytearray(datas[7])
+    bad[len(bad) // 2:len(bad) // 2 + 40] = b"\xff\xd9" * 20          # an EOI in mid-scan
+    datas[7] = bytes(bad)
+    _, g = gpu.geom_of(datas[0])
+    want = [orc.decode_rgb(d)[1].reshape(-1) if i != 7 else None for i, d in enumerate(datas)]
+    pins = [gpu.PinnedBytes(d) for d in datas] if mode in ("pinned", "mixed") else []
+    srcs = [p.array for p in pins] if mode == "pinned" else list(datas)
+    outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in datas]
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2,
+                      batch=1, depth=2, unstuff={"pinned": 0, "mixed": 0, "device": 2, "host": 1}[mode])
+    try:
+        jobs = gpu.Pipeline.make_jobs(srcs, host_outs=outs, pinned=(mode == "pinned"))
+        if mode == "mixed":
+            for i in range(0, len(datas), 2):
+                jobs[i].jpeg, jobs[i].pinned = pins[i].array.ctypes.data, 1
+        rc = pl.run_jobs(jobs)
+        assert rc == 1 and [j.status for j in jobs] == [int(i == 7) for i in range(len(datas))]
+        for i in range(len(datas)):
+            if i != 7:
+                assert np.array_equal(outs[i], want[i]), (mode, i)
+    finally:
+        pl.close()
+        for p in pins:
+            p.free()
+
+
 # ---- PACK wire format expanded on the GPU (SURVEY.md §8f-2) ---------------------------
 
 @pytest.mark.parametrize("sampling", SAMPLINGS)
@@ -421,6 +456,45 @@ def test_gpu_huffman_equals_oracle_quant_stage(gpu, orc, synth, sampling, ri):
     for d, c in zip(datas, coefs):
         assert np.array_equal(c, oracle_quant(orc, d)), (sampling, ri)
         assert np.array_equal(c, gpu.entropy_decode(d, g)), (sampling, ri)
+
+
+@pytest.mark.parametrize("sampling", SAMPLINGS)
+@pytest.mark.parametrize("ri", [0, -1, 1, 3])
+def test_gpu_unstuffing_then_huffman_equals_oracle_quant_stage(gpu, orc, synth, sampling, ri):
+    """The scan cleaned up ON THE DEVICE (csrc/unstuff_kernels.hip: stuffed zeros, fill bytes,
+    RSTn markers -> restart segments) and decoded there == the ORACLE's QUANT planes; sizes that
+    span several 4 KB chunks, with restart intervals from one MCU to a row to none."""
+    datas = [synth.synthetic_jpeg(333, 211, sampling, quality=q, restart_interval=ri, seed=q)
+             for q in (95, 60, 30)]
+    g, coefs, rounds = gpu.gpu_entropy_decode(datas, device_unstuff=True)
+    for d, c in zip(datas, coefs):
+        assert np.array_equal(c, oracle_quant(orc, d)), (sampling, ri)
+
+
+def test_gpu_unstuffing_full_size_golden_and_flat(gpu, orc, synth, golden_jpegs):
+    """8K with a restart interval per MCU row (BASELINE config 5), the golden files (Pillow's
+    optimised tables and DRI), and flat frames whose streams need the host's walk — which then
+    has to fetch the clean streams and segment tables from the device."""
+    data = synth.synthetic_jpeg(7680, 4320, "420", quality=90, restart_interval=-1, seed=5)
+    g, coefs, _ = gpu.gpu_entropy_decode([data], device_unstuff=True)
+    real = gpu.real_coef_mask(g)
+    assert np.array_equal(coefs[0][real], oracle_quant(orc, data)[real])
+    for name in golden_jpegs.names:
+        g, coefs, _ = gpu.gpu_entropy_decode([golden_jpegs.jpeg(name)], device_unstuff=True)
+        assert np.array_equal(coefs[0], golden_jpegs[name + ".quant"]), name
+    assisted = 0
+    for pattern in range(3):
+        lv = np.zeros(synth.coef_shorts(1920, 1080, "420"), np.int16)
+        if pattern == 1:
+            lv.reshape(-1, 64)[:, 0] = 5
+            lv.reshape(-1, 64)[::2, 0] = -5
+        elif pattern == 2:
+            lv.reshape(-1, 64)[:, 63] = 1
+        flat = synth.encode_levels(lv, 1920, 1080, "420")
+        g, coefs, _ = gpu.gpu_entropy_decode([flat, flat], device_unstuff=True)
+        assisted += gpu.gpu_entropy_decode.assisted
+        assert np.array_equal(coefs[1], oracle_quant(orc, flat)), pattern
+    assert assisted > 0
 
 
 def _letterboxed(gpu, synth, w, h, sampling, seed):
@@ -659,7 +733,7 @@ def test_gpu_huffman_on_corrupted_scans_agrees_with_the_host_stage(gpu, orc, syn
         except gpu.JgaError:
             want = None
         try:
-            got = gpu.gpu_entropy_decode([d])[1][0]
+            got = gpu.gpu_entropy_decode([d], device_unstuff=bool(it & 1))[1][0]    # both clean-ups
         except gpu.JgaError:
             got = None
         assert (got is None) == (want is None), it

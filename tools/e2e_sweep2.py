@@ -9,14 +9,19 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
 W, H = 3840, 2160
 with ThreadPoolExecutor(16) as ex:
     distinct = list(ex.map(lambda s: synth.synthetic_jpeg(W, H, "420", 90, seed=1234 + s), range(64)))
+PINNED = os.environ.get("PINNED", "0") == "1"
+if PINNED:
+    _pins = [lib.PinnedBytes(d) for d in distinct]
+    distinct = [p.array for p in _pins]
 cfgs = [(48, 6, t) for t in (6, 12, 24, 48, 96, 192)] + [(48, 4, 24), (48, 8, 48), (24, 8, 48), (32, 6, 48), (64, 6, 48), (96, 4, 48)]
 if os.environ.get("SWEEP_CFGS"):
     cfgs = [tuple(int(v) for v in c.split(",")) for c in os.environ["SWEEP_CFGS"].split()]
 for batch, depth, nthr in cfgs:
-    pl = lib.Pipeline(device=0, nthreads=nthr, out=abi.JPEG_DECODE_RGB, transport=2, batch=batch, depth=depth)
+    pl = lib.Pipeline(device=0, nthreads=nthr, out=abi.JPEG_DECODE_RGB, transport=2, batch=batch, depth=depth,
+                      unstuff=int(os.environ.get('UNSTUFF', '0')))
     cyc = lambda k, o=0: [distinct[(o + i) % 64] for i in range(k)]
-    pl.run_jobs(lib.Pipeline.make_jobs(cyc(batch * depth)))
-    jobs = lib.Pipeline.make_jobs(cyc(n, 3))
+    pl.run_jobs(lib.Pipeline.make_jobs(cyc(batch * depth), pinned=PINNED))
+    jobs = lib.Pipeline.make_jobs(cyc(n, 3), pinned=PINNED)
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter(); rc = pl.run_jobs(jobs); best = min(best, time.perf_counter() - t0)

@@ -57,6 +57,26 @@ int huff_emul_prepare_head(const unsigned char *jpeg, int size) {
   return hj_prepare_head(jpeg, size, &P);
 }
 
+// The host's clean-up of a file's scan (hj_prepare_scan): clean bytes, segment (start, end)
+// pairs.  Returns hj_prepare_image's code (0 ok); *scan_len / *nseg are set when it is 0.
+extern "C" __attribute__((visibility("default")))
+int huff_emul_clean_scan(const unsigned char *jpeg, int size, unsigned char *clean, long long cap,
+ unsigned *scan_len, unsigned *segs, int seg_cap, int *nseg, int *scan_off) {
+  hj_prepared P;
+  P.sub_log2 = g_sub_log2;
+  const int rc = hj_prepare_head(jpeg, size, &P);
+  if (rc != EXIT_SUCCESS) return rc;
+  if (scan_off) *scan_off = size - (int)P.avail;
+  P.clean.assign((size_t)P.avail + 16, 0);
+  if (hj_prepare_scan(jpeg, size, &P, P.clean.data()) != EXIT_SUCCESS) return 1;
+  if ((long long)P.scan_len > cap || (int)P.segs.size() > seg_cap) return 3;
+  memcpy(clean, P.clean.data(), P.scan_len);
+  *scan_len = P.scan_len;
+  *nseg = (int)P.segs.size();
+  for (size_t k = 0; k < P.segs.size(); k++) { segs[2*k] = P.segs[k].start; segs[2*k + 1] = P.segs[k].end; }
+  return 0;
+}
+
 static int g_assist_after = 0;
 // After this many rounds without settling, the host walk of huff_api.cpp's assist_chains()
 // (hj_walk_unsettled) is applied once per further round; 0 = never.  Returns walked
