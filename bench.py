@@ -426,6 +426,41 @@ def main():
         if not ok:
             raise SystemExit("bench.py: pipeline output differs from the oracle")
     pl.close()
+
+    # ---- the same measurement with the files in PINNED host memory (ingest buffers allocated with
+    # jga_host_malloc_pinned): the scans are DMA'd straight out of them and cleaned
+    # up on the GPU, the host only parses marker segments — what matters when ranks outnumber
+    # the CPUs the container grants (profiles/r2_unstuff_by_cpus.txt)
+    pinned_leg = None
+    if not args.no_e2e:
+        pins = [lib.PinnedBytes(j) for j in jpegs]
+        pcyc = lambda n, o=0: [pins[(o + i) % len(pins)].array for i in range(n)]
+        plp = lib.Pipeline(device=local_rank, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
+                           copy_back=False, transport=2, batch=B, depth=args.lanes)
+        plp.run_jobs(lib.Pipeline.make_jobs(pcyc(args.lanes * B), pinned=True))
+        pj = lib.Pipeline.make_jobs(pcyc(K * B, 13), pinned=True)
+        fence()
+        t0 = time.perf_counter()
+        rcp = plp.run_jobs(pj)
+        fence()
+        rp, _, tp = shard.aggregate_throughput(K * B * W * H, time.perf_counter() - t0,
+                                               dist if world > 1 else None, device="cuda")
+        okp = rcp == 0
+        if rank == 0:                               # its pixels too, against the oracle
+            import oracle
+            buf = lib.DeviceBuffer(g.rgb_bytes)
+            okp = okp and plp.run_jobs(lib.Pipeline.make_jobs(pcyc(1, 9), dev_outs=[buf.ptr], pinned=True)) == 0
+            okp = okp and bool(np.array_equal(buf.download(g.rgb_bytes),
+                                              oracle.Oracle().decode_rgb(jpegs[9 % len(jpegs)])[1].reshape(-1)))
+            buf.free()
+        plp.close()
+        pinned_leg = {"value": round(rp / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * B,
+                      "ok": okp, "ms_per_step": round(tp / K * 1e3, 4),
+                      "note": "as `value`, but the files lie in pinned host memory: scans DMA'd in place, "
+                              "unstuffed on the GPU (csrc/unstuff_kernels.hip); aggregated over ranks"}
+        del pj
+        for p_ in pins:
+            p_.free()
     PB, B = B, args.kernel_batch       # from here on B = images per launch of the stand-alone kernel legs
 
     # ---- roofline: the fused kernel alone, coefficient planes resident in HBM ----
@@ -477,6 +512,8 @@ def main():
     # ---- the north-star transport at every N: host Huffman threads -> pinned hipMemcpyAsync ->
     # fused kernel (entropy.c on this rank's cores; 24.9 MB of planes per image over PCIe)
     e2e = {}
+    if pinned_leg:
+        e2e["pinned_ingest_buffers_to_rgb_hbm"] = pinned_leg
     if not args.no_e2e:
         # Huffman threads also block on their slot's event: ~3 per granted CPU measured best
         # (profiles/r2_t0_sweep.txt: 32-48 threads on a 16-CPU grant, fewer AND more are slower)
