@@ -4,7 +4,7 @@
 #include <stddef.h>
 #include "huff_common.h"
 
-#define HJ_UNSTUFF_CHUNK 4096        /* raw bytes per workgroup (256 threads x 16) */
+#define HJ_UNSTUFF_CHUNK 16384       /* raw bytes per workgroup (256 threads x 4 groups of 16) */
 
 /* What the host knows about one image's entropy-coded bytes before anyone has looked at them. */
 typedef struct hj_unstuff_image {

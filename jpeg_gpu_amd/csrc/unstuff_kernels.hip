@@ -25,8 +25,9 @@
 #include <stdint.h>
 #include "unstuff_kernels.h"
 
-#define UB 256                       /* threads per workgroup; 16 raw bytes per thread */
-static_assert(UB*16 == HJ_UNSTUFF_CHUNK, "chunk size");
+#define UB 256                       /* threads per workgroup */
+#define UG 4                         /* 16-byte groups per thread: 64 consecutive raw bytes */
+static_assert(UB*16*UG == HJ_UNSTUFF_CHUNK, "chunk size");
 
 namespace {
 
@@ -53,16 +54,16 @@ __device__ __forceinline__ uint32_t zero_bytes(uint32_t x) { return ~(((x & UB_K
 // Classify the 16 bytes at p0 (a multiple of 16).  Bytes at or beyond `limit` are not valid
 // (not counted, not copied); what follows a byte is judged against `avail`, the real end of the
 // file, whatever the limit.
-__device__ __forceinline__ void classify(const uint8_t *raw, uint32_t avail, uint32_t limit, uint32_t p0,
- byte_class &c) {
+// `v` = the 16 bytes, `prev` / `next` = the bytes either side of them as they lie in the file
+// (the caller has them in registers or fetches them).
+__device__ __forceinline__ void classify(const uint4 v, uint32_t prev, uint32_t next, uint32_t avail,
+ uint32_t limit, uint32_t p0, byte_class &c) {
 #pragma unroll
   for (int k = 0; k < 4; k++) c.valid[k] = c.drop[k] = c.rst[k] = c.term[k] = c.w[k] = 0;
   c.next = 0xD9u;
   if (p0 >= limit || p0 >= avail) return;
-  const uint4 v = *reinterpret_cast<const uint4 *>(raw + p0);     // (the region is padded to 16)
   c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
-  const uint32_t prev = p0 ? raw[p0 - 1] : 0u;
-  if (p0 + 16 < avail) c.next = raw[p0 + 16];
+  if (p0 + 16 < avail) c.next = next;
   if (p0 + 16 <= limit && p0 + 16 <= avail) {
     // all sixteen bytes count: four dwords at a time
     uint32_t F[5], Z[5], R[5];
@@ -144,18 +145,47 @@ __device__ __forceinline__ void block_scan2(uint32_t a, uint32_t b, uint32_t &ea
 
 }  // namespace
 
+// A thread's 64 bytes: four groups, with the bytes either side of each.
+struct thread_bytes {
+  uint4 v[UG];
+  uint32_t prev[UG], next[UG];
+  __device__ __forceinline__ void load(const uint8_t *raw, uint32_t avail, uint32_t pt) {
+    const uint4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < UG; j++) {
+      v[j] = pt + 16u*j < avail ? *reinterpret_cast<const uint4 *>(raw + pt + 16u*j) : zero;   // (padded to 16)
+    }
+    prev[0] = pt && pt <= avail ? raw[pt - 1] : 0u;
+    next[UG - 1] = pt + 16u*UG < avail ? raw[pt + 16u*UG] : 0xD9u;
+#pragma unroll
+    for (int j = 1; j < UG; j++) {
+      prev[j] = v[j - 1].w >> 24;
+      next[j - 1] = v[j].x & 255u;
+    }
+  }
+};
+
 // 1: kept bytes and RSTn markers of every chunk; position of the first non-RST marker.
 __global__ __launch_bounds__(UB) void hj_unstuff_count(const hj_unstuff_args A) {
   __shared__ uint32_t wt[UB/64][2];
   const hj_unstuff_image u = A.uimg[blockIdx.y];
   if (blockIdx.x >= u.nchunks) return;
-  const uint32_t p0 = blockIdx.x*HJ_UNSTUFF_CHUNK + threadIdx.x*16u;
-  byte_class c;
-  classify(A.raw + u.raw_off, u.avail, u.avail, p0, c);
-  const uint32_t ft = first_of(c.term);
-  if (ft < 16u) atomicMin(&A.info[blockIdx.y].hard_end, p0 + ft);
+  const uint32_t pt = blockIdx.x*HJ_UNSTUFF_CHUNK + threadIdx.x*(16u*UG);
+  thread_bytes tb;
+  tb.load(A.raw + u.raw_off, u.avail, pt);
+  uint32_t kept = 0, nrst = 0, ft = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = 0; j < UG; j++) {
+    byte_class c;
+    classify(tb.v[j], tb.prev[j], tb.next[j], u.avail, u.avail, pt + 16u*j, c);
+    kept += c.kept();
+    nrst += c.nrst();
+    const uint32_t f = first_of(c.term);
+    if (f < 16u && ft == 0xFFFFFFFFu) ft = pt + 16u*j + f;
+  }
+  if (ft != 0xFFFFFFFFu) atomicMin(&A.info[blockIdx.y].hard_end, ft);
   uint32_t ek, er, tk, tr;
-  block_scan2(c.kept(), c.nrst(), ek, er, tk, tr, wt);
+  block_scan2(kept, nrst, ek, er, tk, tr, wt);
   if (threadIdx.x == 0) {
     A.part[2*(size_t)(u.chunk0 + blockIdx.x)] = tk;
     A.part[2*(size_t)(u.chunk0 + blockIdx.x) + 1] = tr;
@@ -187,14 +217,25 @@ __global__ __launch_bounds__(UB) void hj_unstuff_resolve(const hj_unstuff_args A
   __syncthreads();
   const uint32_t cstar = s_cstar;
   if (cstar != 0xFFFFFFFFu) {                                // look inside that chunk for RSTn number `limit`
-    byte_class c;
-    classify(A.raw + u.raw_off, u.avail, u.avail, cstar*HJ_UNSTUFF_CHUNK + threadIdx.x*16u, c);
+    const uint32_t pt = cstar*HJ_UNSTUFF_CHUNK + threadIdx.x*(16u*UG);
+    thread_bytes tb;
+    tb.load(A.raw + u.raw_off, u.avail, pt);
+    byte_class c[UG];
+    uint32_t nr = 0;
+#pragma unroll
+    for (int j = 0; j < UG; j++) {
+      classify(tb.v[j], tb.prev[j], tb.next[j], u.avail, u.avail, pt + 16u*j, c[j]);
+      nr += c[j].nrst();
+    }
     uint32_t e0, er, t0, tr;
-    block_scan2(0u, c.nrst(), e0, er, t0, tr, wt);
+    block_scan2(0u, nr, e0, er, t0, tr, wt);
     uint32_t rank = s_rbase + er;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      if (UB_BIT(c.rst, i) && rank++ == limit) s_pos = cstar*HJ_UNSTUFF_CHUNK + threadIdx.x*16u + (uint32_t)i;
+    for (int j = 0; j < UG; j++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (UB_BIT(c[j].rst, i) && rank++ == limit) s_pos = pt + 16u*j + (uint32_t)i;
+      }
     }
     __syncthreads();
   }
@@ -218,14 +259,21 @@ __global__ __launch_bounds__(UB) void hj_unstuff_scatter(const hj_unstuff_args A
   const uint32_t end = I->end;
   const uint32_t c0 = blockIdx.x*HJ_UNSTUFF_CHUNK;
   if (c0 >= end) return;
-  const uint32_t p0 = c0 + threadIdx.x*16u;
-  byte_class c;
-  classify(A.raw + u.raw_off, u.avail, end, p0, c);
-  const uint32_t keep[4] = {c.valid[0] & ~c.drop[0], c.valid[1] & ~c.drop[1], c.valid[2] & ~c.drop[2],
-                            c.valid[3] & ~c.drop[3]};
-  const uint32_t cnt = c.kept();
+  const uint32_t pt = c0 + threadIdx.x*(16u*UG);
+  thread_bytes tb;
+  tb.load(A.raw + u.raw_off, u.avail, pt);
+  byte_class c[UG];
+  uint32_t cnt = 0, nr = 0;
+#pragma unroll
+  for (int j = 0; j < UG; j++) {
+    classify(tb.v[j], tb.prev[j], tb.next[j], u.avail, end, pt + 16u*j, c[j]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[j].valid[k] &= ~c[j].drop[k];     // valid := kept
+    cnt += (uint32_t)(__popc(c[j].valid[0]) + __popc(c[j].valid[1]) + __popc(c[j].valid[2]) + __popc(c[j].valid[3]));
+    nr += c[j].nrst();
+  }
   uint32_t ek, er, tk, tr;
-  block_scan2(cnt, c.nrst(), ek, er, tk, tr, wt);
+  block_scan2(cnt, nr, ek, er, tk, tr, wt);
   const uint32_t kbase = A.part[2*(size_t)(u.chunk0 + blockIdx.x)];      // clean bytes before this chunk
   const uint32_t rbase = A.part[2*(size_t)(u.chunk0 + blockIdx.x) + 1];  // RSTn markers before it
   const hj_image *im = A.images + blockIdx.y;
@@ -235,28 +283,34 @@ __global__ __launch_bounds__(UB) void hj_unstuff_scatter(const hj_unstuff_args A
   {
     uint32_t n = s0 + ek;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      if (UB_BIT(keep, i)) stage[n++] = (uint8_t)(c.w[i >> 2] >> (8*(i & 3)));
-    }
-  }
-  if (c.rst[0] | c.rst[1] | c.rst[2] | c.rst[3]) {
-    const uint32_t limit = u.nseg - 1u;
-    uint32_t rank = rbase + er, before = 0;                  // kept bytes of this thread before byte i
+    for (int j = 0; j < UG; j++) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      if (UB_BIT(c.rst, i)) {
-        if (rank < limit) {
-          A.bnd[im->seg0 + rank] = kbase + ek + before;
-          const uint32_t code = i < 15 ? (c.w[(i + 1) >> 2] >> (8*((i + 1) & 3))) & 255u : c.next;
-          if (code != 0xD0u + (rank & 7u)) atomicOr(&A.errors[blockIdx.y], 1u);    // "invalid RST counter"
-          atomicMax(&I->found, rank + 1u);
-        }
-        rank++;
+      for (int i = 0; i < 16; i++) {
+        if (UB_BIT(c[j].valid, i)) stage[n++] = (uint8_t)(c[j].w[i >> 2] >> (8*(i & 3)));
       }
-      before += UB_BIT(keep, i);
     }
   }
-  if (threadIdx.x == 0 && tk) atomicMax(&I->scan_len, kbase + tk);   // (one atomic per chunk, not per thread)
+  if (nr) {
+    const uint32_t limit = u.nseg - 1u;
+    uint32_t rank = rbase + er, before = 0;                  // kept bytes of this thread before the byte
+#pragma unroll
+    for (int j = 0; j < UG; j++) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (UB_BIT(c[j].rst, i)) {
+          if (rank < limit) {
+            A.bnd[im->seg0 + rank] = kbase + ek + before;
+            const uint32_t code = i < 15 ? (c[j].w[(i + 1) >> 2] >> (8*((i + 1) & 3))) & 255u : c[j].next;
+            if (code != 0xD0u + (rank & 7u)) atomicOr(&A.errors[blockIdx.y], 1u);    // "invalid RST counter"
+            atomicMax(&I->found, rank + 1u);
+          }
+          rank++;
+        }
+        before += UB_BIT(c[j].valid, i);
+      }
+    }
+  }
+  if (threadIdx.x == 0 && tk) atomicMax(&I->scan_len, kbase + tk);   // (one atomic per chunk)
   __syncthreads();
   // the chunk's tk clean bytes sit at stage[s0 ..): ragged ends as bytes, the middle as dwords
   const uint32_t head = tk < ((4u - s0) & 3u) ? tk : ((4u - s0) & 3u);

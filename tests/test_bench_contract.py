@@ -96,6 +96,29 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
 
 
 @pytest.mark.gpu
+def test_two_ranks_started_by_bench_itself(gpu):
+    """`python bench.py --gpus 2` with nobody's torchrun around it: two ranks, each with its own
+    pipeline and its own share of the host cores, max-over-ranks timing, pixels of both summed.
+    (On a one-GPU box the ranks share the device — JGA_BENCH_SHARE_GPUS — and use gloo: the
+    rates mean nothing then, the code path is the N-rank one.)"""
+    os.environ["JGA_BENCH_SHARE_GPUS"] = "1"
+    try:
+        d = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--distinct", "4",
+                      "--lanes", "2", "--prewarm", "0", "--kernel-reps", "3", "--kernel-batch", "4")
+    finally:
+        del os.environ["JGA_BENCH_SHARE_GPUS"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["images_timed_per_gpu"] == 8 and d["config"]["bit_exact_vs_oracle"] is True
+    # whole-job pixels / max-over-ranks time
+    assert abs(d["value"] - 2 * 8 * 3840 * 2160 / (d["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.01 * d["value"]
+    assert "cpu_baseline" not in d                                 # N = 1 only
+    e = d["e2e"]
+    assert e["north_star_host_huffman_to_rgb_hbm"]["ok"] and e["pinned_ingest_buffers_to_rgb_hbm"]["ok"]
+    pin = d["config"]["cpu_pinning"]
+    assert pin and 1 <= pin["cpus"] <= len(os.sched_getaffinity(0))
+
+
+@pytest.mark.gpu
 def test_graft_entry_smoke_runs(gpu):
     """__graft_entry__.smoke(): one small decode on cuda:0 checked against the oracle."""
     sys.path.insert(0, ROOT)

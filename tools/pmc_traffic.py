@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=48)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc_traffic"))
     args = ap.parse_args()
+    args.out = os.path.abspath(args.out)         # (rocprofv3 runs with /tmp as its directory)
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         sys.exit("rocprofv3 not found")
