@@ -42,21 +42,37 @@
 // The Huffman tables of one image in device form: a two-level lookup that never
 // leaves LDS.  Level 1 is indexed by the next 9 bits and holds, for codes of up to 9
 // bits, a 16-bit ENTRY
-//     len << 10 | s << 6 | adv1        len  = code length (1..16)
-//                                      s    = magnitude bits that follow (symbol & 15)
-//                                      adv1 = how far the zig-zag index moves, minus one:
-//                                             0 for a DC code, the run for an AC code,
-//                                             63 for EOB (k + 64 always ends the block)
-// so that the decode loops need no per-symbol case analysis: k' = k + adv1 + 1 and the
-// block is complete iff k' >= 64.  For a longer code level 1 holds 0x8000 | n and the
-// code's bits 9..15 select an entry of level-2 block n (128 entries).  Bit patterns that
+//     tot | adv << 5 | s << 12         tot  = code length + magnitude bits: what the symbol takes (1..31)
+//                                      adv  = how far the zig-zag index moves: 1 for a DC code,
+//                                             run + 1 for an AC code, 64 for EOB (always ends the block)
+//                                      s    = magnitude bits that follow the code (symbol & 15)
+// so that the decode loops need no per-symbol case analysis: k' = k + adv and the block is
+// complete iff k' >= 64.  For a longer code level 1 holds tot = 0 and n + 1 in the adv/s bits:
+// the code's bits 9..15 select an entry of level-2 block n (128 entries).  Bit patterns that
 // are no code decode as a 17-bit EOB (AC) / zero difference (DC): they occur on
 // trajectories that started out of step (harmless) or in corrupt data, where the final
 // pass reports them (len > 16), like the host stage's "invalid code" errors.  With SIMT divergence a rarely taken slow path is taken by
 // every wave, so it has to be as cheap as the fast one.
+//
+// AC entries are 32 bits wide: the low half is the ENTRY above; the high half is a PACK — what
+// the next 9 bits hold when they hold MORE than one whole AC symbol (code + magnitude bits each;
+// at ~3.5 bits per symbol in photographic data that is the usual case):
+//     bits | adv << 4 | prefix << 11            bits   = bits all its symbols take (<= 9), 0 = no pack
+//                                               adv    = their zig-zag advance together; an EOB,
+//                                                        allowed as the LAST symbol only, counts 64
+//                                               prefix = the advance of all but the last symbol (<= 31)
+// A run may take the whole pack in one step iff k + prefix < 64, i.e. iff no symbol but the
+// last completes the block (the symbol after a completed block is a DC code from another
+// table), and iff the pack ends at or before the run's stop bit (the loops ask for nine bits
+// of room, whatever the pack takes) — then it is, bit for bit and
+// for ANY input, what the symbols decoded one by one would have been.  Synchronisation runs only want the end state and the counts, so they decode
+// two to three symbols per step; the write pass, which needs every value, uses the low half.
+// A frame may use two DC and two AC tables (luma / chroma, what every encoder emits): the
+// component -> table choice is hj_image::comp_tbl.  10 KB in all, as before the packs.
 #define HJ_L2_BLOCKS 16
 struct hj_tables {
-  uint16_t l1[6][1 << HJ_FAST_BITS];   // [2*comp] = DC, [2*comp + 1] = AC of that component
+  uint16_t dc[2][1 << HJ_FAST_BITS];
+  uint32_t ac[2][1 << HJ_FAST_BITS];
   uint16_t l2[HJ_L2_BLOCKS*128];
 };
 
@@ -75,9 +91,8 @@ struct hj_image {
   uint8_t slot_sbx[HJ_MAX_SLOTS];
   uint8_t slot_sby[HJ_MAX_SLOTS];
   uint8_t comp_hs[3], comp_vs[3], comp_xdec[3];
-  uint8_t pad_[3];
+  uint8_t comp_tbl[3];               // bit 0: which hj_tables::dc the component uses, bit 1: which ::ac
   int64_t comp_coef_off[3];          // plane base in the image's coefficient buffer (shorts)
-  // tables: [2*comp] = DC, [2*comp + 1] = AC of that component
 };
 
 struct hj_segment {                  // one restart interval (or the whole scan)
@@ -142,6 +157,7 @@ struct hj_reader {
     src = source; p = (uint32_t)pos; stop = (uint32_t)stop_bit;
   }
   HJ_HD bool before_stop() const { return p < stop; }
+  HJ_HD bool room9() const { return p + 9u <= stop; }                     // nine more bits end at or before the stop
   HJ_HD uint32_t window() const { return src.window32(p); }
   HJ_HD void skip(int n) { p += (uint32_t)n; }
   HJ_HD uint64_t tell() const { return p; }
@@ -154,16 +170,26 @@ struct hj_reader_of { typedef hj_reader<Src> type; };
 template <class Src>
 struct hj_reader_of<Src, typename Src::has_reader> { typedef typename Src::reader type; };
 
-// Look up the code at the top of window `w` in table `ti`: returns its entry.
-HJ_HD uint32_t hj_lookup(const hj_tables *T, int ti, uint32_t w) {
-  uint32_t e = T->l1[ti][w >> (32 - HJ_FAST_BITS)];
-  if (e & 0x8000u) e = T->l2[((e & 0x7fffu) << 7) | ((w >> 16) & 127u)];
+// Look up the code at the top of window `w` — in DC table tbl & 1 if `isdc`, else in AC table
+// tbl >> 1: its entry in the low half, for an AC code the pack (or 0) in the high half.
+HJ_HD uint32_t hj_lookup(const hj_tables *T, int isdc, int tbl, uint32_t w) {
+  const uint32_t idx = w >> (32 - HJ_FAST_BITS);
+  uint32_t e = isdc ? (uint32_t)T->dc[tbl & 1][idx] : T->ac[tbl >> 1][idx];
+  if ((e & 31u) == 0u) e = T->l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];   // (a long code has no pack)
   return e;
 }
-#define HJ_ENTRY(len, s, adv1) ((uint16_t)(((len) << 10) | ((s) << 6) | (adv1)))
-#define HJ_E_LEN(e) ((int)((e) >> 10))
-#define HJ_E_S(e) ((int)(((e) >> 6) & 15u))
-#define HJ_E_ADV1(e) ((int)((e) & 63u))
+#define HJ_PACK(bits, adv, prefix) ((uint32_t)((bits) | ((adv) << 4) | ((prefix) << 11)))   /* the high half */
+#define HJ_P_BITS(e32) ((int)(((e32) >> 16) & 15u))       /* 0: no pack */
+#define HJ_P_ADV(e32) ((int)(((e32) >> 20) & 127u))
+#define HJ_P_PREFIX(e32) ((int)((e32) >> 27))
+#define HJ_ENTRY(len, s, adv1) ((uint16_t)(((len) + (s)) | (((adv1) + 1) << 5) | ((s) << 12)))
+#define HJ_ESCAPE(n) ((uint16_t)(((n) + 1) << 5))         /* level-2 block n */
+#define HJ_IS_ESCAPE(e) (((e) & 31u) == 0u)
+#define HJ_ESCAPE_BLOCK(e) ((int)((e) >> 5) - 1)
+#define HJ_E_TOT(e) ((int)((e) & 31u))
+#define HJ_E_ADV(e) ((int)(((e) >> 5) & 127u))
+#define HJ_E_S(e) ((int)(((e) >> 12) & 15u))
+#define HJ_E_LEN(e) (HJ_E_TOT(e) - HJ_E_S(e))
 
 // The `s` magnitude bits that follow a `len`-bit code in window `w`, extended (T.81 F.2.2.1).
 HJ_HD int hj_value(uint32_t w, int len, int s) {
@@ -189,8 +215,11 @@ HJ_HD int hj_value(uint32_t w, int len, int s) {
 template <class Src, bool LITE = false>
 HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables *T,
  uint64_t start, uint64_t stop_bit, bool last = false) {
-  uint32_t slot_comp_bits = 0;
-  for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+  uint32_t slot_comp_bits = 0, slot_tbl_bits = 0;
+  for (int q = 0; q < im.nslots; q++) {
+    slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+    slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
+  }
   const int nslots = im.nslots;
   typename hj_reader_of<Src>::type br;
   hj_run r;
@@ -199,23 +228,30 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
   uint32_t nblocks = 0;
   br.init(src, hj_pos(start), stop_bit);
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+  int tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
   while (br.before_stop()) {
     const uint32_t w = br.window();
     const int isdc = k == 0;
-    const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
-    const int len = HJ_E_LEN(e), s = HJ_E_S(e);
-    br.skip(len + s);
+    const uint32_t e = hj_lookup(T, isdc, tbl, w);
+    // several AC symbols at once, unless one of them (other than the last) ends the block — or
+    // the run: a run ends at the FIRST symbol boundary at or past its stop bit whichever way it
+    // got there (runs that have fallen into step must hand on identical states), so a pack is
+    // only taken whole if all of it lies before the stop
+    const bool packed = HJ_P_BITS(e) != 0 && k + HJ_P_PREFIX(e) < 64 && br.room9();
+    br.skip(packed ? HJ_P_BITS(e) : HJ_E_TOT(e));
     if (!LITE && isdc) {                                   // DC difference, extended
+      const int s = HJ_E_S(e), len = HJ_E_TOT(e) - s;
       const int v = hj_value(w, len, s);
       dcall += v;
       dc1 += comp == 1 ? v : 0;
       dc2 += comp == 2 ? v : 0;
     }
-    const int kn = k + HJ_E_ADV1(e) + 1;                   // DC: 1; AC: past the run; EOB: >= 64
+    const int kn = k + (packed ? HJ_P_ADV(e) : HJ_E_ADV(e));   // DC: 1; AC: past the run(s); EOB: >= 64
     const int done = kn >= 64;
     if (!LITE) nblocks += (uint32_t)done;
     c = done ? (c + 1 == nslots ? 0 : c + 1) : c;
     comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+    tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
     k = done ? 0 : kn;
   }
   // (k == 0 with a block counted: the run's final symbol completed it)
@@ -250,8 +286,11 @@ template <class Src, class Out>
 HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T,
  const uint8_t *dezz, uint64_t start, uint64_t stop_bit, uint32_t max_blocks,
  int pred0, int pred1, int pred2, Out &out) {
-  uint32_t slot_comp_bits = 0;
-  for (int q = 0; q < im.nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+  uint32_t slot_comp_bits = 0, slot_tbl_bits = 0;
+  for (int q = 0; q < im.nslots; q++) {
+    slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+    slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
+  }
   const int nslots = im.nslots;
   typename hj_reader_of<Src>::type br;
   int k = hj_k(start), c = hj_slot(start), error = 0;
@@ -259,6 +298,7 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
   uint32_t n = 0;
   br.init(src, hj_pos(start), stop_bit);
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+  int tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
   for (;;) {
     bool running = !waiting && br.before_stop() && n < max_blocks;
     if (!out.any(running || waiting)) break;
@@ -270,8 +310,8 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
       if (!running) continue;
       const uint32_t w = br.window();
       const int isdc = k == 0;
-      const uint32_t e = hj_lookup(T, 2*comp + 1 - isdc, w);
-      const int len = HJ_E_LEN(e), s = HJ_E_S(e), adv1 = HJ_E_ADV1(e);
+      const uint32_t e = hj_lookup(T, isdc, tbl, w) & 0xffffu;       // (every value is wanted: no packs)
+      const int s = HJ_E_S(e), len = HJ_E_TOT(e) - s, adv1 = HJ_E_ADV(e) - 1;
       int v = hj_value(w, len, s);
       br.skip(len + s);
       if (isdc) {
@@ -293,6 +333,7 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
         n++;
         c = c + 1 == nslots ? 0 : c + 1;
         comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+        tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
         head = true;
         waiting = false;
       }

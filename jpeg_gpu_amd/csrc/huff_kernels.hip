@@ -57,6 +57,7 @@ struct hj_lds_src {
       stop1 = (int32_t)((uint32_t)stop_bit - bit0) - 1;
     }
     __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
+    __device__ __forceinline__ bool room9() const { return r1 + 9 <= stop1; }
     __device__ __forceinline__ uint32_t window() const {
       const uint32_t *q = base + (r1 >> 5);                  // r1 = -1: the dword before (unused bits)
       return __builtin_amdgcn_alignbit(q[0], q[1], ~(uint32_t)r1);
@@ -95,6 +96,7 @@ struct hj_gmem_src {
       w2raw = scan32[dw0 + (uint32_t)(d + 2) < last ? dw0 + (uint32_t)(d + 2) : last];
     }
     __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
+    __device__ __forceinline__ bool room9() const { return r1 + 9 <= stop1; }
     __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w0, w1, ~(uint32_t)r1); }
     __device__ __forceinline__ void skip(int n) {
       r1 += n;

@@ -43,18 +43,16 @@ static uint32_t copy_until_ff(unsigned char *dst, const unsigned char *src, uint
   return copy_until_ff_plain(dst, src, n);
 }
 
-// Build the two-level lookup of one table into T->l1[ti] (+ level-2 blocks taken
-// from *l2_used).  Returns 0, 1 = malformed DHT, 2 = out of level-2 blocks.
-static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char bits[16],
+// Build the two-level lookup of one table into l1[512] (+ level-2 blocks taken from
+// *l2_used).  Returns 0, 1 = malformed DHT, 2 = out of level-2 blocks.
+static int build_table(hj_tables *T, uint16_t *l1, bool is_dc, int *l2_used, const unsigned char bits[16],
  const unsigned char *vals) {
   unsigned code = 0;
   int k = 0;
-  const bool is_dc = (ti & 1) == 0;
   // what a bit pattern that is no code decodes as (see hj_tables)
   const uint16_t nocode = HJ_ENTRY(17, 0, is_dc ? 0 : 63);
   const int l2_first = *l2_used;
-  uint16_t *l1 = T->l1[ti];
-  memset(l1, 0, sizeof(T->l1[ti]));
+  memset(l1, 0, sizeof(uint16_t) << HJ_FAST_BITS);
   for (int len = 1; len <= 16; len++) {
     for (int i = 0; i < bits[len - 1]; i++, k++, code++) {
       if (k >= 256 || code >= (1u << len)) return 1;
@@ -66,13 +64,13 @@ static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char b
       }
       else {
         const unsigned prefix = code >> (len - HJ_FAST_BITS);
-        if (!(l1[prefix] & 0x8000u)) {
+        if (!l1[prefix] || !HJ_IS_ESCAPE(l1[prefix])) {
           if (l1[prefix]) return 1;                       // prefix of a shorter code: not prefix-free
           if (*l2_used >= HJ_L2_BLOCKS) return 2;
           memset(T->l2 + 128*(*l2_used), 0, 256);
-          l1[prefix] = (uint16_t)(0x8000u | (unsigned)(*l2_used)++);
+          l1[prefix] = HJ_ESCAPE((*l2_used)++);
         }
-        uint16_t *blk = T->l2 + 128*(l1[prefix] & 0x7fffu);
+        uint16_t *blk = T->l2 + 128*HJ_ESCAPE_BLOCK(l1[prefix]);
         const unsigned c = (code & ((1u << (len - HJ_FAST_BITS)) - 1u)) << (16 - len);
         for (unsigned j = 0; j < (1u << (16 - len)); j++) blk[c + j] = entry;
       }
@@ -82,6 +80,30 @@ static int build_table(hj_tables *T, int ti, int *l2_used, const unsigned char b
   for (int j = 0; j < (1 << HJ_FAST_BITS); j++) if (!l1[j]) l1[j] = nocode;
   for (int j = 128*l2_first; j < 128*(*l2_used); j++) if (!T->l2[j]) T->l2[j] = nocode;
   return 0;
+}
+
+// The pack of every 9-bit pattern (hj_tables): as many whole AC symbols — code and magnitude
+// bits — as the pattern holds, at most three, an EOB only as the last; none if fewer than two.
+static void build_packs(uint32_t *ac, const uint16_t *l1) {
+  static const bool off = getenv("JGA_HUFF_PACKS") && atoi(getenv("JGA_HUFF_PACKS")) == 0;   // (A/B knob)
+  for (unsigned v = 0; v < (1u << HJ_FAST_BITS); v++) {
+    int rem = HJ_FAST_BITS, n = 0, bits = 0, adv = 0, prefix = 0;
+    unsigned val = v;
+    while (n < 3 && rem > 0) {
+      const uint16_t e = l1[(val << (HJ_FAST_BITS - rem)) & ((1u << HJ_FAST_BITS) - 1u)];   // zero padded: decides
+      if (HJ_IS_ESCAPE(e)) break;                              // nothing unless the code fits the bits left
+      const int tot = HJ_E_TOT(e), a = HJ_E_ADV(e);
+      if (HJ_E_LEN(e) > 16 || tot > rem || adv > 31) break;    // (no code / too long / prefix field full)
+      prefix = adv;
+      adv += a;
+      bits += tot;
+      rem -= tot;
+      val &= (1u << rem) - 1u;
+      n++;
+      if (a == 64) break;                                      // EOB ends the block: the last symbol of a pack
+    }
+    ac[v] = (uint32_t)l1[v] | (n >= 2 && !off ? HJ_PACK(bits, adv, prefix) << 16 : 0u);
+  }
 }
 
 hj_prepared::~hj_prepared() { free(desc); }
@@ -108,6 +130,7 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
     return HJ_PREPARE_IRREGULAR;
   }
   int slot = 0, l2_used = 0;
+  int nslot[2] = {0, 0}, slot_id[2][2] = {{-1, -1}, {-1, -1}};       // [DC / AC]: DHT ids in the two table slots
   memset(&out->tabs, 0, sizeof(out->tabs));
   for (int c = 0; c < g.nplanes; c++) {
     const jpeg_component &cp = d->header.comp[c];
@@ -125,14 +148,23 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
       }
     }
     {
-      // components that select the same DHT (Cb/Cr usually do) share its level-2 blocks
+      // the device format holds two DC and two AC tables (luma / chroma): components that
+      // select the same DHT share a slot
       int rc = 0;
+      im.comp_tbl[c] = 0;
       for (int w = 0; w < 2 && !rc; w++) {
         const int id = w ? 4 + d->ta[c] : d->td[c];
-        int same = -1;
-        for (int pc = 0; pc < c; pc++) if ((w ? 4 + d->ta[pc] : d->td[pc]) == id) same = pc;
-        if (same >= 0) memcpy(out->tabs.l1[2*c + w], out->tabs.l1[2*same + w], sizeof(out->tabs.l1[0]));
-        else rc = build_table(&out->tabs, 2*c + w, &l2_used, d->dht_bits[id], d->dht_vals[id]);
+        int slot_of = -1;
+        for (int q = 0; q < nslot[w]; q++) if (slot_id[w][q] == id) slot_of = q;
+        if (slot_of < 0) {
+          if (nslot[w] >= 2) { rc = 2; break; }
+          slot_of = nslot[w]++;
+          slot_id[w][slot_of] = id;
+          uint16_t l1[1 << HJ_FAST_BITS];
+          rc = build_table(&out->tabs, w ? l1 : out->tabs.dc[slot_of], w == 0, &l2_used, d->dht_bits[id], d->dht_vals[id]);
+          if (!rc && w) build_packs(out->tabs.ac[slot_of], l1);
+        }
+        im.comp_tbl[c] |= (uint8_t)(slot_of << w);
       }
       if (rc) {
         jga_fail(rc == 2 ? "Huffman table too irregular for the GPU entropy stage"

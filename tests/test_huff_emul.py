@@ -135,3 +135,24 @@ def test_frames_beyond_32_bit_offsets_are_handed_to_the_host_stage(emul, synth):
                        ((65500, 65500), 2)):
         data[sof + 5:sof + 9] = bytes([dims[1] >> 8, dims[1] & 255, dims[0] >> 8, dims[0] & 255])
         assert emul.huff_emul_prepare_head(bytes(data), len(data)) == want, dims
+
+
+def test_ac_packs_change_nothing_on_any_bit_string(emul, synth, golden_jpegs):
+    """hj_tables' AC entries carry PACKS (several whole symbols of the next 9 bits taken in one
+    step).  A run with them must compute what the symbols one by one would — for real scans and
+    for arbitrary bytes (runs that start out of step decode garbage): end state, block count
+    and DC sums of 20 000 runs per table set, with the packs and with them stripped."""
+    emul.huff_emul_pack_mismatches.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                               C.POINTER(C.c_longlong)]
+    rng = np.random.default_rng(12)
+    files = [synth.synthetic_jpeg(64, 48, s, quality=q, seed=q) for s, q in (("420", 90), ("444", 35), ("grey", 75))]
+    files += [golden_jpegs.jpeg(n) for n in golden_jpegs.names[:4]]          # Pillow's optimised tables too
+    for f in files:
+        real = synth.synthetic_jpeg(640, 480, "420", quality=88, seed=5)
+        scan = real[real.find(b"\xff\xda") + 14:]
+        for data in (rng.integers(0, 256, 60000, dtype=np.uint8).tobytes(), bytes(scan[:60000]),
+                     bytes(60000), b"\xff" * 60000):
+            packs = C.c_longlong()
+            bad = emul.huff_emul_pack_mismatches(f, len(f), data, len(data), 5000, C.byref(packs))
+            assert bad == 0
+            assert packs.value > 200                               # a good part of the 9-bit patterns hold >= 2 symbols

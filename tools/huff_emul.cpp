@@ -77,6 +77,40 @@ int huff_emul_clean_scan(const unsigned char *jpeg, int size, unsigned char *cle
   return 0;
 }
 
+// The packs of the AC tables (hj_tables) must not change what a synchronisation run computes,
+// whatever the bits are: run hj_sync_decode over `data` (any bytes, not a scan) from `nstarts`
+// start states spread over it, once with the file's tables and once with the packs removed,
+// and count the runs that differ (end state, blocks, DC sums).  Returns that count, or -1.
+extern "C" __attribute__((visibility("default")))
+int huff_emul_pack_mismatches(const unsigned char *jpeg, int size, const unsigned char *data, int ndata,
+ int nstarts, long long *packed_steps) {
+  hj_prepared P;
+  if (hj_prepare_head(jpeg, size, &P) != EXIT_SUCCESS) return -1;
+  hj_tables plain = P.tabs;
+  long long packs = 0;
+  for (int t = 0; t < 2; t++) {
+    for (int j = 0; j < (1 << HJ_FAST_BITS); j++) { packs += (plain.ac[t][j] >> 16) != 0; plain.ac[t][j] &= 0xffffu; }
+  }
+  if (packed_steps) *packed_steps = packs;
+  std::vector<unsigned char> buf(data, data + ndata);
+  buf.resize((size_t)ndata + 16, 0xFF);
+  hj_mem_src src;
+  src.s = buf.data();
+  int bad = 0;
+  for (int i = 0; i < nstarts; i++) {
+    const uint64_t p = (uint64_t)i*(uint64_t)(ndata - 160)*8/(uint64_t)nstarts + (uint64_t)(i % 8);
+    const int c = i % P.im.nslots, k = (i*7) % 64;
+    const uint64_t stop = p + 1024;
+    const hj_run a = hj_sync_decode(src, P.im, &P.tabs, hj_pack(p, c, k), stop, (i & 1) != 0);
+    const hj_run b = hj_sync_decode(src, P.im, &plain, hj_pack(p, c, k), stop, (i & 1) != 0);
+    if (a.end_state != b.end_state || a.nblocks != b.nblocks || a.dcsum[0] != b.dcsum[0]
+     || a.dcsum[1] != b.dcsum[1] || a.dcsum[2] != b.dcsum[2]) {
+      bad++;
+    }
+  }
+  return bad;
+}
+
 static int g_assist_after = 0;
 // After this many rounds without settling, the host walk of huff_api.cpp's assist_chains()
 // (hj_walk_unsettled) is applied once per further round; 0 = never.  Returns walked
