@@ -92,3 +92,33 @@ def gpu(lib):
         pytest.fail("GPU test selected but no HIP device is visible "
                     "(the product has no CPU fallback)")
     return lib
+
+
+def three_table_variant(data):
+    """The same image with its Cr component on a THIRD pair of Huffman tables: the chroma DHTs are
+    repeated under table id 2 and the SOS points Cr there.  Decodes to the same coefficients;
+    the GPU entropy stage's table format (two DC + two AC tables per frame) cannot hold it."""
+    d = bytearray(data)
+    i, dhts, sos = 2, [], None
+    while i < len(d):
+        assert d[i] == 0xFF
+        m, n = d[i + 1], (d[i + 2] << 8) | d[i + 3]
+        if m == 0xC4:
+            dhts.append((i, n))
+        if m == 0xDA:
+            sos = i
+            break
+        i += 2 + n
+    extra = bytearray()
+    for off, n in dhts:
+        p = off + 4
+        while p < off + 2 + n:
+            cnt = sum(d[p + 1:p + 17])
+            if d[p] & 15 == 1:                          # a chroma table (id 1): repeat it as id 2
+                seg = bytearray(d[p:p + 17 + cnt])
+                seg[0] = (seg[0] & 0xF0) | 2
+                extra += b"\xff\xc4" + bytes([(len(seg) + 2) >> 8, (len(seg) + 2) & 255]) + seg
+            p += 17 + cnt
+    assert extra and d[sos + 4] == 3                    # three components in the scan
+    d[sos + 5 + 2 * 2 + 1] = 0x22                       # third component: Td = Ta = 2
+    return bytes(d[:sos]) + bytes(extra) + bytes(d[sos:])

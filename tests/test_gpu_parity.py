@@ -624,20 +624,23 @@ def test_irregular_huffman_tables_take_the_host_entropy_stage(gpu, orc, synth):
     the plugin and the transport-2 pipeline decode such a file with the host entropy stage
     (same coefficients) and the GPU kernels — results equal the oracle."""
     from jpeg_gpu_amd import abi
+    from conftest import three_table_variant
     odd = synth.synthetic_jpeg(320, 200, "420", quality=85, seed=3, flags=synth.FLAT_AC)
-    with pytest.raises(gpu.JgaError, match="too irregular"):
-        gpu.gpu_entropy_decode([odd])
-    want = orc.decode_rgb(odd)[1]
-    with gpu.Decoder(odd) as d:
-        d.read_header()
-        d.init_image()
-        d.decode(abi.JPEG_DECODE_RGB)
-        assert np.array_equal(d.pixels(), want)
+    odd3 = three_table_variant(synth.synthetic_jpeg(320, 200, "420", quality=85, seed=4))   # Cr on tables of its own
+    for f in (odd, odd3):
+        with pytest.raises(gpu.JgaError, match="too irregular"):
+            gpu.gpu_entropy_decode([f])
+        want = orc.decode_rgb(f)[1]
+        with gpu.Decoder(f) as d:
+            d.read_header()
+            d.init_image()
+            d.decode(abi.JPEG_DECODE_RGB)
+            assert np.array_equal(d.pixels(), want)
     normal = [synth.synthetic_jpeg(320, 200, "420", quality=85, seed=10 + i) for i in range(5)]
-    datas = normal[:2] + [odd] + normal[2:]
+    datas = normal[:2] + [odd] + normal[2:4] + [odd3] + normal[4:]
     outs = [np.zeros(320 * 200 * 3, np.uint8) for _ in datas]
     pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2,
-                      batch=6, depth=1)
+                      batch=7, depth=1)
     try:
         rc, jobs = pl.run(datas, host_outs=outs)
         assert rc == 0 and all(j.status == 0 for j in jobs)

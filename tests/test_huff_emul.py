@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, three_table_variant
 
 
 @pytest.fixture(scope="module")
@@ -156,3 +156,19 @@ def test_ac_packs_change_nothing_on_any_bit_string(emul, synth, golden_jpegs):
             bad = emul.huff_emul_pack_mismatches(f, len(f), data, len(data), 5000, C.byref(packs))
             assert bad == 0
             assert packs.value > 200                               # a good part of the 9-bit patterns hold >= 2 symbols
+
+
+def test_three_tables_of_a_class_go_to_the_host_stage(emul, lib, orc, synth):
+    """Two DC + two AC tables is what the device format holds (what every encoder emits: luma /
+    chroma).  A frame whose Cr has tables of its own is valid JPEG: prepare() gives it the
+    verdict "host entropy stage", and that stage (and the oracle) decode it to the same planes."""
+    import oracle
+    emul.huff_emul_prepare_head.argtypes = [C.c_char_p, C.c_int]
+    base = synth.synthetic_jpeg(97, 64, "420", quality=80, seed=4)
+    odd = three_table_variant(base)
+    assert emul.huff_emul_prepare_head(base, len(base)) == 0
+    assert emul.huff_emul_prepare_head(odd, len(odd)) == 2
+    _, g = lib.geom_of(odd)
+    want = lib.entropy_decode(base, g)
+    assert np.array_equal(lib.entropy_decode(odd, g), want)
+    assert np.array_equal(orc.decode(odd, oracle.QUANT)[1], want)
