@@ -438,7 +438,17 @@ class HuffBatch:
         n = len(jpegs)
         self._keep = [bytes(j) for j in jpegs]
         arr = (C.c_char_p * n)(*self._keep)
-        sizes = (C.c_int * n)(*[len(j) for j in self._keep])
+        return self._prepare(arr, n, stream)
+
+    def prepare_at(self, addresses, sizes, stream=None):
+        """prepare() on files given by address (e.g. PinnedBytes buffers): no copy is made here."""
+        n = len(addresses)
+        self._keep = None
+        self._addr = (C.c_void_p * n)(*[int(a) for a in addresses])
+        return self._prepare(C.cast(self._addr, C.POINTER(C.c_char_p)), n, stream, sizes)
+
+    def _prepare(self, arr, n, stream, sizes=None):
+        sizes = (C.c_int * n)(*(sizes if sizes is not None else [len(j) for j in self._keep]))
         g = abi.jga_geom()
         check(L.jga_huff_prepare(self.ptr, arr, sizes, n, C.byref(g), stream))
         self.n, self.geom = n, g

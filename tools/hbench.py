@@ -16,10 +16,19 @@ distinct = [synth.synthetic_jpeg(w, h, samp, quality=90, restart_interval=ri, se
             for i in range(min(n, 6))]
 jpegs = [distinct[i % len(distinct)] for i in range(n)]
 hb = lib.HuffBatch(n, sum(map(len, jpegs)) + 4096 * n)
+if os.environ.get("PINNED") == "1":        # files in pinned memory, scans DMA'd in place + cleaned up on the GPU
+    pins = [lib.PinnedBytes(j) for j in distinct]
+    lib.L.jga_huff_set_device_unstuff(hb.ptr, 1)
+    lib.L.jga_huff_set_inputs_pinned(hb.ptr, 1)
+if os.environ.get("THREADS"):
+    lib.L.jga_huff_set_threads(hb.ptr, int(os.environ["THREADS"]))
 preps = []
 for _ in range(4):
     t0 = time.perf_counter()
-    g = hb.prepare(jpegs)
+    if os.environ.get("PINNED") == "1":
+        g = hb.prepare_at([pins[i % len(pins)].array.ctypes.data for i in range(n)], [len(j) for j in jpegs])
+    else:
+        g = hb.prepare(jpegs)
     t1 = time.perf_counter()
     lib.check(lib.L.jga_stream_sync(None))
     preps.append((t1 - t0, time.perf_counter() - t0))
