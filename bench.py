@@ -667,7 +667,7 @@ def main():
         others["yuv_to_rgb_420"] = {"kernel": "jga_yuv_rgb_kernel", "ms": round(t, 4),
                                     "GBps": round(ab / t / 1e6, 1), "images": B}
         d_yuv.free()
-        for name, samp, n in (("rgb_444", "444", 24), ("grey", "grey", 48)):
+        for name, samp, n in (("rgb_444", "444", 24), ("rgb_422", "422", 32), ("grey", "grey", 48)):
             data = synth.synthetic_jpeg(W, H, samp, quality=90, seed=1234)
             h2, g2 = lib.geom_of(data)
             cs2 = (g2.coef_shorts * 2 + 255) // 256 * 128
