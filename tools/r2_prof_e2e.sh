@@ -1,9 +1,9 @@
 #!/bin/bash
 # kernel stats of the transport-2 pipeline for both unstuff modes
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for hu in 0 1; do
+for hu in 0; do
   OUT=gpurun_out/prof_e2e_hu$hu; rm -rf $OUT; mkdir -p $OUT
-  HOST_UNSTUFF=$hu SWEEP_CFGS="32,8,24" timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o s -f csv -- python tools/e2e_sweep2.py 1536 > $OUT/run.txt 2>&1
+  UNSTUFF=$((2-hu)) SWEEP_CFGS="32,8,24" timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o s -f csv -- python tools/e2e_sweep2.py 1536 > $OUT/run.txt 2>&1
   echo "host_unstuff=$hu"; tail -1 $OUT/run.txt
   python3 - <<PY
 import csv,glob
