@@ -259,8 +259,15 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
       const uint32_t sb = lds_stop[sub];
       hj_run r;
       if (lite) {
+        // ... and since falling into step takes tens of bytes, not 128, it need not start at the
+        // subsequence's first bit either: it starts `lite_first - 1` bytes in (never past the
+        // middle of what the subsequence holds)
+        const uint64_t stop_bit = (uint64_t)(sb & 0x7fffffffu)*8;
+        uint64_t from = hj_pos(start);
+        uint64_t skip = (uint64_t)(lite_first - 1)*8;
+        if (from + 2*skip > stop_bit) skip = from < stop_bit ? (stop_bit - from)/2 : 0;
         r = hj_sync_decode<hj_lds_src, true>(hj_source(lds_win, lds_start, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
-         start, (uint64_t)(sb & 0x7fffffffu)*8, (sb >> 31) == 0u);
+         hj_pack(from + skip, hj_slot(start), hj_k(start)), stop_bit, (sb >> 31) == 0u);
         lds_ran[sub] = 2;                                    // ran, but nothing to publish
         lds_dirty[sub] = 1;                                  // (its own flag: no other lane writes it now)
       }
@@ -717,7 +724,11 @@ extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, vo
 }
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,
  void *stream) {
-  static const int lite_first = !(getenv("JGA_HUFF_LITE") && atoi(getenv("JGA_HUFF_LITE")) == 0);   // (A/B knob)
+  // JGA_HUFF_LITE: 0 = the first run of all counts like any other; n > 0 = it is a lite run that
+  // starts n - 1 bytes into its subsequence (A/B knob)
+  // (default 49: measured 2.45 ms / 5 rounds from the first bit, 2.42-2.47 ms / 4 rounds from byte 48,
+  // a lone 1080p frame 0.77 -> 0.70 ms: profiles/r2_lite_first_run_ab.txt)
+  static const int lite_first = getenv("JGA_HUFF_LITE") ? atoi(getenv("JGA_HUFF_LITE")) : 49;
   dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
   if (sparse) {
     const dim3 sgrid((grid.x + HJ_SPARSE_GROUPS - 1)/HJ_SPARSE_GROUPS, grid.y);

@@ -38,7 +38,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 200):
     except lib.JgaError:
         stats["host_err"] += 1
     try:
-        _, c, _ = lib.gpu_entropy_decode([d])
+        _, c, _ = lib.gpu_entropy_decode([d], device_unstuff=bool(it & 1))
         if h is None: stats["gpu_ok_host_err"] += 1
         elif np.array_equal(c[0], h): stats["both_ok_equal"] += 1
         else: stats["both_ok_diff"] += 1

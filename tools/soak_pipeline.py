@@ -18,14 +18,16 @@ specs += specs[: n // 3]                       # repeats: same-geometry groups f
 datas = [synth.synthetic_jpeg(w, h, s, quality=q, restart_interval=ri, seed=sd) for (w, h, s, q, ri, sd) in specs]
 want = [orc.decode_rgb(d)[1].reshape(-1) for d in datas]
 t0 = time.time(); bad = 0
-for transport in (0, 1, 2):
+pins = [lib.PinnedBytes(d) for d in datas]
+for transport, unstuff, pinned in ((0, 0, False), (1, 0, False), (2, 1, False), (2, 2, False), (2, 0, True)):
     outs = [np.zeros(x.size, np.uint8) for x in want]
     pl = lib.Pipeline(device=0, nthreads=8, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=transport,
-                      batch=5, depth=3)
-    rc, jobs = pl.run(datas, host_outs=outs)
+                      batch=5, depth=3, unstuff=unstuff)
+    jobs = lib.Pipeline.make_jobs([p.array for p in pins] if pinned else datas, host_outs=outs, pinned=pinned)
+    rc = pl.run_jobs(jobs)
     pl.close()
     mism = sum(not np.array_equal(o, x) for o, x in zip(outs, want))
-    print("transport %d: rc %d, %d/%d images differ" % (transport, rc, mism, len(datas)))
+    print("transport %d unstuff %d pinned %d: rc %d, %d/%d images differ" % (transport, unstuff, pinned, rc, mism, len(datas)))
     bad += mism + (rc != 0)
 print("%.1f s" % (time.time() - t0))
 sys.exit(1 if bad else 0)
