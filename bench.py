@@ -10,8 +10,8 @@ GPU, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` of itse
 The metric is BASELINE.json's: Mpixel/s END-TO-END — from JPEG file bytes in host RAM to RGB8
 pixels in HBM (what a frame is in the reference: src/jpeg_gpu.c:1231-1237,
 its cpu/gpu split 1437-1458) — on 3840x2160 4:2:0 q90 baseline files.  A "step" is ONE
-batch of `--batch` (32) images per GPU through the pipelined decoder (jga_pipeline,
-transport 2): host threads parse markers and unstuff the scans into pinned memory, the
+batch of `--batch` (128) images per GPU through the pipelined decoder (jga_pipeline,
+transport 2, which works on them in groups of `--group` = 32): host threads parse markers and unstuff the scans into pinned memory, the
 compressed bytes cross PCIe, the GPU does the Huffman decode and the fused dequantise + IDCT
 + upsample + RGB kernel.  The timed region is exactly K such batches per rank, streamed
 through the rank's lanes, bracketed by barrier + device synchronise; `value` = pixels of
@@ -58,9 +58,11 @@ def log(*a):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=72)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
+    ap.add_argument("--group", type=int, default=32,
+                    help="images the pipeline hands to the GPU entropy stage at a time (one lane's batch)")
     ap.add_argument("--kernel-batch", type=int, default=48, help="images per launch in the roofline leg")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic images per rank")
     ap.add_argument("--lanes", type=int, default=8, help="batches in flight per GPU")
@@ -389,6 +391,7 @@ def main():
     jpegs = make_inputs(synth, args.distinct, rank, min(my_cpus, 64))
     hdr, g = lib.geom_of(jpegs[0])
     B, K, Wm = args.batch, args.steps, args.warmup
+    G = max(1, min(args.group, B))
     # transport 2's host threads parse + unstuff and then wait for the device: 1.5 per granted
     # CPU measured best (profiles/r2_e2e_sweep.txt); with no grant to respect, up to 96
     nthreads = args.host_threads or (min(my_cpus, max(args.lanes, budget + budget // 2)) if quota
@@ -400,9 +403,9 @@ def main():
 
     # ---- headline: JPEG bytes in host RAM -> RGB8 in HBM, K batches of B images per rank ----
     pl = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
-                      copy_back=False, transport=2, batch=B, depth=args.lanes)
+                      copy_back=False, transport=2, batch=G, depth=args.lanes)
     cyc = lambda n, o=0: [jpegs[(o + i) % len(jpegs)] for i in range(n)]
-    setup_jobs = lib.Pipeline.make_jobs(cyc(args.lanes * B))          # lanes allocate their buffers
+    setup_jobs = lib.Pipeline.make_jobs(cyc(args.lanes * G))          # lanes allocate their buffers
     warm_jobs = lib.Pipeline.make_jobs(cyc(Wm * B, 7)) if Wm > 0 else None
     timed_jobs = lib.Pipeline.make_jobs(cyc(K * B, 13))
     if pl.run_jobs(setup_jobs) != 0:
@@ -445,8 +448,8 @@ def main():
         pins = [lib.PinnedBytes(j) for j in jpegs]
         pcyc = lambda n, o=0: [pins[(o + i) % len(pins)].array for i in range(n)]
         plp = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
-                           copy_back=False, transport=2, batch=B, depth=args.lanes)
-        plp.run_jobs(lib.Pipeline.make_jobs(pcyc(args.lanes * B), pinned=True))
+                           copy_back=False, transport=2, batch=G, depth=args.lanes)
+        plp.run_jobs(lib.Pipeline.make_jobs(pcyc(args.lanes * G), pinned=True))
         if Wm > 0:
             plp.run_jobs(lib.Pipeline.make_jobs(pcyc(Wm * B, 7), pinned=True))
         pj = lib.Pipeline.make_jobs(pcyc(K * B, 13), pinned=True)
@@ -559,8 +562,8 @@ def main():
                         "(end to end); step = one batch of %d images per GPU through the pipelined "
                         "decoder: host marker parse + unstuffing into pinned memory, compressed "
                         "bytes over PCIe, GPU Huffman decode + fused dequant/IDCT/upsample/RGB "
-                        "kernel; %d steps streamed through %d lanes per GPU" % (PB, K, args.lanes),
-            "batch_per_gpu": PB, "distinct_images_per_gpu": len(jpegs),
+                        "kernel; %d steps streamed through %d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
+            "batch_per_gpu": PB, "pipeline_group": G, "distinct_images_per_gpu": len(jpegs),
             "images_timed_per_gpu": K * PB, "h2d_bytes_per_image": int(h2d_per_image),
             "parallelism": "image-sharded x%d, one process per GPU, no data-path collective" % world,
             "host_threads_per_gpu": nthreads, "cpu_pinning": pin,
@@ -615,12 +618,12 @@ def main():
                                           ("gpu_entropy_to_rgb_host", True, 2)):
             nt = nthreads if transport == 2 else nthr
             p2 = lib.Pipeline(device=gpu, nthreads=nt, out=abi.JPEG_DECODE_RGB,
-                              copy_back=copy_back, transport=transport, batch=PB, depth=args.lanes)
-            n = 24 * PB if transport == 2 else max(96, 4 * nthr)
+                              copy_back=copy_back, transport=transport, batch=G, depth=args.lanes)
+            n = 24 * G if transport == 2 else max(96, 4 * nthr)
             if copy_back:
                 n = min(n, 288)                   # 25 MB of host pixels per image
             outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None
-            nw = min(n, args.lanes * PB if transport == 2 else 2 * nthr)
+            nw = min(n, args.lanes * G if transport == 2 else 2 * nthr)
             p2.run_jobs(lib.Pipeline.make_jobs(cyc(nw), host_outs=outs[:nw] if outs else None))
             jr = lib.Pipeline.make_jobs(cyc(n, 3), host_outs=outs)
             t0 = time.perf_counter()

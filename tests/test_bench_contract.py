@@ -64,7 +64,7 @@ def test_rank_cpu_shares():
 
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
-    d = run_bench("--steps", "2", "--warmup", "1", "--batch", "4", "--distinct", "4", "--lanes", "2",
+    d = run_bench("--steps", "2", "--warmup", "1", "--batch", "4", "--group", "2", "--distinct", "4", "--lanes", "2",
                   "--prewarm", "0", "--kernel-reps", "3", "--kernel-batch", "4", "--cpu-rounds", "1", "--cpu-frames", "1",
                   "--no-e2e", "--no-pack", "--no-other", "--no-gpu-entropy")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
