@@ -248,7 +248,8 @@ JGA_EXPORT int jga_unpack_batch(const jga_geom *g, int nimages,
 JGA_EXPORT const char *jga_kernel_name(const jga_geom *g, int rgb) {
   if (!rgb) return "jga_idct_yuv_kernel";
   if (g->nplanes == 1) return "jga_idct_grey_kernel";
-  return g->plane[1].xdec == 0 && g->plane[1].ydec == 0 ? "jga_idct_rgb444_kernel" : "jga_idct_rgb_kernel";
+  // (4:4:4, 4:2:2, 4:4:0 run the row-parallel kernel, 4:2:0 and 4:1:1 the tile kernel)
+  return g->plane[1].xdec + g->plane[1].ydec <= 1 ? "jga_idct_rgb_rows_kernel" : "jga_idct_rgb_kernel";
 }
 
 JGA_EXPORT int jga_time_idct_batch(const jga_geom *g, int nimages,

@@ -652,34 +652,71 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
 }
 
 // ---------------------------------------------------------------------------
-// 4:4:4 (BASELINE config 3, "exercises the no-upsample path"): every pixel has its own Cb and
-// Cr sample, so a luma lane of the generic kernel above needs all 128 chroma floats of its MCU
-// — a 32 KB hand-off per 64 MCUs that pins the kernel at 4 workgroups (12 waves) per CU, leaves
-// no LDS for the wave-staged stores, and gives the luma wave 40 % more work than the chroma
-// waves.  This kernel keeps the block-per-lane IDCT (wave w = component w of 64 adjacent MCUs)
-// but runs the colour stage ROW-PARALLEL: in three phases the three waves publish pixel rows
-// [3p, 3p+3) of their blocks (clamped, 18 KB in all), and wave w then converts row 3p+w of all
-// 64 MCUs — one (MCU, row) unit per lane, its 1536 output bytes contiguous, so every store is
-// wave-staged.  Same arithmetic per pixel (rgb_row / chroma_row, CW = 8), 23 KB of LDS
-// (5-6 workgroups per CU), and the three waves carry equal work.
+// Row-parallel colour stage, for the samplings whose tile holds exactly as many (luma block,
+// pixel row) units per PR rows as the workgroup has lanes: 4:4:4 (BASELINE config 3,
+// "exercises the no-upsample path"; PR = 3), 4:2:2 and 4:4:0 (PR = 2).
+//
+// In the tile kernel above a luma lane converts its own block: it needs every chroma sample of
+// its MCU (4:4:4: 128 floats per lane, a 32 KB hand-off per 64 MCUs that pins the kernel at 12
+// waves per CU, leaves no LDS for the wave-staged stores, and gives the luma wave 40 % more work
+// than the chroma waves).  Here the IDCT stays block-per-lane (same waves, same lanes, same
+// loads), but the colour stage runs in phases of PR pixel rows: every lane publishes rows
+// [p*PR, p*PR+PR) of its block (clamped) and the chroma rows that go with them, then lane u
+// converts ONE (luma block u % NLB, row p*PR + u / NLB) unit — 8 pixels.  All lanes carry equal
+// work, LDS is 8-18 KB, and where a wave's 64 units are 64 adjacent blocks of one row (4:4:4,
+// 4:2:2) their 1536 output bytes leave through the wave-staged stores.  Same arithmetic per
+// pixel as everywhere (rgb_row / chroma_row).
 // ---------------------------------------------------------------------------
-template <bool DEQUANT>
-__global__ __launch_bounds__(192) void jga_idct_rgb444_kernel(const jga_kparams P) {
-  constexpr int TILE = 64, PR = 3;                   // MCUs per tile, pixel rows per phase
-  __shared__ __attribute__((aligned(16))) float pub[3*PR*TILE*8];   // [comp][row in phase][MCU][8]
+template <int XDEC, int YDEC>
+struct rows_cfg {
+  typedef rgb_cfg<XDEC, YDEC> tile;
+  static constexpr int PR = tile::THREADS/tile::NLB;         // luma pixel rows per phase
+  static constexpr int NPH = (8 + PR - 1)/PR;                // phases
+  static constexpr int CSLOTS = YDEC ? tile::LH : PR;        // chroma rows published per phase and component
+  static constexpr bool STAGED = tile::ROWLEN % 64 == 0;
+  static_assert(PR*tile::NLB == tile::THREADS, "one unit per lane and phase");
+  static_assert(tile::NLB % 64 == 0, "a wave converts one row index");
+};
+
+template <int XDEC, int YDEC, bool DEQUANT>
+__global__ __launch_bounds__((rgb_cfg<XDEC, YDEC>::THREADS))
+void jga_idct_rgb_rows_kernel(const jga_kparams P) {
+  typedef rgb_cfg<XDEC, YDEC> cfg;
+  typedef rows_cfg<XDEC, YDEC> rc;
+  __shared__ __attribute__((aligned(16))) float ypub[rc::PR*cfg::NLB*8];              // [row in phase][luma block][8]
+  __shared__ __attribute__((aligned(16))) float cpub[2*rc::CSLOTS*cfg::TILE*8];       // [comp][slot][chroma block][8]
   __shared__ uint4 qlds[24];
-  __shared__ __attribute__((aligned(16))) uint32_t stage_mem[3][384];
+  __shared__ __attribute__((aligned(16))) uint32_t stage_mem[rc::STAGED ? cfg::NLW + cfg::NCW : 1][384];
   const int lane = threadIdx.x & 63;
-  const int comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t *wstage = stage_mem[comp];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t *wstage = stage_mem[rc::STAGED ? wave : 0];
   const int tx = blockIdx.x, mrow = blockIdx.y, img = blockIdx.z;
-  const int bx = tx*TILE + lane;
-  const int hblocks = P.plane_hblocks[0];
-  const bool valid = bx < hblocks;
-  const int bxl = valid ? bx : hblocks - 1;          // tail lanes reload a real block
+  const int cbx0 = tx*cfg::TILE;
   const long long rs = (long long)P.w0_blocks*64;
-  const int16_t *src = P.coef + (long long)img*P.coef_stride + P.plane_coef_off[comp]
-   + rs*mrow + (long long)bxl*64;
+
+  // the block this lane transforms: as in the tile kernel
+  const bool is_luma = wave < cfg::NLW;
+  int pl, bx, by, cb = 0, comp = 0, myidx = 0, mysuby = 0;
+  if (is_luma) {
+    myidx = wave*64 + lane;
+    mysuby = myidx/cfg::ROWLEN;
+    pl = 0;
+    bx = cbx0*cfg::LW + (myidx - mysuby*cfg::ROWLEN);
+    by = mrow*cfg::LH + mysuby;
+  }
+  else {
+    const int cidx = (wave - cfg::NLW)*64 + lane;
+    comp = cidx/cfg::TILE;
+    cb = cidx - comp*cfg::TILE;
+    pl = 1 + comp;
+    bx = cbx0 + cb;
+    by = mrow;
+  }
+  const int hblocks = P.plane_hblocks[pl];
+  const int bxl = bx < hblocks ? bx : hblocks - 1;     // tail lanes reload a real block
+  const int xdec = is_luma ? 0 : XDEC;
+  const int16_t *src = P.coef + (long long)img*P.coef_stride + P.plane_coef_off[pl]
+   + rs*(by >> xdec) + (rs >> xdec)*(by & ((1 << xdec) - 1)) + (long long)bxl*64;
   uint4 rows[8];
   load_block_direct(src, rows);                      // in flight across the barrier below
   if (DEQUANT) {
@@ -689,66 +726,103 @@ __global__ __launch_bounds__(192) void jga_idct_rgb444_kernel(const jga_kparams 
     __syncthreads();
   }
   float z[64], t[64];
-  row_pass_ldsq<DEQUANT>(rows, qlds + comp*8, z);
+  row_pass_ldsq<DEQUANT>(rows, qlds + pl*8, z);
   const float tmax = col_pass(z, t);
   const bool clip = __builtin_amdgcn_ballot_w64(tmax > 127.0f) != 0ull;
 
+  // the unit this lane converts in every phase: luma block uidx, row urr of the phase
+  const int u = threadIdx.x;
+  const int urr = __builtin_amdgcn_readfirstlane(u/cfg::NLB);
+  const int uidx = u - urr*cfg::NLB;
+  const int usuby = uidx/cfg::ROWLEN, ulx = uidx - usuby*cfg::ROWLEN;
+  const int ubx = cbx0*cfg::LW + ulx, uby = mrow*cfg::LH + usuby;
+  const bool uvalid = ubx < P.plane_hblocks[0];
+  const int ucb = ulx >> XDEC, usubx = ulx & (cfg::LW - 1);
+  const int uslot = YDEC ? usuby : urr;
   const long long pitch = (long long)P.width*3;
   uint8_t *img_out = P.out + (long long)img*P.out_stride;
-  const int x0 = bx*8;
-  const unsigned long long inside = __builtin_amdgcn_ballot_w64(valid && x0 + 8 <= P.width);
+  const int x0 = ubx*8;
+  const unsigned long long inside = __builtin_amdgcn_ballot_w64(uvalid && x0 + 8 <= P.width);
   const int nin = (int)__builtin_popcountll(inside);
-  const bool wfast = P.out_aligned && (pitch & 15) == 0 && nin >= 2 && (nin & 1) == 0
+  const bool wfast = rc::STAGED && P.out_aligned && (pitch & 15) == 0 && nin >= 2 && (nin & 1) == 0
    && inside == (nin == 64 ? ~0ull : (1ull << nin) - 1ull)
    && (((uintptr_t)img_out + (unsigned long long)__builtin_amdgcn_readfirstlane(x0)*3u) & 15u) == 0;
   const bool fast = P.out_aligned && x0 + 8 <= P.width;
 
 #pragma unroll
-  for (int p0 = 0; p0 < 8; p0 += PR) {
-    // publish rows [p0, p0+PR) of this lane's block, clamped like clamp255(s+128)-128
+  for (int p = 0; p < rc::NPH; p++) {
+    // publish (clamped like clamp255(s+128)-128)
+    if (is_luma) {
 #pragma unroll
-    for (int rr = 0; rr < PR; rr++) {
-      if (p0 + rr < 8) {
-        float *dst = pub + ((comp*PR + rr)*TILE + lane)*8;
+      for (int rr = 0; rr < rc::PR; rr++) {
+        const int r = p*rc::PR + rr;
+        if (r < 8) {
+          float *dst = ypub + (rr*cfg::NLB + myidx)*8;
 #pragma unroll
-        for (int h = 0; h < 8; h += 4) {
-          v4f v;
-          v.x = t[(p0 + rr)*8 + h]; v.y = t[(p0 + rr)*8 + h + 1];
-          v.z = t[(p0 + rr)*8 + h + 2]; v.w = t[(p0 + rr)*8 + h + 3];
-          if (clip) {
-            v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
-            v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
-            v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
-            v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
+          for (int h = 0; h < 8; h += 4) {
+            v4f v;
+            v.x = t[r*8 + h]; v.y = t[r*8 + h + 1]; v.z = t[r*8 + h + 2]; v.w = t[r*8 + h + 3];
+            if (clip) {
+              v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
+              v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
+              v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
+              v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
+            }
+            *reinterpret_cast<v4f *>(dst + h) = v;
           }
-          *reinterpret_cast<v4f *>(dst + h) = v;
+        }
+      }
+    }
+    else {
+#pragma unroll
+      for (int sl = 0; sl < rc::CSLOTS; sl++) {
+        // chroma row that goes with luma row p*PR + rr of block row suby: (suby*8 + p*PR + rr) >> YDEC
+        const int crow = YDEC ? sl*4 + p : p*rc::PR + sl;
+        if (crow < 8) {
+          float *dst = cpub + ((comp*rc::CSLOTS + sl)*cfg::TILE + cb)*8;
+#pragma unroll
+          for (int h = 0; h < 8; h += 4) {
+            v4f v;
+            v.x = t[crow*8 + h]; v.y = t[crow*8 + h + 1]; v.z = t[crow*8 + h + 2]; v.w = t[crow*8 + h + 3];
+            if (clip) {
+              v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
+              v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
+              v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
+              v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
+            }
+            *reinterpret_cast<v4f *>(dst + h) = v;
+          }
         }
       }
     }
     __syncthreads();
-    // wave `comp` converts pixel row p0 + comp of the tile's 64 MCUs
-    const int k = p0 + comp;
-    if (k < 8) {                                     // (wave-uniform)
-      const v4f *ys = reinterpret_cast<const v4f *>(pub + ((0*PR + comp)*TILE + lane)*8);
-      const v4f *us = reinterpret_cast<const v4f *>(pub + ((1*PR + comp)*TILE + lane)*8);
-      const v4f *vs = reinterpret_cast<const v4f *>(pub + ((2*PR + comp)*TILE + lane)*8);
-      const v4f y0 = ys[0], y1 = ys[1], u0 = us[0], u1 = us[1], v0 = vs[0], v1 = vs[1];
+    const int k = p*rc::PR + urr;                    // pixel row inside the luma block (wave-uniform)
+    if (k < 8) {
+      const v4f *ys = reinterpret_cast<const v4f *>(ypub + (urr*cfg::NLB + uidx)*8);
+      const v4f y0 = ys[0], y1 = ys[1];
       const float y8[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-      const float u8[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-      const float v8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      chroma_row<8> cr;
+      const float *ub = cpub + ((0*rc::CSLOTS + uslot)*cfg::TILE + ucb)*8 + usubx*cfg::CW;
+      const float *vb = cpub + ((1*rc::CSLOTS + uslot)*cfg::TILE + ucb)*8 + usubx*cfg::CW;
+      float u8[cfg::CW], v8[cfg::CW];
+#pragma unroll
+      for (int c = 0; c < cfg::CW; c += 4) {
+        const v4f a = *reinterpret_cast<const v4f *>(ub + c), b = *reinterpret_cast<const v4f *>(vb + c);
+        u8[c] = a.x; u8[c + 1] = a.y; u8[c + 2] = a.z; u8[c + 3] = a.w;
+        v8[c] = b.x; v8[c + 1] = b.y; v8[c + 2] = b.z; v8[c + 3] = b.w;
+      }
+      chroma_row<cfg::CW> cr;
       cr.set(u8, v8);
       uint4 a;
       uint2 b;
-      rgb_row<0, 8, false>(y8, cr, a, b);            // published values are clamped already
-      const int yy = mrow*8 + k;
+      rgb_row<XDEC, cfg::CW, false>(y8, cr, a, b);   // published values are clamped already
+      const int yy = uby*8 + k;
       uint8_t *o = img_out + (long long)yy*pitch + (long long)x0*3;
       if (yy < P.height) {
         if (wfast) store_rgb_row_wave(wstage, lane, o - lane*24, a, b, nin*3/2);
-        else if (valid) store_rgb_row(o, a, b, fast, x0, P.width);
+        else if (uvalid) store_rgb_row(o, a, b, fast, x0, P.width);
       }
     }
-    if (p0 + PR < 8) __syncthreads();                // the next phase overwrites `pub`
+    if (p + 1 < rc::NPH) __syncthreads();            // the next phase overwrites the published rows
   }
 }
 
@@ -900,6 +974,15 @@ static hipError_t launch_rgb_t(const jga_kparams &P, hipStream_t st) {
   return hipGetLastError();
 }
 
+template <int XDEC, int YDEC>
+static hipError_t launch_rows_t(const jga_kparams &P, hipStream_t st) {
+  typedef rgb_cfg<XDEC, YDEC> cfg;
+  dim3 grid((P.nhmb + cfg::TILE - 1)/cfg::TILE, P.nvmb, P.nimages), block(cfg::THREADS);
+  if (P.dequant) hipLaunchKernelGGL((jga_idct_rgb_rows_kernel<XDEC, YDEC, true>), grid, block, 0, st, P);
+  else hipLaunchKernelGGL((jga_idct_rgb_rows_kernel<XDEC, YDEC, false>), grid, block, 0, st, P);
+  return hipGetLastError();
+}
+
 extern "C" int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec,
  int staged, void *stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -913,14 +996,11 @@ extern "C" int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec,
     e = hipGetLastError();
   }
   else {
-    // 4:4:4: the row-parallel kernel (JGA_RGB444=tile selects the generic tile kernel, for A/B)
-    static const bool generic444 = getenv("JGA_RGB444") && !strcmp(getenv("JGA_RGB444"), "tile");
-    if (xdec == 0 && ydec == 0 && !generic444) {
-      dim3 grid((P->nhmb + 63)/64, P->nvmb, P->nimages), block(192);
-      if (P->dequant) hipLaunchKernelGGL(jga_idct_rgb444_kernel<true>, grid, block, 0, st, *P);
-      else hipLaunchKernelGGL(jga_idct_rgb444_kernel<false>, grid, block, 0, st, *P);
-      e = hipGetLastError();
-    }
+    // 4:4:4, 4:2:2, 4:4:0: the row-parallel kernel (JGA_RGB_ROWS=0 selects the tile kernel, for A/B)
+    static const bool tile_only = getenv("JGA_RGB_ROWS") && atoi(getenv("JGA_RGB_ROWS")) == 0;
+    if (!tile_only && xdec == 0 && ydec == 0) e = launch_rows_t<0, 0>(*P, st);
+    else if (!tile_only && xdec == 1 && ydec == 0) e = launch_rows_t<1, 0>(*P, st);
+    else if (!tile_only && xdec == 0 && ydec == 1) e = launch_rows_t<0, 1>(*P, st);
     else if (xdec == 0 && ydec == 0) e = launch_rgb_t<0, 0>(*P, st);
     else if (xdec == 1 && ydec == 0) e = launch_rgb_t<1, 0>(*P, st);
     else if (xdec == 1 && ydec == 1) e = launch_rgb_t<1, 1>(*P, st);
