@@ -98,7 +98,7 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   b->sub_cap = (size_t)(max_scan_bytes >> hj_choose_sub_log2((uint64_t)max_scan_bytes)) + (size_t)max_images*4096 + 1024;
   if (const char *e = getenv("JGA_HUFF_SUB")) {               // tuning knob / tests: 32, 64 or 128
     const int v = atoi(e);
-    b->force_sub_log2 = v == 32 ? 5 : v == 64 ? 6 : v == 128 ? 7 : 0;
+    b->force_sub_log2 = v == 32 ? 5 : v == 64 ? 6 : v == 128 ? 7 : v == 256 ? 8 : v == 512 ? 9 : 0;
   }
   if (const char *e = getenv("JGA_HUFF_DEVICE_UNSTUFF")) b->device_unstuff = atoi(e) != 0;
   const size_t seg_cap = b->sub_cap;   // worst case one segment per subsequence
@@ -669,8 +669,10 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
     }
   };
   static const knobs K;
+  const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;     // no LDS rows that long: global-memory readers only
   const int it0 = K.it0, it1 = K.it1, group = K.group, flush_lanes = K.flush_lanes,
-            sparse_from = K.sparse_from, write_gmem = K.write_gmem, assist_after = K.assist_after;
+            sparse_from = long_subs ? 0 : K.sparse_from, write_gmem = long_subs ? 1 : K.write_gmem,
+            assist_after = K.assist_after;
   A.flush_lanes = flush_lanes;
   A.sub_log2 = b->sub_log2;
   const int GROUP = group;
