@@ -5,7 +5,8 @@
 // and the RSTn markers, which also cut the scan into restart intervals (T.81 B.1.1.5, F.1.2.3;
 // the reference handles them symbol by symbol inside its bit reader, src/xjpeg.c:113-127, and
 // per interval at 593-629).  huff_prepare.cpp's hj_prepare_scan does this on the host — one
-// core unstuffs ~3 GB/s, and a GPU that decodes 14 000 4K frames a second wants 44 GB/s of it.
+// core unstuffs ~12 GB/s (as fast as it could memcpy), and a GPU that decodes 16 000 4K frames a
+// second wants 44 GB/s of it: fine for one GPU and 16 cores, not for eight GPUs sharing them.
 // Here the raw bytes go up as they are and the device produces exactly what hj_prepare_scan
 // would have: the clean stream, the segment table, the image's clean length and subsequence
 // count.  The host's share of a frame shrinks to the marker parse and one memcpy.
@@ -20,7 +21,7 @@
 // frame has (the host loop's `mcu0 < total_mcus` test); RSTn number k must carry counter k & 7.
 // Four launches: per-chunk counts -> per-image prefix over the chunks + the end -> scatter
 // (bytes through an LDS line, so that global writes are whole dwords) -> segment table.
-// Integer/byte work, HBM-bound: reads the raw bytes three times, writes them once.
+// Integer/byte work, HBM-bound: reads the raw bytes twice (count, scatter), writes them once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "unstuff_kernels.h"
