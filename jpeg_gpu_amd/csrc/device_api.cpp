@@ -227,8 +227,8 @@ JGA_EXPORT int jga_unpack_batch(const jga_geom *g, int nimages,
       P.plane_vs[p] = vs;
       for (int sy = 0; sy < vs; sy++) {
         for (int sx = 0; sx < hs; sx++) {
-          if (slot >= 10 || sx > 3 || sy > 3) return jga_fail("Unsupported sampling (MCU too large)");
-          P.slot_desc |= (unsigned long long)(p | (sx << 2) | (sy << 4)) << (6*slot);
+          if (slot >= 20 || sx > 3 || sy > 3) return jga_fail("Unsupported sampling (MCU too large)");
+          P.slot_desc[slot/10] |= (unsigned long long)(p | (sx << 2) | (sy << 4)) << (6*(slot % 10));
           slot++;
         }
       }

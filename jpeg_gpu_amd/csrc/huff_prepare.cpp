@@ -140,7 +140,12 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
     im.comp_coef_off[c] = g.plane[c].coef_off;
     for (int sy = 0; sy < cp.vsamp; sy++) {
       for (int sx = 0; sx < cp.hsamp; sx++) {
-        if (slot >= HJ_MAX_SLOTS) return jga_fail("Unsupported sampling (MCU too large)");
+        if (slot >= HJ_MAX_SLOTS) {
+          // more blocks per MCU than T.81 B.2.3 allows (ten); the reference decodes such files
+          // all the same (4x4 luma: src/xjpeg.c:384-391), so does the host entropy stage
+          jga_fail("MCU of more than %d blocks: not for the GPU entropy stage", HJ_MAX_SLOTS);
+          return HJ_PREPARE_IRREGULAR;
+        }
         im.slot_comp[slot] = (uint8_t)c;
         im.slot_sbx[slot] = (uint8_t)sx;
         im.slot_sby[slot] = (uint8_t)sy;

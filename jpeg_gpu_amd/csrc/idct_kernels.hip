@@ -1006,6 +1006,12 @@ extern "C" int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec,
     else if (xdec == 1 && ydec == 1) e = launch_rgb_t<1, 1>(*P, st);
     else if (xdec == 0 && ydec == 1) e = launch_rgb_t<0, 1>(*P, st);
     else if (xdec == 2 && ydec == 0) e = launch_rgb_t<2, 0>(*P, st);
+    // the reference takes any sampling factors in {1, 2, 4} (src/xjpeg.c:384-391; pass 3 is generic
+    // in xdec / ydec, res/unyuv.fs.glsl:30-31): the rarer ones run the same tile kernel
+    else if (xdec == 2 && ydec == 1) e = launch_rgb_t<2, 1>(*P, st);
+    else if (xdec == 1 && ydec == 2) e = launch_rgb_t<1, 2>(*P, st);
+    else if (xdec == 0 && ydec == 2) e = launch_rgb_t<0, 2>(*P, st);
+    else if (xdec == 2 && ydec == 2) e = launch_rgb_t<2, 2>(*P, st);
   }
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -102,9 +102,9 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
       const uint32_t slot = b - mcu*nslots;
       const uint32_t mby = (uint32_t)(((uint64_t)mcu*P.div_nhmb.mul) >> P.div_nhmb.shift);
       const uint32_t mbx = mcu - mby*nhmb;
-      // slot -> plane / position inside the MCU: 6 bits per slot of one 64-bit word, and
+      // slot -> plane / position inside the MCU: 6 bits per slot, ten slots per 64-bit word, and
       // three-way selects instead of indexed kernel arguments (those would be memory loads)
-      const uint32_t sd = (uint32_t)(P.slot_desc >> (6u*slot)) & 63u;
+      const uint32_t sd = (uint32_t)(slot < 10u ? P.slot_desc[0] >> (6u*slot) : P.slot_desc[1] >> (6u*(slot - 10u))) & 63u;
       const uint32_t pl = sd & 3u, sbx = (sd >> 2) & 3u, sby = sd >> 4;
 #define PK_SEL(a) (pl == 0u ? (a)[0] : pl == 1u ? (a)[1] : (a)[2])
       const uint32_t bx = mbx*(uint32_t)PK_SEL(P.plane_hs) + sbx;

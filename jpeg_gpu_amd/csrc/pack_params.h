@@ -23,7 +23,8 @@ typedef struct jga_pack_params {
   int nhmb, nvmb;             /* MCUs per row / rows */
   int nslots;                 /* blocks per MCU */
   struct { uint32_t mul, shift; } div_nslots, div_nhmb;   /* n/d == (n*mul) >> shift, n < 2^31 */
-  unsigned long long slot_desc; /* 6 bits per slot: plane | sbx << 2 | sby << 4 (<= 10 slots) */
+  unsigned long long slot_desc[2]; /* 6 bits per slot: plane | sbx << 2 | sby << 4; ten slots per word
+                                 * (18 = luma 4x4 + 2 is the most the reference's factors give) */
   int plane_hs[3], plane_vs[3];
 } jga_pack_params;
 

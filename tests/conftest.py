@@ -58,9 +58,13 @@ def golden_blocks():
 
 
 class GoldenJpegs:
-    def __init__(self):
-        self.z = np.load(os.path.join(GOLDEN, "jpegs.npz"))
-        self.names = sorted(k[:-4] for k in self.z.files if k.endswith(".jpg"))
+    """Files + the compiled reference's outputs for them (tests/golden/make_golden.py)."""
+    def __init__(self, files=("jpegs.npz", "jpegs_rare.npz")):
+        self.z = {}
+        for f in files:
+            with np.load(os.path.join(GOLDEN, f)) as z:
+                self.z.update({k: z[k] for k in z.files})
+        self.names = sorted(k[:-4] for k in self.z if k.endswith(".jpg"))
 
     def jpeg(self, name):
         return self.z[name + ".jpg"].tobytes()
@@ -78,6 +82,12 @@ class GoldenJpegs:
 @pytest.fixture(scope="session")
 def golden_jpegs():
     return GoldenJpegs()
+
+
+@pytest.fixture(scope="session")
+def golden_mcu18():
+    """Luma 4x4 (18 blocks per MCU): beyond T.81 B.2.3 and libjpeg, decoded by the reference."""
+    return GoldenJpegs(("jpegs_mcu18.npz",))
 
 
 @pytest.fixture(scope="session")

@@ -2,7 +2,8 @@
 
 Run in the build container (needs /root/reference, via oracle/_ref, and Pillow):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py          # the three files below
+    python tests/golden/make_golden.py rare     # jpegs_rare.npz + jpegs_mcu18.npz only
 
 Writes (all small, committed):
   idct_blocks.npz   4096 input blocks + the reference glj_real_idct8x8 output
@@ -12,6 +13,11 @@ Writes (all small, committed):
                     QUANT planes, DCT planes, Y/Cb/Cr planes, PACK words + index
   layout.json       image_init results for the BASELINE.json geometries
                     
+  jpegs_rare.npz    (rare) the sampling factors the reference accepts beyond the usual six
+                    (src/xjpeg.c:384-391: any of 1, 2, 4): luma 4x2, 2x4, 1x4 — same arrays
+                    as jpegs.npz, loaded together with it by tests/conftest.py
+  jpegs_mcu18.npz   (rare) luma 4x4: 18 blocks per MCU, more than T.81 B.2.3 allows and
+                    libjpeg takes, but the reference decodes it
 The files are DATA (inputs and expected outputs); no reference source is stored.
 """
 import io
@@ -39,6 +45,44 @@ def lcg_blocks(n, lo, hi, seed):
         v = (x & 0x7FFFFFFE) / float(0x7FFFFFFF)
         out[i] = int(v * span) + lo
     return out.reshape(n, 64).astype(np.int16)
+
+
+def reference_outputs(R, files):
+    store = {}
+    for name, data in files.items():
+        info, quant = R.decode(data, oracle.QUANT)
+        _, dct = R.decode(data, oracle.DCT)
+        _, planes = R.decode(data, oracle.YUV)
+        _, (pack, index) = R.decode(data, oracle.PACK)
+        store[name + ".jpg"] = np.frombuffer(data, np.uint8)
+        store[name + ".quant"] = quant
+        store[name + ".dct"] = dct
+        store[name + ".pack"] = pack
+        store[name + ".index"] = index
+        for i, p in enumerate(planes):
+            store[name + ".plane%d" % i] = p
+        store[name + ".info"] = np.frombuffer(json.dumps(info.as_dict()).encode(), np.uint8)
+    return store
+
+
+def rare():
+    R = oracle.Reference()
+    files = {
+        "synth_4x2_72x40_q85": synth.synthetic_jpeg(72, 40, (4, 2), quality=85, seed=21),
+        "synth_4x2_dri2_35x33": synth.synthetic_jpeg(35, 33, (4, 2), quality=70, restart_interval=2, seed=22),
+        "synth_2x4_40x72_q85": synth.synthetic_jpeg(40, 72, (2, 4), quality=85, seed=23),
+        "synth_2x4_dri_row_50x70": synth.synthetic_jpeg(50, 70, (2, 4), quality=60, restart_interval=-1, seed=24),
+        "synth_1x4_24x64_q90": synth.synthetic_jpeg(24, 64, (1, 4), quality=90, seed=25),
+        "synth_1x4_dqt16_17x37": synth.synthetic_jpeg(17, 37, (1, 4), quality=50, seed=26, flags=synth.DQT16),
+    }
+    np.savez_compressed(os.path.join(HERE, "jpegs_rare.npz"), **reference_outputs(R, files))
+    files = {
+        "synth_4x4_64x64_q85": synth.synthetic_jpeg(64, 64, (4, 4), quality=85, seed=27),
+        "synth_4x4_dri3_75x45": synth.synthetic_jpeg(75, 45, (4, 4), quality=75, restart_interval=3, seed=28),
+    }
+    np.savez_compressed(os.path.join(HERE, "jpegs_mcu18.npz"), **reference_outputs(R, files))
+    for f in ("jpegs_rare.npz", "jpegs_mcu18.npz"):
+        print("%8d %s" % (os.path.getsize(os.path.join(HERE, f)), f))
 
 
 def main():
@@ -88,20 +132,7 @@ def main():
         "synth_440_24x48": synth.synthetic_jpeg(24, 48, "440", seed=11),
         "synth_grey_33x17": synth.synthetic_jpeg(33, 17, "grey", seed=12),
     }
-    store = {}
-    for name, data in files.items():
-        info, quant = R.decode(data, oracle.QUANT)
-        _, dct = R.decode(data, oracle.DCT)
-        _, planes = R.decode(data, oracle.YUV)
-        _, (pack, index) = R.decode(data, oracle.PACK)
-        store[name + ".jpg"] = np.frombuffer(data, np.uint8)
-        store[name + ".quant"] = quant
-        store[name + ".dct"] = dct
-        store[name + ".pack"] = pack
-        store[name + ".index"] = index
-        for i, p in enumerate(planes):
-            store[name + ".plane%d" % i] = p
-        store[name + ".info"] = np.frombuffer(json.dumps(info.as_dict()).encode(), np.uint8)
+    store = reference_outputs(R, files)
     np.savez_compressed(os.path.join(HERE, "jpegs.npz"), **store)
     # ---- layout --------------------------------------------------------------
     geoms = {
@@ -124,4 +155,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    rare() if sys.argv[1:] == ["rare"] else main()
