@@ -253,7 +253,13 @@ int jga_entropy_decode_pack(const unsigned char *buf, int size,
  *     d_rgb  : image i at d_rgb + i*rgb_stride, row pitch width*nplanes.
  *     d_yuv  : image i at d_yuv + i*yuv_stride, planes concatenated at
  *              g->plane[p].data_off, each padded, ystride = plane width.
- *     stream : hipStream_t (NULL = default stream).  Asynchronous. -------- */
+ *     stream : hipStream_t (NULL = default stream).  Asynchronous.
+ *
+ *     Sampling: any factors of 1, 2, 4 with luma the finest plane (the reference's pass 3
+ *     reads Y undecimated, res/unyuv.fs.glsl:23-28; src/xjpeg.c:384-391).  Cb and Cr
+ *     decimated alike — every usual file — run one fused kernel; Cb and Cr decimated
+ *     DIFFERENTLY (res/unyuv.fs.glsl:6-9 allows it) make jga_idct_rgb_batch run the YUV
+ *     stage and pass 3 through a scratch buffer and return with the pixels complete. ---- */
 int jga_device_count(void);
 int jga_idct_rgb_batch(const jga_geom *g, int nimages,
  const short *d_coef, long long coef_stride, const unsigned short *d_qtab,

@@ -40,9 +40,11 @@ static int fill_params(jga_kparams *P, const jga_geom *g, int nimages,
     return jga_fail("Unsupported number of components %i", g->nplanes);
   }
   if (dequant && !d_qtab) return jga_fail("Missing quantisation tables");
+  // (luma must be the finest plane: the reference's pass 3 reads it undecimated,
+  // res/unyuv.fs.glsl:23-28; the fused RGB kernels also want Cb and Cr decimated alike —
+  // jga_idct_rgb_batch takes the files where they are not through the YUV stage)
   if (g->nplanes == 3 && (g->plane[0].xdec || g->plane[0].ydec
-   || g->plane[1].xdec != g->plane[2].xdec
-   || g->plane[1].ydec != g->plane[2].ydec)) {
+   || (rgb && (g->plane[1].xdec != g->plane[2].xdec || g->plane[1].ydec != g->plane[2].ydec)))) {
     return jga_fail("Unsupported sampling for the device stage");
   }
   if (coef_stride < g->coef_shorts) return jga_fail("coef_stride too small");
@@ -103,6 +105,26 @@ JGA_EXPORT int jga_idct_rgb_batch(const jga_geom *g, int nimages,
  void *stream) {
   jga_kparams P;
   int rc;
+  if (g->nplanes == 3 && !g->plane[0].xdec && !g->plane[0].ydec
+   && (g->plane[1].xdec != g->plane[2].xdec || g->plane[1].ydec != g->plane[2].ydec)) {
+    // Cb and Cr decimated differently (res/unyuv.fs.glsl takes u_xdec/u_ydec and v_xdec/v_ydec
+    // separately, src/jpeg_gpu.c:868-877): rare enough to go the reference's own way, planes
+    // first and pass 3 behind them, through a scratch buffer that lives for the call (so this
+    // variant returns with the pixels complete, not merely queued)
+    const long long ystride = (g->yuv_bytes + 255)/256*256;
+    unsigned char *tmp = NULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (rgb_stride < g->rgb_bytes) return jga_fail("rgb_stride too small");
+    HIP_TRY(hipMalloc((void **)&tmp, (size_t)ystride*(size_t)nimages));
+    rc = jga_idct_yuv_batch(g, nimages, d_coef, coef_stride, d_qtab, dequant_on_device, tmp, ystride, stream);
+    if (rc == EXIT_SUCCESS) rc = jga_yuv_rgb_batch(g, nimages, tmp, ystride, d_rgb, rgb_stride, stream);
+    {
+      const hipError_t e = hipStreamSynchronize(st);
+      (void)hipFree(tmp);
+      if (rc == EXIT_SUCCESS && e != hipSuccess) rc = jga_fail("HIP error %d (%s) in the two-pass RGB stage", (int)e, hipGetErrorString(e));
+    }
+    return rc;
+  }
   if (fill_params(&P, g, nimages, d_coef, coef_stride, d_qtab,
    dequant_on_device, d_rgb, rgb_stride, 1) != EXIT_SUCCESS) {
     return EXIT_FAILURE;
@@ -137,9 +159,7 @@ JGA_EXPORT int jga_yuv_rgb_batch(const jga_geom *g, int nimages,
   if (g->nplanes != 1 && g->nplanes != 3) {
     return jga_fail("Unsupported number of components %i", g->nplanes);
   }
-  if (g->nplanes == 3 && (g->plane[0].xdec || g->plane[0].ydec
-   || g->plane[1].xdec != g->plane[2].xdec
-   || g->plane[1].ydec != g->plane[2].ydec)) {
+  if (g->nplanes == 3 && (g->plane[0].xdec || g->plane[0].ydec)) {
     return jga_fail("Unsupported sampling for the device stage");
   }
   if (yuv_stride < g->yuv_bytes) return jga_fail("yuv_stride too small");
@@ -158,8 +178,9 @@ JGA_EXPORT int jga_yuv_rgb_batch(const jga_geom *g, int nimages,
   }
   P.out_aligned = (((long long)g->width*3) % 4 == 0) && (rgb_stride % 4 == 0)
    && (((uintptr_t)d_rgb) % 4 == 0);
-  rc = jga_launch_yuv_rgb(&P, g->nplanes == 3 ? g->plane[1].xdec : 0,
-   g->nplanes == 3 ? g->plane[1].ydec : 0, stream);
+  rc = g->nplanes == 3
+   ? jga_launch_yuv_rgb(&P, g->plane[1].xdec, g->plane[1].ydec, g->plane[2].xdec, g->plane[2].ydec, stream)
+   : jga_launch_yuv_rgb(&P, 0, 0, 0, 0, stream);
   if (rc) return jga_fail("YUV->RGB kernel launch failed (HIP error %d)", rc);
   return EXIT_SUCCESS;
 }

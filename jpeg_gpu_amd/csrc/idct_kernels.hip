@@ -883,7 +883,7 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
 // img->pixels.  Used when a caller stops the decode at the YUV stage (the harness's
 // `-o yuv`).  SURVEY.md A.5 arithmetic, evaluated literally.  One thread = 8 pixels
 // of one row; HBM-bound: reads 1 + 2/(LW*LH) bytes, writes 3 bytes per pixel.
-__global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, int xdec, int ydec) {
+__global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, int uxdec, int uydec, int vxdec, int vydec) {
   // 8 pixels per thread: Y as one 8-byte load, chroma as 8 >> xdec bytes, 24 output bytes.  A
   // wave's 64 threads cover 512 consecutive pixels of one row = 1536 contiguous output bytes,
   // which leave through the wave's LDS line as 16 bytes per lane (store_rgb_row_wave) when the
@@ -910,30 +910,32 @@ __global__ __launch_bounds__(256) void jga_yuv_rgb_kernel(const jga_kparams P, i
     }
     return;
   }
-  const uint8_t *pu = base + P.plane_data_off[1] + (long long)(y >> ydec)*(P.plane_hblocks[1]*8)
-   + (xl >> xdec);
-  const uint8_t *pv = base + P.plane_data_off[2] + (long long)(y >> ydec)*(P.plane_hblocks[2]*8)
-   + (xl >> xdec);
+  // (Cb and Cr carry their own decimation, as in res/unyuv.fs.glsl:6-9, 29-31, 39-41: files whose
+  // chroma planes differ are rare, and this kernel is also their colour stage — jga_idct_rgb_batch)
+  const uint8_t *pu = base + P.plane_data_off[1] + (long long)(y >> uydec)*(P.plane_hblocks[1]*8)
+   + (xl >> uxdec);
+  const uint8_t *pv = base + P.plane_data_off[2] + (long long)(y >> vydec)*(P.plane_hblocks[2]*8)
+   + (xl >> vxdec);
   uint32_t ub[2] = {0, 0}, vb[2] = {0, 0};                         // 8 >> xdec chroma bytes
-  if (xdec == 0) {
-    const uint2 a = *reinterpret_cast<const uint2 *>(pu), b = *reinterpret_cast<const uint2 *>(pv);
-    ub[0] = a.x; ub[1] = a.y; vb[0] = b.x; vb[1] = b.y;
+  if (uxdec == 0) {
+    const uint2 a = *reinterpret_cast<const uint2 *>(pu);
+    ub[0] = a.x; ub[1] = a.y;
   }
-  else if (xdec == 1) {
-    ub[0] = *reinterpret_cast<const uint32_t *>(pu);
-    vb[0] = *reinterpret_cast<const uint32_t *>(pv);
+  else if (uxdec == 1) ub[0] = *reinterpret_cast<const uint32_t *>(pu);
+  else ub[0] = *reinterpret_cast<const uint16_t *>(pu);
+  if (vxdec == 0) {
+    const uint2 b = *reinterpret_cast<const uint2 *>(pv);
+    vb[0] = b.x; vb[1] = b.y;
   }
-  else {
-    ub[0] = *reinterpret_cast<const uint16_t *>(pu);
-    vb[0] = *reinterpret_cast<const uint16_t *>(pv);
-  }
+  else if (vxdec == 1) vb[0] = *reinterpret_cast<const uint32_t *>(pv);
+  else vb[0] = *reinterpret_cast<const uint16_t *>(pv);
   float rgb[24];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const int c = i >> xdec;
+    const int cu = i >> uxdec, cv = i >> vxdec;
     const float Y = (float)(((i < 4 ? yy.x : yy.y) >> (8*(i & 3))) & 255u);
-    const float u = (float)((ub[c >> 2] >> (8*(c & 3))) & 255u) - 128.0f;
-    const float v = (float)((vb[c >> 2] >> (8*(c & 3))) & 255u) - 128.0f;
+    const float u = (float)((ub[cu >> 2] >> (8*(cu & 3))) & 255u) - 128.0f;
+    const float v = (float)((vb[cv >> 2] >> (8*(cv & 3))) & 255u) - 128.0f;
     // clamp + 0.5 + truncation of SURVEY.md A.5; v_cvt_pk_u8_f32 then converts an
     // integer-valued float in [0,255]
     rgb[3*i + 0] = __builtin_floorf(__builtin_fminf(__builtin_fmaxf(Y + 1.402f*v, 0.0f), 255.0f) + 0.5f);
@@ -1027,9 +1029,10 @@ extern "C" int jga_launch_yuv(const jga_kparams *P, int staged, void *stream) {
   return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int jga_launch_yuv_rgb(const jga_kparams *P, int xdec, int ydec, void *stream) {
+extern "C" int jga_launch_yuv_rgb(const jga_kparams *P, int uxdec, int uydec, int vxdec, int vydec,
+ void *stream) {
   dim3 grid((P->width + 2047)/2048, P->height, P->nimages), block(256);
-  hipLaunchKernelGGL(jga_yuv_rgb_kernel, grid, block, 0, (hipStream_t)stream, *P, xdec, ydec);
+  hipLaunchKernelGGL(jga_yuv_rgb_kernel, grid, block, 0, (hipStream_t)stream, *P, uxdec, uydec, vxdec, vydec);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -43,7 +43,7 @@ int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec, int staged,
  void *stream);
 int jga_launch_yuv(const jga_kparams *P, int staged, void *stream);
 /* P->coef = the YUV-stage bytes (as int16*), coef_stride in BYTES */
-int jga_launch_yuv_rgb(const jga_kparams *P, int xdec, int ydec, void *stream);
+int jga_launch_yuv_rgb(const jga_kparams *P, int uxdec, int uydec, int vxdec, int vydec, void *stream);
 #ifdef __cplusplus
 }
 #endif

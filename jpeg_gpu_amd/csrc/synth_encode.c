@@ -189,6 +189,18 @@ typedef struct frame {
 
 static int ilog(unsigned v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
 
+/* Chroma sampling factors of the frames made from here on (Cb h, v, Cr h, v): 1,1,1,1 unless a
+ * test asks for a file whose chroma planes are decimated differently, or whose luma is not the
+ * finest plane.  Process-wide and not thread-safe: set, encode, reset (synth.py does). */
+static int g_chroma[4] = {1, 1, 1, 1};
+JGS_API int jgs_set_chroma_factors(int cbh, int cbv, int crh, int crv) {
+  const int v[4] = {cbh, cbv, crh, crv};
+  int i;
+  for (i = 0; i < 4; i++) if (v[i] != 1 && v[i] != 2 && v[i] != 4) return 1;
+  memcpy(g_chroma, v, sizeof(v));
+  return 0;
+}
+
 static int frame_init(frame *f, int width, int height, int ncomps, int hs,
  int vs) {
   int i;
@@ -199,8 +211,13 @@ static int frame_init(frame *f, int width, int height, int ncomps, int hs,
   if ((hs != 1 && hs != 2 && hs != 4) || (vs != 1 && vs != 2 && vs != 4)) return 1;
   f->width = width; f->height = height; f->ncomps = ncomps;
   f->hs[0] = ncomps == 1 ? 1 : hs; f->vs[0] = ncomps == 1 ? 1 : vs;
-  f->hs[1] = f->hs[2] = f->vs[1] = f->vs[2] = 1;
+  f->hs[1] = g_chroma[0]; f->vs[1] = g_chroma[1];
+  f->hs[2] = g_chroma[2]; f->vs[2] = g_chroma[3];
   f->hmax = f->hs[0]; f->vmax = f->vs[0];
+  for (i = 1; i < ncomps; i++) {
+    if (f->hs[i] > f->hmax) f->hmax = f->hs[i];
+    if (f->vs[i] > f->vmax) f->vmax = f->vs[i];
+  }
   f->nhmb = (width + 8*f->hmax - 1)/(8*f->hmax);
   f->nvmb = (height + 8*f->vmax - 1)/(8*f->vmax);
   for (i = 0; i < ncomps; i++) {

@@ -32,10 +32,25 @@ S.jgs_quality_tables.argtypes = [C.c_int, C.c_void_p]
 S.jgs_synthetic_pixels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint]
 
 
+S.jgs_set_chroma_factors.argtypes = [C.c_int] * 4
+
+
 def _samp(sampling, ncomps):
+    """(hs, vs) of the luma plane, with the chroma factors of the next frame set to match:
+    a name, (hs, vs) — chroma 1x1 — or ((hs, vs), (hs, vs), (hs, vs)) for Y, Cb, Cr."""
+    chroma = (1, 1, 1, 1)
     if ncomps == 1:
-        return 1, 1
-    return SAMPLING[sampling] if isinstance(sampling, str) else tuple(sampling)
+        luma = (1, 1)
+    elif isinstance(sampling, str):
+        luma = SAMPLING[sampling]
+    elif isinstance(sampling[0], (tuple, list)):
+        luma = tuple(sampling[0])
+        chroma = tuple(sampling[1]) + tuple(sampling[2])
+    else:
+        luma = tuple(sampling)
+    if S.jgs_set_chroma_factors(*chroma):
+        raise ValueError("sampling factors must be 1, 2 or 4")
+    return luma
 
 
 def synthetic_jpeg(width, height, sampling="420", quality=90, restart_interval=0, seed=1234,

@@ -14,7 +14,8 @@ Writes (all small, committed):
   layout.json       image_init results for the BASELINE.json geometries
                     
   jpegs_rare.npz    (rare) the sampling factors the reference accepts beyond the usual six
-                    (src/xjpeg.c:384-391: any of 1, 2, 4): luma 4x2, 2x4, 1x4 — same arrays
+                    (src/xjpeg.c:384-391: any of 1, 2, 4): luma 4x2, 2x4, 1x4, and Cb / Cr
+                    decimated differently from each other — same arrays
                     as jpegs.npz, loaded together with it by tests/conftest.py
   jpegs_mcu18.npz   (rare) luma 4x4: 18 blocks per MCU, more than T.81 B.2.3 allows and
                     libjpeg takes, but the reference decodes it
@@ -74,6 +75,11 @@ def rare():
         "synth_2x4_dri_row_50x70": synth.synthetic_jpeg(50, 70, (2, 4), quality=60, restart_interval=-1, seed=24),
         "synth_1x4_24x64_q90": synth.synthetic_jpeg(24, 64, (1, 4), quality=90, seed=25),
         "synth_1x4_dqt16_17x37": synth.synthetic_jpeg(17, 37, (1, 4), quality=50, seed=26, flags=synth.DQT16),
+        # Cb and Cr decimated differently (res/unyuv.fs.glsl has u_xdec/u_ydec and v_xdec/v_ydec)
+        "synth_y2x2_cb2x1_cr1x1_70x50": synth.synthetic_jpeg(70, 50, ((2, 2), (2, 1), (1, 1)), quality=85, seed=29),
+        "synth_y4x1_cb1x1_cr2x1_dri4_90x30": synth.synthetic_jpeg(90, 30, ((4, 1), (1, 1), (2, 1)), quality=70,
+                                                                 restart_interval=4, seed=30),
+        "synth_y2x2_cb1x2_cr2x1_41x39": synth.synthetic_jpeg(41, 39, ((2, 2), (1, 2), (2, 1)), quality=90, seed=31),
     }
     np.savez_compressed(os.path.join(HERE, "jpegs_rare.npz"), **reference_outputs(R, files))
     files = {

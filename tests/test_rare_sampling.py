@@ -8,6 +8,10 @@ import numpy as np
 import pytest
 
 RARE = [(4, 2), (2, 4), (1, 4), (4, 4)]
+# Cb and Cr with their own factors (luma still the finest plane): res/unyuv.fs.glsl:6-9 takes
+# u_xdec/u_ydec and v_xdec/v_ydec separately, src/jpeg_gpu.c:868-877
+MIXED = [((2, 2), (2, 1), (1, 1)), ((2, 1), (1, 1), (2, 1)), ((2, 2), (1, 2), (2, 1)),
+         ((4, 1), (1, 1), (2, 1)), ((2, 2), (2, 2), (1, 1)), ((4, 2), (2, 1), (1, 2))]
 
 
 def rgb_of(orc, data):
@@ -36,7 +40,7 @@ def test_mcu18_goldens_oracle_and_host_stages(orc, lib, golden_mcu18):
         assert (pack == G[name + ".pack"]).all() and (index == G[name + ".index"]).all(), name
 
 
-@pytest.mark.parametrize("samp", RARE)
+@pytest.mark.parametrize("samp", RARE + MIXED)
 @pytest.mark.parametrize("size", [(8, 8), (150, 90), (33, 65)])
 def test_oracle_equals_reference(orc, ref, synth, samp, size):
     import oracle
@@ -63,11 +67,12 @@ def test_gpu_entropy_stage_verdicts(synth):
         assert emul.huff_emul_prepare_head(d, len(d)) == want, samp
 
 
-def test_plugin_host_stages(lib, orc, synth):
+@pytest.mark.parametrize("samp", [(4, 2), MIXED[0], MIXED[3]])
+def test_plugin_host_stages(lib, orc, synth, samp):
     """The plugin instance's CPU-side stages (PACK / QUANT / DCT) for a rare sampling."""
     import oracle
     from jpeg_gpu_amd import abi
-    data = synth.synthetic_jpeg(90, 70, (4, 2), quality=75, restart_interval=2, seed=9)
+    data = synth.synthetic_jpeg(90, 70, samp, quality=75, restart_interval=2, seed=9)
     with lib.Decoder(data) as d:
         d.read_header()
         d.init_image()
@@ -82,7 +87,7 @@ def test_plugin_host_stages(lib, orc, synth):
 # ---- on the GPU --------------------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("samp", RARE)
+@pytest.mark.parametrize("samp", RARE + MIXED)
 @pytest.mark.parametrize("size", [(8, 8), (17, 9), (150, 90), (640, 360), (1031, 517)])
 def test_kernels_match_oracle(gpu, orc, synth, samp, size):
     from test_gpu_parity import check_image
@@ -109,7 +114,7 @@ def test_mcu18_goldens_device_stages(gpu, golden_mcu18):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("samp", RARE)
+@pytest.mark.parametrize("samp", RARE + MIXED)
 def test_plugin_and_pipeline(gpu, orc, synth, samp):
     """decode_image(YUV / RGB) through the plugin instance, and the three pipeline transports
     (the GPU entropy stage for the samplings it can hold, the host stage for luma 4x4)."""
@@ -147,7 +152,10 @@ def test_gpu_entropy_stage(gpu, orc, synth):
     """Ten-block MCUs through the GPU Huffman decoder (both clean-ups) against the oracle's QUANT
     planes; the eighteen-block one is turned away with the host-stage verdict."""
     import oracle
-    for samp in ((4, 2), (2, 4), (1, 4)):
+    def blocks_per_mcu(samp):
+        return sum(h * v for h, v in samp) if isinstance(samp[0], tuple) else samp[0] * samp[1] + 2
+    assert [blocks_per_mcu(s) for s in RARE] == [10, 10, 6, 18]
+    for samp in [s for s in RARE + MIXED if blocks_per_mcu(s) <= 10]:
         for ri in (0, -1, 3):
             datas = [synth.synthetic_jpeg(333, 222, samp, quality=q, restart_interval=ri, seed=q)
                      for q in (35, 92)]
@@ -156,5 +164,6 @@ def test_gpu_entropy_stage(gpu, orc, synth):
                 real = gpu.real_coef_mask(g)
                 for d, c in zip(datas, coefs):
                     assert np.array_equal(c[real], orc.decode(d, oracle.QUANT)[1][real]), (samp, ri, dev)
-    with pytest.raises(gpu.JgaError, match="GPU entropy stage"):
-        gpu.gpu_entropy_decode([synth.synthetic_jpeg(64, 64, (4, 4), seed=1)])
+    for samp in [s for s in RARE + MIXED if blocks_per_mcu(s) > 10]:      # luma 4x4; 4x2 + 2x1 + 1x2
+        with pytest.raises(gpu.JgaError, match="GPU entropy stage"):
+            gpu.gpu_entropy_decode([synth.synthetic_jpeg(64, 64, samp, seed=1)])
