@@ -343,8 +343,10 @@ typedef struct jga_pipeline_config {
                                 * frames fill a group to about the same pixel count (up to 16x
                                 * as many); jobs are grouped by geometry in arrival order */
   int unstuff;                 /* transport 2, where stuffing and RSTn markers are removed: 0 = auto (on
-                                * the GPU for groups whose jobs are all `pinned`, else on the host:
-                                * one core unstuffs ~12 GB/s, as fast as it could copy), 1 = host,
+                                * the GPU for groups whose jobs are all `pinned`, and for every group
+                                * when the host side has 8 cores or fewer to count on — the smaller of
+                                * the process's CPU grant and `nthreads`; else on the host: one core
+                                * unstuffs ~12 GB/s, as fast as it could copy), 1 = host,
                                 * 2 = GPU (jga_huff_set_device_unstuff) */
 } jga_pipeline_config;
 
@@ -399,7 +401,7 @@ int jga_huff_image_error(const jga_huff_batch *b, int i);
 const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
 /* Where the scan's byte-level clean-up happens (stuffed zeros, fill bytes, RSTn markers ->
  * restart segments; T.81 B.1.1.5, the reference's bit reader src/xjpeg.c:113-127, 593-629):
- * 0 = on the host inside jga_huff_prepare (one core unstuffs ~3 GB/s), 1 = on the GPU — prepare
+ * 0 = on the host inside jga_huff_prepare (one core unstuffs ~12 GB/s), 1 = on the GPU — prepare
  * then only parses the marker segments and copies the raw scans into pinned memory.  Same
  * planes either way; with 1 a damaged restart structure is reported by jga_huff_decode
  * (per-image verdicts) instead of jga_huff_prepare.  Default 0, or JGA_HUFF_DEVICE_UNSTUFF. */
@@ -409,8 +411,9 @@ void jga_huff_set_device_unstuff(jga_huff_batch *b, int on);
  * straight from where they lie and the host touches no entropy-coded byte at all.  The buffers
  * must stay unchanged until the stream has executed prepare()'s copies. */
 void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on);
-/* 1: the host waits inside jga_huff_decode sleep on a blocking event instead of spinning in
- * hipStreamSynchronize — for pipelines whose lanes outnumber the CPUs they may use. */
+/* 1: the host waits inside jga_huff_decode poll the stream's event and sleep in between instead of
+ * spinning in hipStreamSynchronize — for pipelines whose lanes outnumber the CPUs they may use
+ * (a wait on a hipEventBlockingSync event spins just the same on this stack: csrc/host_wait.h). */
 void jga_huff_set_blocking_waits(jga_huff_batch *b, int on);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);

@@ -13,8 +13,10 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <time.h>
 #include <vector>
 #include "huff_kernels.h"
+#include "host_wait.h"
 #include "huff_prepare.h"
 #include "unstuff_kernels.h"
 
@@ -118,7 +120,7 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_zeroed, hipEventDisableTiming) == hipSuccess
-   && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
+   && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     jga_fail("huff: allocation failed (%d images, %lld scan bytes)", max_images, max_scan_bytes);
     jga_huff_destroy(b);
@@ -211,6 +213,8 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
  jga_geom *geom, void *stream) {
   std::vector<hj_prepared> prep((size_t)n);
   std::atomic<int> next_a(0), next_b(0), failed(0), irregular(0);
+  const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  const auto t_0 = std::chrono::steady_clock::now();
   int nt = b->prepare_threads;
   if (nt <= 0) {
     nt = jga_cpu_budget();
@@ -325,6 +329,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->unstuffed_on_device = 1;
   b->shadow.clear();
   hipStream_t st = (hipStream_t)stream;
+  const auto t_1 = std::chrono::steady_clock::now();
   if (zero_copy) {
     // the files lie in pinned memory: the DMA engine reads the scans where they are (the host
     // never touches an entropy-coded byte); descriptors + tables go up from the blob as usual
@@ -351,7 +356,15 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   U.errors = (uint32_t *)(b->d_blob + b->off_perr);
   U.nimages = n;
   U.sub_log2 = b->sub_log2;
+  const auto t_2 = std::chrono::steady_clock::now();
   if (hj_launch_unstuff(&U, b->max_chunks, st)) return jga_fail("huff: launch failed");
+  if (trace) {
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
+      return std::chrono::duration<double, std::milli>(c - a).count(); };
+    fprintf(stderr, "  prepare (device clean-up%s, %d threads): heads + blob %.2f ms, %d copy call(s) + 2 memsets %.2f ms, 4 launches %.2f ms\n",
+     zero_copy ? ", files pinned" : "", nt, ms(t_0, t_1), zero_copy ? n + 1 : 1, ms(t_1, t_2),
+     ms(t_2, std::chrono::steady_clock::now()));
+  }
   if (geom) *geom = b->geom;
   return EXIT_SUCCESS;
 }
@@ -587,12 +600,12 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
 
 // Wait for everything queued on `st`.  hipStreamSynchronize spins on a host core — the right
 // thing for one frame's latency, the wrong one for a pipeline whose lanes outnumber the CPUs
-// the container grants: there the waiting lane sleeps on a blocking event and leaves the core
-// to the lanes that are parsing headers.
+// the container grants: there the waiting lane polls and sleeps (host_wait.h; an event with
+// hipEventBlockingSync spins just the same on this stack) and leaves the core to the lanes that
+// are parsing headers.
 static hipError_t wait_stream(jga_huff_batch *b, hipStream_t st) {
   if (!b->blocking_waits) return hipStreamSynchronize(st);
-  const hipError_t e = hipEventRecord(b->ev_wait, st);
-  return e != hipSuccess ? e : hipEventSynchronize(b->ev_wait);
+  return jga_stream_wait_sleeping(st, b->ev_wait);
 }
 
 JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
@@ -611,7 +624,16 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   return rc;
 }
 
+static double thread_cpu_ms() {
+  timespec ts;
+  clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+  return (double)ts.tv_sec*1e3 + (double)ts.tv_nsec*1e-6;
+}
+
 static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, hipStream_t st) {
+  static const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  double c0 = trace ? thread_cpu_ms() : 0.0, c_launch = 0.0, c_wait = 0.0;
+  auto lap = [&](double &acc) { if (trace) { const double c = thread_cpu_ms(); acc += c - c0; c0 = c; } };
   hj_args A;
   memset(&A, 0, sizeof(A));
   A.images = (const hj_image *)(b->d_blob + b->off_images);
@@ -683,7 +705,9 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
       }
     }
     HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
+    lap(c_launch);
     HOK(wait_stream(b, st));
+    lap(c_wait);
     if (b->h_ran[round - 1] == 0) break;                   // a round in which nothing moved
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
     // (a batch object whose previous decode needed the walk — the same camera, the same
@@ -697,7 +721,10 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
   if (hj_launch_write(&A, (int)b->max_nsub, write_gmem, st)) return jga_fail("huff: launch failed");
   HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
+  lap(c_launch);
   HOK(wait_stream(b, st));
+  lap(c_wait);
+  if (trace) fprintf(stderr, "  huff decode: this thread's CPU in launches + copies %.2f ms, in waits %.2f ms\n", c_launch, c_wait);
   // per-image verdicts stay readable (jga_huff_image_error): the other images of the batch
   // are decoded correctly whatever one damaged member did
   b->image_errors = 0;

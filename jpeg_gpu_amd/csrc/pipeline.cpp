@@ -26,9 +26,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <time.h>
 #include <unordered_map>
 #include <vector>
 #include "jga_internal.h"
+#include "host_wait.h"
 
 namespace {
 
@@ -83,8 +85,14 @@ struct jga_pipeline {
   std::condition_variable dev_cv;
   int dev_slots = 3;
   // Lanes wait for the device several times per group; spinning in hipStreamSynchronize would
-  // hold a core each, and a container may grant fewer cores than there are lanes.
+  // hold a core each, and a container may grant fewer cores than there are lanes: they poll and
+  // sleep instead (host_wait.h; JGA_PIPE_SPIN=1 restores the spinning).
   int blocking = 1;
+  // cfg.unstuff = 0 (auto): the scan clean-up runs on the device for groups whose files are all
+  // pinned, and for any group when the host is short of cores — with 4 CPUs the device
+  // clean-up of pageable files runs 100 Gpixel/s against 80 (2 CPUs: 84 / 67; 16 CPUs: equal,
+  // the device being the limit either way; profiles/r2_host_waits.txt)
+  bool offload_cleanup = false;
 };
 
 namespace {
@@ -155,7 +163,7 @@ bool ensure_slot(slot &s, long long coef_shorts, long long out_bytes, bool copy_
 // Wait for the slot's GPU work and hand the result to the job.
 void retire(slot &s, bool copy_back) {
   if (!s.job) return;
-  if (!HOK(hipEventSynchronize(s.done))) s.job->status = EXIT_FAILURE;
+  if (!HOK(jga_event_wait_sleeping(s.done))) s.job->status = EXIT_FAILURE;     // (usually over already)
   else if (copy_back && s.job->host_out) memcpy(s.job->host_out, s.h_out, (size_t)s.out_bytes);
   s.job = nullptr;
 }
@@ -310,12 +318,18 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
 
   }
   const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  auto thread_cpu_ms = []() {          // CPU time this lane thread has burnt so far
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec*1e3 + (double)ts.tv_nsec*1e-6;
+  };
   const auto t_a = std::chrono::steady_clock::now();
+  const double c_a = trace ? thread_cpu_ms() : 0.0;
   jga_huff_set_threads(l.hb, threads);
   {
     bool pinned = true;
     for (int i = 0; i < m; i++) pinned = pinned && jobv[i]->pinned != 0;
-    const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pinned);
+    const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && (pinned || pl->offload_cleanup));
     jga_huff_set_device_unstuff(l.hb, on_device);
     jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
@@ -347,6 +361,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   device_turn turn(pl);
   turn.take();                        // (the group's upload is already in flight)
   const auto t_b = std::chrono::steady_clock::now();
+  const double c_b = trace ? thread_cpu_ms() : 0.0;
   if (host_entropy) {
     unsigned short q[192];
     memset(q, 0, sizeof(q));
@@ -367,6 +382,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     }
   }
   const auto t_c = std::chrono::steady_clock::now();
+  const double c_c = trace ? thread_cpu_ms() : 0.0;
   bool scattered = false;
   for (int i = 0; i < m; i++) scattered = scattered || jobv[i]->dev_out != nullptr;
   if (!scattered) {
@@ -391,8 +407,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
       if (!HOK(hipMemcpyAsync(l.h_out + ostride*i, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return EXIT_FAILURE;
     }
   }
-  if (pl->blocking ? !(HOK(hipEventRecord(l.done, l.stream)) && HOK(hipEventSynchronize(l.done)))
-   : !HOK(hipStreamSynchronize(l.stream))) {
+  if (!HOK(pl->blocking ? jga_stream_wait_sleeping(l.stream, l.done) : hipStreamSynchronize(l.stream))) {
     return EXIT_FAILURE;
   }
   turn.give();
@@ -400,8 +415,10 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     const auto t_d = std::chrono::steady_clock::now();
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count(); };
-    fprintf(stderr, "lane group of %d: prepare %.2f ms, entropy decode %.2f ms, idct+out+sync %.2f ms\n",
-     m, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d));
+    const double c_d = thread_cpu_ms();
+    fprintf(stderr, "lane group of %d: prepare + wait for a device slot %.2f ms (%.2f of this thread's CPU), "
+     "entropy decode %.2f ms (%.2f), idct+out+sync %.2f ms (%.2f)\n",
+     m, ms(t_a, t_b), c_b - c_a, ms(t_b, t_c), c_c - c_b, ms(t_c, t_d), c_d - c_c);
   }
   const long long up = host_entropy ? g.coef_shorts*2 : jga_huff_upload_bytes(l.hb)/m;
   if (copy_back) {
@@ -503,6 +520,13 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->cfg.nthreads = pl->cfg.transport == 2 ? cpus + cpus/2 : 3*cpus;
     if (pl->cfg.nthreads > 96) pl->cfg.nthreads = 96;
   }
+  {
+    // how many cores the host side can count on: what the process is granted, or fewer if the
+    // caller asked for fewer threads (a rank that shares its grant with seven others does)
+    const int cpus = jga_cpu_budget();
+    const int at = getenv("JGA_PIPE_OFFLOAD_AT") ? atoi(getenv("JGA_PIPE_OFFLOAD_AT")) : 8;      // tuning knob
+    pl->offload_cleanup = (cpus < pl->cfg.nthreads ? cpus : pl->cfg.nthreads) <= at;
+  }
   if (!hip_ok(hipSetDevice(pl->cfg.device), "hipSetDevice")) {
     delete pl;
     return nullptr;
@@ -514,7 +538,7 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     if (const char *e = getenv("JGA_PIPE_SPIN")) pl->blocking = atoi(e) == 0;         // tuning knob
     for (auto &l : pl->lanes) {
       if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")
-       || !hip_ok(hipEventCreateWithFlags(&l.done, hipEventDisableTiming | hipEventBlockingSync), "hipEventCreate")) {
+       || !hip_ok(hipEventCreateWithFlags(&l.done, hipEventDisableTiming), "hipEventCreate")) {
         jga_pipeline_destroy(pl);
         return nullptr;
       }

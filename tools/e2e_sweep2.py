@@ -22,9 +22,31 @@ for batch, depth, nthr in cfgs:
     cyc = lambda k, o=0: [distinct[(o + i) % 64] for i in range(k)]
     pl.run_jobs(lib.Pipeline.make_jobs(cyc(batch * depth), pinned=PINNED))
     jobs = lib.Pipeline.make_jobs(cyc(n, 3), pinned=PINNED)
+    import resource
+    def task_times():
+        out = {}
+        for t in os.listdir("/proc/self/task"):
+            try:
+                f = open("/proc/self/task/%s/stat" % t).read().rsplit(")", 1)[1].split()
+                out[t] = (open("/proc/self/task/%s/comm" % t).read().strip(), (int(f[11]) + int(f[12])) / os.sysconf("SC_CLK_TCK"))
+            except OSError:
+                pass
+        return out
     best = 1e9
+    tt0 = task_times()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     for _ in range(3):
         t0 = time.perf_counter(); rc = pl.run_jobs(jobs); best = min(best, time.perf_counter() - t0)
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    if os.environ.get("RUSAGE"):
+        tt1 = task_times()
+        per = sorted(((tt1[t][1] - tt0.get(t, (None, 0))[1], tt1[t][0], t) for t in tt1), reverse=True)[:5]
+        print("   threads that outlive the run (runtime helpers, main), CPU us per image:",
+              ", ".join("%s %.0f" % (nm, dt / (3 * n) * 1e6) for dt, nm, t in per), flush=True)
     pl.close()
-    print("batch %2d lanes %d threads %3d: %6.1f ms for %d images = %6.1f Gpixel/s (rc %d)" % (
-        batch, depth, nthr, best * 1e3, n, n * W * H / best / 1e9, rc), flush=True)
+    cpu = " | host CPU per image: user %.0f us, sys %.0f us, %d vol / %d invol switches per image x100" % (
+        (ru1.ru_utime - ru0.ru_utime) / (3 * n) * 1e6, (ru1.ru_stime - ru0.ru_stime) / (3 * n) * 1e6,
+        (ru1.ru_nvcsw - ru0.ru_nvcsw) * 100 // (3 * n), (ru1.ru_nivcsw - ru0.ru_nivcsw) * 100 // (3 * n)) \
+        if os.environ.get("RUSAGE") else ""
+    print("batch %2d lanes %d threads %3d: %6.1f ms for %d images = %6.1f Gpixel/s (rc %d)%s" % (
+        batch, depth, nthr, best * 1e3, n, n * W * H / best / 1e9, rc, cpu), flush=True)
