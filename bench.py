@@ -565,6 +565,9 @@ def main():
                         "kernel; %d steps streamed through %d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
             "batch_per_gpu": PB, "pipeline_group": G, "distinct_images_per_gpu": len(jpegs),
             "images_timed_per_gpu": K * PB, "h2d_bytes_per_image": int(h2d_per_image),
+            # what the link carries per GPU at this rate (it sustains ~56 GB/s from pinned memory,
+            # tools/h2d_probe.py): `value` sits within ~10 % of the PCIe ceiling for this content
+            "h2d_GBps_per_gpu_at_value": round(rate / world / (W * H) * h2d_per_image / 1e9, 1),
             "parallelism": "image-sharded x%d, one process per GPU, no data-path collective" % world,
             "host_threads_per_gpu": nthreads, "cpu_pinning": pin,
             "host_cpus": {"visible_to_rank": my_cpus, "cgroup_cpu_quota": quota,
