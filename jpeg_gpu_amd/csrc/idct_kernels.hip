@@ -727,8 +727,7 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
   }
   float z[64], t[64];
   row_pass_ldsq<DEQUANT>(rows, qlds + pl*8, z);
-  const float tmax = col_pass(z, t);
-  const bool clip = __builtin_amdgcn_ballot_w64(tmax > 127.0f) != 0ull;
+  (void)col_pass(z, t);
 
   // the unit this lane converts in every phase: luma block uidx, row urr of the phase
   const int u = threadIdx.x;
@@ -762,12 +761,12 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
           for (int h = 0; h < 8; h += 4) {
             v4f v;
             v.x = t[r*8 + h]; v.y = t[r*8 + h + 1]; v.z = t[r*8 + h + 2]; v.w = t[r*8 + h + 3];
-            if (clip) {
-              v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
-              v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
-              v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
-              v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
-            }
+            // (always: a wave-uniform "does anybody overshoot?" test around these four turns into
+            // med3 + select, two instructions per value instead of one)
+            v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
+            v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
+            v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
+            v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
             *reinterpret_cast<v4f *>(dst + h) = v;
           }
         }
@@ -784,12 +783,12 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
           for (int h = 0; h < 8; h += 4) {
             v4f v;
             v.x = t[crow*8 + h]; v.y = t[crow*8 + h + 1]; v.z = t[crow*8 + h + 2]; v.w = t[crow*8 + h + 3];
-            if (clip) {
-              v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
-              v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
-              v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
-              v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
-            }
+            // (always: a wave-uniform "does anybody overshoot?" test around these four turns into
+            // med3 + select, two instructions per value instead of one)
+            v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
+            v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
+            v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
+            v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
             *reinterpret_cast<v4f *>(dst + h) = v;
           }
         }
