@@ -11,7 +11,8 @@ stats = {"gpu_err": 0, "host_err": 0, "both_ok_equal": 0, "both_ok_diff": 0, "gp
 t0 = time.time()
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 200):
     if len(sys.argv) > 3:             # wide variant: every sampling, larger frames, more restart patterns
-        samp = ["420", "444", "grey", "422", "440", "411"][it % 6]
+        samp = ["420", "444", "grey", "422", "440", "411", (4, 2), (2, 4), (1, 4), ((2, 2), (2, 1), (1, 1)),
+                ((4, 1), (1, 1), (2, 1)), ((2, 2), (1, 2), (2, 1))][it % 12]
         ri = [0, 1, 2, 7, -1][it % 5]
         d = bytearray(synth.synthetic_jpeg(300 + (it * 37) % 400, 150 + (it * 23) % 300, samp,
                                            quality=30 + (it * 13) % 66, restart_interval=ri, seed=it))
