@@ -28,8 +28,7 @@
 
 typedef struct htab {
   int valid;
-  uint16_t fast[1 << FAST_BITS];     /* (len << 8) | symbol, 0 = longer code */
-  int32_t fast_ac[1 << FAST_BITS];   /* (value << 8) | (run << 4) | total bits */
+  uint32_t fast[1 << FAST_BITS];     /* tot | len << 8 | symbol << 16 (tot = len + the symbol's magnitude bits), 0 = longer code */
   uint32_t maxcode[18];              /* left-aligned 16-bit exclusive bounds */
   int32_t delta[17];                 /* symbol index = code + delta[len] */
   uint8_t sym[256];
@@ -121,20 +120,10 @@ static int build_htab(htab *h, const uint8_t counts[16], const uint8_t *syms,
     if (s <= FAST_BITS) {
       unsigned c = (unsigned)codes[i] << (FAST_BITS - s);
       unsigned m = 1u << (FAST_BITS - s), j;
-      for (j = 0; j < m; j++) h->fast[c + j] = (uint16_t)((s << 8) | h->sym[i]);
-    }
-  }
-  if (is_ac) {
-    for (i = 0; i < (1 << FAST_BITS); i++) {
-      int e = h->fast[i];
-      if (e) {
-        int rs = e & 255, len0 = e >> 8;
-        int run = rs >> 4, mag = rs & 15;
-        if (mag && len0 + mag <= FAST_BITS) {
-          int v = (i >> (FAST_BITS - len0 - mag)) & ((1 << mag) - 1);
-          if (v < (1 << (mag - 1))) v -= (1 << mag) - 1;
-          h->fast_ac[i] = (int32_t)((uint32_t)v << 8) | (run << 4) | (len0 + mag);
-        }
+      /* what the symbol takes from the stream in all: its code and, behind it, the
+         magnitude bits its low nibble announces (DC: the category; AC: SSSS) */
+      for (j = 0; j < m; j++) {
+        h->fast[c + j] = (uint32_t)(s + (h->sym[i] & 15)) | ((uint32_t)s << 8) | ((uint32_t)h->sym[i] << 16);
       }
     }
   }
@@ -427,8 +416,8 @@ static inline int huff_symbol(bitreader *br, const htab *h) {
   unsigned code;
   int len;
   if (e) {
-    SKIP(br, e >> 8);
-    return (int)(e & 255);
+    SKIP(br, (e >> 8) & 255);
+    return (int)(e >> 16);
   }
   code = PEEK(br, 16);
   len = FAST_BITS + 1;
@@ -436,13 +425,6 @@ static inline int huff_symbol(bitreader *br, const htab *h) {
   if (len > 16) return -1;
   SKIP(br, len);
   return h->sym[((int)(code >> (16 - len)) + h->delta[len]) & 255];
-}
-
-static inline int receive_extend(bitreader *br, int s) {
-  int v = (int)PEEK(br, s);
-  SKIP(br, s);
-  if (v < (1 << (s - 1))) v -= (1 << s) - 1;
-  return v;
 }
 
 /* ---- scan --------------------------------------------------------------- */
@@ -456,14 +438,28 @@ typedef struct scan_out {
   int *index;
 } scan_out;
 
-/* One block.  `blk` receives 64 natural-order shorts (QUANT/DCT stages). */
+/* Sign extension of an s-bit magnitude (T.81 F.2.2.1 EXTEND), without a branch: values whose
+ * top bit is clear are negative, v - (2^s - 1). */
+static inline int extend_bits(unsigned v, int s) {
+  return (int)v + (int)(((v >> (s - 1)) - 1u) & (unsigned)(1 - (1 << s)));
+}
+
+/* One block.  `blk` receives 64 natural-order shorts (QUANT/DCT stages).
+ * One path per symbol whatever its length: a table look-up for the code (codes of up to
+ * FAST_BITS bits — nearly all — in one step), then the magnitude bits straight from the
+ * window.  The branches left are the ones that go the same way almost every time (window
+ * low, code longer than FAST_BITS, end of block): the earlier version chose between a
+ * combined code+value table and this path on every symbol, a coin toss on busy images. */
 static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
  const unsigned short *q, short *pred, short *blk, scan_out *so, int stage) {
   int s, k;
-  refill(br);
+  refill(br);                                      /* >= 57 bits: DC code + magnitude <= 27 */
   s = huff_symbol(br, dc);
   if (s < 0 || s > 15) return jga_fail("Error invalid DC code.");
-  if (s) *pred = (short)(*pred + receive_extend(br, s));
+  if (s) {
+    *pred = (short)(*pred + extend_bits(PEEK(br, s), s));
+    SKIP(br, s);
+  }
   if (stage == JGA_STAGE_PACK) {
     if (so->nwords + 64 > so->pack_cap) return jga_fail("Error PACK buffer too small.");   /* a block is at most 1 + 63 words */
     so->pack[so->nwords++] = (short)(*pred & 0xfff);
@@ -473,25 +469,37 @@ static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
     blk[0] = stage == JGA_STAGE_DCT ? (short)(*pred*q[0]) : *pred;
   }
   for (k = 1; k < 64;) {
-    int e, rs, r, v;
-    refill(br);
-    e = ac->fast_ac[PEEK(br, FAST_BITS)];
-    if (e) {
-      r = (e >> 4) & 15;
-      s = 1;
-      v = e >> 8;
-      SKIP(br, e & 15);
+    unsigned e;
+    int rs, r, v;
+    if (br->nbits < 32) refill(br);                /* a symbol takes at most 16 + 15 bits */
+    e = ac->fast[PEEK(br, FAST_BITS)];
+    if (__builtin_expect(e != 0, 1)) {
+      /* code and magnitude leave the window in ONE shift (the next look-up waits for nothing
+         else); the value is read from the bits as they were */
+      const uint64_t w = br->bits << ((e >> 8) & 255);
+      rs = (int)(e >> 16);
+      r = rs >> 4;
+      s = rs & 15;
+      SKIP(br, e & 255);
+      v = s ? extend_bits((unsigned)(w >> (64 - s)), s) : 0;
     }
     else {
       rs = huff_symbol(br, ac);
       if (rs < 0) return jga_fail("Error invalid AC code.");
+      r = rs >> 4;
+      s = rs & 15;
+      v = 0;
+      if (s) {
+        v = extend_bits(PEEK(br, s), s);
+        SKIP(br, s);
+      }
+    }
+    if (__builtin_expect(s == 0, 0)) {
       if (rs == 0) {                               /* EOB */
         if (stage == JGA_STAGE_PACK) so->pack[so->nwords++] = 0;
         break;
       }
-      r = rs >> 4;
-      s = rs & 15;
-      v = s ? receive_extend(br, s) : 0;
+      v = 0;                                       /* ZRL (or any run without a value): r + 1 zeros, xjpeg.c:507-508 */
     }
     k += r;
     if (k > 63) return jga_fail("Error indexing outside block.");
@@ -499,7 +507,7 @@ static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
       so->pack[so->nwords++] = (short)((r << 12) | (v & 0xfff));
     }
     else if (s) {
-      int n = DEZZ[k];
+      const int n = DEZZ[k];
       blk[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v;
     }
     k++;
