@@ -637,8 +637,27 @@ def main():
                         "ok": rc2 == 0, "host_threads": nt,
                         "h2d_bytes_per_image": int(sum(j.h2d_bytes for j in jr) // n)}
             del outs
+        # ... and with the callers' pixel buffers pinned (jga_job.pinned bit 1): D2H straight into
+        # them, no staging buffer and no host memcpy — the link is what is left (64 buffers, reused)
+        pouts = [lib.PinnedBytes(bytes(g.rgb_bytes)) for _ in range(64)]
+        p3 = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=True,
+                          transport=2, batch=G, depth=args.lanes)
+        n = 288
+        oc = [pouts[i % 64].array for i in range(n)]
+        p3.run_jobs(lib.Pipeline.make_jobs(cyc(args.lanes * G), host_outs=oc[:args.lanes * G], outs_pinned=True))
+        jr = lib.Pipeline.make_jobs(cyc(n, 3), host_outs=oc, outs_pinned=True)
+        t0 = time.perf_counter()
+        rc3 = p3.run_jobs(jr)
+        te = time.perf_counter() - t0
+        p3.close()
+        e2e["gpu_entropy_to_rgb_pinned_host"] = {
+            "value": round(n * W * H / te / 1e6, 1), "unit": "Mpixel/s", "images": n, "ok": rc3 == 0,
+            "d2h_GBps": round(n * g.rgb_bytes / te / 1e9, 1), "host_threads": nthreads}
+        for p_ in pouts:
+            p_.free()
         e2e["note"] = "all PCIe- and host-inclusive; *_to_rgb_host also copies the pixels back into " \
-                      "the callers' host buffers (the plugin's decode_image semantics)"
+                      "the callers' host buffers (the plugin's decode_image semantics), " \
+                      "*_to_rgb_pinned_host into buffers the caller pinned (no host memcpy)"
 
     if solo and not args.no_other:
         # Supplementary: the other device stages, each against its own algorithmic bytes

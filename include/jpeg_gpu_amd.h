@@ -358,8 +358,10 @@ typedef struct jga_job {
   int status;                  /* out: 0 ok, 1 failed */
   int width, height, nplanes;  /* out */
   long long h2d_bytes;         /* out: coefficient bytes this image sent over PCIe */
-  int pinned;                  /* in : `jpeg` lies in pinned memory (transport 2 with on-device
-                                * unstuffing then uploads the scan straight from it) */
+  int pinned;                  /* in : bit 0: `jpeg` lies in pinned memory (transport 2 with on-device
+                                * unstuffing then uploads the scan straight from it); bit 1: `host_out`
+                                * does (copy_back then writes the pixels straight into it: no staging
+                                * buffer, no host memcpy) — jga_host_malloc_pinned / jga_host_register */
 } jga_job;
 
 jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);

@@ -164,7 +164,7 @@ bool ensure_slot(slot &s, long long coef_shorts, long long out_bytes, bool copy_
 void retire(slot &s, bool copy_back) {
   if (!s.job) return;
   if (!HOK(jga_event_wait_sleeping(s.done))) s.job->status = EXIT_FAILURE;     // (usually over already)
-  else if (copy_back && s.job->host_out) memcpy(s.job->host_out, s.h_out, (size_t)s.out_bytes);
+  else if (copy_back && s.job->host_out && !(s.job->pinned & 2)) memcpy(s.job->host_out, s.h_out, (size_t)s.out_bytes);
   s.job = nullptr;
 }
 
@@ -231,8 +231,9 @@ void run_worker(jga_pipeline *pl, worker *w, jga_job *jobs, int n,
        != EXIT_SUCCESS) {
         return false;
       }
+      // (a destination the caller says is pinned takes the pixels straight from the device)
       if (copy_back && job->host_out
-       && !HOK(hipMemcpyAsync(s.h_out, dst, out_bytes, hipMemcpyDeviceToHost, w->stream))) {
+       && !HOK(hipMemcpyAsync((job->pinned & 2) ? job->host_out : s.h_out, dst, out_bytes, hipMemcpyDeviceToHost, w->stream))) {
         return false;
       }
       return HOK(hipEventRecord(s.done, w->stream));
@@ -328,7 +329,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   jga_huff_set_threads(l.hb, threads);
   {
     bool pinned = true;
-    for (int i = 0; i < m; i++) pinned = pinned && jobv[i]->pinned != 0;
+    for (int i = 0; i < m; i++) pinned = pinned && (jobv[i]->pinned & 1) != 0;
     const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && (pinned || pl->offload_cleanup));
     jga_huff_set_device_unstuff(l.hb, on_device);
     jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
@@ -404,7 +405,8 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     for (int i = 0; i < m; i++) {
       if (!jobv[i]->host_out) continue;
       const unsigned char *src = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
-      if (!HOK(hipMemcpyAsync(l.h_out + ostride*i, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return EXIT_FAILURE;
+      unsigned char *to = (jobv[i]->pinned & 2) ? jobv[i]->host_out : l.h_out + ostride*i;   // pinned destination: no staging
+      if (!HOK(hipMemcpyAsync(to, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return EXIT_FAILURE;
     }
   }
   if (!HOK(pl->blocking ? jga_stream_wait_sleeping(l.stream, l.done) : hipStreamSynchronize(l.stream))) {
@@ -427,7 +429,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     std::atomic<int> next(0);
     auto mover = [&]() {
       for (int i = next.fetch_add(1); i < m; i = next.fetch_add(1)) {
-        if (jobv[i]->host_out) memcpy(jobv[i]->host_out, l.h_out + ostride*i, (size_t)out_bytes);
+        if (jobv[i]->host_out && !(jobv[i]->pinned & 2)) memcpy(jobv[i]->host_out, l.h_out + ostride*i, (size_t)out_bytes);
       }
     };
     const int movers = threads < m ? (threads < 1 ? 1 : threads) : m;

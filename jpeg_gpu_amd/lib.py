@@ -388,9 +388,10 @@ class Pipeline:
         self.copy_back = copy_back
 
     @staticmethod
-    def make_jobs(jpegs, host_outs=None, dev_outs=None, pinned=False):
+    def make_jobs(jpegs, host_outs=None, dev_outs=None, pinned=False, outs_pinned=False):
         """The jga_job array for a run (built outside any timed region).  The returned object
-        keeps the input buffers alive."""
+        keeps the input buffers alive.  pinned: the files lie in pinned memory; outs_pinned: the
+        host_outs do (PinnedBytes / PinnedArray)."""
         n = len(jpegs)
         views = {}
         jobs = (abi.jga_job * n)()
@@ -403,7 +404,7 @@ class Pipeline:
             jobs[i].size = v.size
             jobs[i].host_out = host_outs[i].ctypes.data if host_outs is not None else None
             jobs[i].dev_out = dev_outs[i] if dev_outs is not None else None
-            jobs[i].pinned = int(pinned)
+            jobs[i].pinned = int(bool(pinned)) | (2 if outs_pinned and host_outs is not None else 0)
         jobs._keep = (list(views.values()), list(jpegs), host_outs)
         return jobs
 

@@ -340,6 +340,32 @@ def oracle_quant(orc, data):
     return orc.decode(data, oracle.QUANT)[1]
 
 
+@pytest.mark.parametrize("transport", [0, 1, 2])
+def test_pipeline_pinned_destinations(gpu, orc, synth, transport):
+    """copy_back into buffers the caller declares pinned (jga_job.pinned bit 1): the pixels are
+    DMA'd straight into them, no staging buffer, no host memcpy; pageable and pinned
+    destinations may be mixed in one run.  Same pixels."""
+    from jpeg_gpu_amd import abi
+    datas = [synth.synthetic_jpeg(320 + 16 * (i % 2), 200, ["420", "444", "grey"][i % 3], quality=70 + i,
+                                  seed=i, restart_interval=[0, -1][i % 2]) for i in range(12)]
+    want = [orc.decode_rgb(d)[1].reshape(-1) for d in datas]
+    pins = [gpu.PinnedBytes(bytes(w.size)) for w in want]
+    outs = [p.array if i % 3 else np.zeros(want[i].size, np.uint8) for i, p in enumerate(pins)]
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True,
+                      transport=transport, batch=4, depth=2)
+    try:
+        jobs = gpu.Pipeline.make_jobs(datas, host_outs=outs)
+        for i in range(len(datas)):
+            jobs[i].pinned = 2 if i % 3 else 0
+        assert pl.run_jobs(jobs) == 0
+        for i in range(len(datas)):
+            assert np.array_equal(outs[i], want[i]), (transport, i)
+    finally:
+        pl.close()
+        for p in pins:
+            p.free()
+
+
 @pytest.mark.parametrize("mode", ["pinned", "device", "host", "mixed"])
 def test_pipeline_unstuff_modes_and_pinned_inputs(gpu, orc, synth, mode):
     """transport 2 with the scan clean-up on the host, on the GPU, and — for jobs whose files lie
