@@ -402,12 +402,18 @@ def main():
         ", cgroup grants %.1f CPUs" % quota if quota else ""))
 
     # ---- headline: JPEG bytes in host RAM -> RGB8 in HBM, K batches of B images per rank ----
+    # The files lie in PINNED ingest buffers (jga_host_malloc_pinned: where a reader would put
+    # them): with cores to spare the host cleans the scans up exactly as it does
+    # for pageable files (same rate, measured below at every N); with few cores per GPU the
+    # library DMAs them where they lie and cleans up on the device (csrc/unstuff_kernels.hip).
+    pins = [lib.PinnedBytes(j) for j in jpegs]
     pl = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
                       copy_back=False, transport=2, batch=G, depth=args.lanes)
     cyc = lambda n, o=0: [jpegs[(o + i) % len(jpegs)] for i in range(n)]
-    setup_jobs = lib.Pipeline.make_jobs(cyc(args.lanes * G))          # lanes allocate their buffers
-    warm_jobs = lib.Pipeline.make_jobs(cyc(Wm * B, 7)) if Wm > 0 else None
-    timed_jobs = lib.Pipeline.make_jobs(cyc(K * B, 13))
+    pcyc = lambda n, o=0: [pins[(o + i) % len(pins)].array for i in range(n)]
+    setup_jobs = lib.Pipeline.make_jobs(pcyc(args.lanes * G), pinned=True)   # lanes allocate their buffers
+    warm_jobs = lib.Pipeline.make_jobs(pcyc(Wm * B, 7), pinned=True) if Wm > 0 else None
+    timed_jobs = lib.Pipeline.make_jobs(pcyc(K * B, 13), pinned=True)
     if pl.run_jobs(setup_jobs) != 0:
         raise SystemExit("bench.py: pipeline failed: " + lib.L.jga_last_error().decode())
     if warm_jobs is not None:
@@ -429,7 +435,7 @@ def main():
         import oracle
         orc = oracle.Oracle()
         bufs = [lib.DeviceBuffer(g.rgb_bytes) for _ in range(2)]
-        chk = lib.Pipeline.make_jobs(cyc(2, 5), dev_outs=[b.ptr for b in bufs])
+        chk = lib.Pipeline.make_jobs(pcyc(2, 5), dev_outs=[b.ptr for b in bufs], pinned=True)
         ok = pl.run_jobs(chk) == 0
         for i, b in enumerate(bufs):
             want = orc.decode_rgb(jpegs[(5 + i) % len(jpegs)])[1].reshape(-1)
@@ -439,42 +445,50 @@ def main():
             raise SystemExit("bench.py: pipeline output differs from the oracle")
     pl.close()
 
-    # ---- the same measurement with the files in PINNED host memory (ingest buffers allocated with
-    # jga_host_malloc_pinned): the scans are DMA'd straight out of them and cleaned
-    # up on the GPU, the host only parses marker segments — what matters when ranks outnumber
-    # the CPUs the container grants (profiles/r2_unstuff_by_cpus.txt)
-    pinned_leg = None
+    # ---- the same measurement with the files in ordinary PAGEABLE memory (Python bytes): the host
+    # (or, short of cores, the device) cleans the scans up out of a copy the host makes.  Equal to
+    # `value` where cores are plentiful; the difference is what pinned ingest buffers buy where
+    # they are not (profiles/r2_host_waits.txt).  Also two forced variants of the pinned run at
+    # N = 1, so that the line shows both clean-ups whatever `auto` chose.
+    pageable_leg = None
+    forced = {}
     if not args.no_e2e:
-        pins = [lib.PinnedBytes(j) for j in jpegs]
-        pcyc = lambda n, o=0: [pins[(o + i) % len(pins)].array for i in range(n)]
-        plp = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
-                           copy_back=False, transport=2, batch=G, depth=args.lanes)
-        plp.run_jobs(lib.Pipeline.make_jobs(pcyc(args.lanes * G), pinned=True))
-        if Wm > 0:
-            plp.run_jobs(lib.Pipeline.make_jobs(pcyc(Wm * B, 7), pinned=True))
-        pj = lib.Pipeline.make_jobs(pcyc(K * B, 13), pinned=True)
-        fence()
-        t0 = time.perf_counter()
-        rcp = plp.run_jobs(pj)
-        fence()
-        rp, _, tp = shard.aggregate_throughput(K * B * W * H, time.perf_counter() - t0,
-                                               dist if world > 1 else None, device=red_dev)
-        okp = rcp == 0
-        if rank == 0:                               # its pixels too, against the oracle
-            import oracle
-            buf = lib.DeviceBuffer(g.rgb_bytes)
-            okp = okp and plp.run_jobs(lib.Pipeline.make_jobs(pcyc(1, 9), dev_outs=[buf.ptr], pinned=True)) == 0
-            okp = okp and bool(np.array_equal(buf.download(g.rgb_bytes),
-                                              oracle.Oracle().decode_rgb(jpegs[9 % len(jpegs)])[1].reshape(-1)))
-            buf.free()
-        plp.close()
-        pinned_leg = {"value": round(rp / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * B,
-                      "ok": okp, "ms_per_step": round(tp / K * 1e3, 4),
-                      "note": "as `value`, but the files lie in pinned host memory: scans DMA'd in place, "
-                              "unstuffed on the GPU (csrc/unstuff_kernels.hip); aggregated over ranks"}
-        del pj
-        for p_ in pins:
-            p_.free()
+        def timed_run(jobs_of, **kw):
+            p_ = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
+                              copy_back=False, transport=2, batch=G, depth=args.lanes, **kw)
+            p_.run_jobs(jobs_of(args.lanes * G, 0))
+            if Wm > 0:
+                p_.run_jobs(jobs_of(Wm * B, 7))
+            jobs = jobs_of(K * B, 13)
+            fence()
+            t0 = time.perf_counter()
+            rc_ = p_.run_jobs(jobs)
+            fence()
+            r_, _, t_ = shard.aggregate_throughput(K * B * W * H, time.perf_counter() - t0,
+                                                   dist if world > 1 else None, device=red_dev)
+            ok_ = rc_ == 0
+            if rank == 0:                               # its pixels too, against the oracle
+                import oracle
+                buf = lib.DeviceBuffer(g.rgb_bytes)
+                one = jobs_of(1, 9)
+                one[0].dev_out = buf.ptr
+                ok_ = ok_ and p_.run_jobs(one) == 0
+                ok_ = ok_ and bool(np.array_equal(buf.download(g.rgb_bytes),
+                                                  oracle.Oracle().decode_rgb(jpegs[9 % len(jpegs)])[1].reshape(-1)))
+                buf.free()
+            p_.close()
+            return {"value": round(r_ / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * B,
+                    "ok": ok_, "ms_per_step": round(t_ / K * 1e3, 4)}
+        pageable_leg = timed_run(lambda n, o: lib.Pipeline.make_jobs(cyc(n, o)))
+        pageable_leg["note"] = ("as `value`, but the files are ordinary pageable buffers: the host copies "
+                                "every scan (cleaning it up on the way, or leaving that to the GPU when "
+                                "cores are few); aggregated over ranks")
+        if world == 1:
+            for name, mode in (("pinned_files_host_cleanup", 1), ("pinned_files_device_cleanup", 2)):
+                forced[name] = timed_run(lambda n, o: lib.Pipeline.make_jobs(pcyc(n, o), pinned=True),
+                                         unstuff=mode)
+    for p_ in pins:
+        p_.free()
     PB, B = B, args.kernel_batch       # from here on B = images per launch of the stand-alone kernel legs
 
     # ---- roofline: the fused kernel alone, coefficient planes resident in HBM ----
@@ -526,8 +540,9 @@ def main():
     # ---- the north-star transport at every N: host Huffman threads -> pinned hipMemcpyAsync ->
     # fused kernel (entropy.c on this rank's cores; 24.9 MB of planes per image over PCIe)
     e2e = {}
-    if pinned_leg:
-        e2e["pinned_ingest_buffers_to_rgb_hbm"] = pinned_leg
+    if pageable_leg:
+        e2e["pageable_files_to_rgb_hbm"] = pageable_leg
+    e2e.update(forced)
     if not args.no_e2e:
         # Huffman threads also block on their slot's event: ~3 per granted CPU measured best
         # (profiles/r2_t0_sweep.txt: 32-48 threads on a 16-CPU grant, fewer AND more are slower)
@@ -558,11 +573,16 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "3840x2160 4:2:0 q90 baseline JPEG files in host RAM -> RGB8 in HBM "
-                        "(end to end); step = one batch of %d images per GPU through the pipelined "
-                        "decoder: host marker parse + unstuffing into pinned memory, compressed "
-                        "bytes over PCIe, GPU Huffman decode + fused dequant/IDCT/upsample/RGB "
-                        "kernel; %d steps streamed through %d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
+            "workload": "3840x2160 4:2:0 q90 baseline JPEG files in host RAM (pinned ingest buffers) -> "
+                        "RGB8 in HBM (end to end); step = one batch of %d images per GPU through the "
+                        "pipelined decoder: host marker parse, scan clean-up (unstuffing) on the host "
+                        "into pinned memory - or, when the rank has 8 cores or fewer, on the GPU with "
+                        "the scans DMA'd where they lie - compressed bytes over PCIe, GPU Huffman "
+                        "decode + fused dequant/IDCT/upsample/RGB kernel; %d steps streamed through "
+                        "%d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
+            # (the library's rule, csrc/pipeline.cpp: the smaller of the CPU grant and nthreads)
+            "scan_cleanup": "device" if min(nthreads, my_cpus, int(quota) if quota else my_cpus)
+                            <= int(os.environ.get("JGA_PIPE_OFFLOAD_AT", "8")) else "host",
             "batch_per_gpu": PB, "pipeline_group": G, "distinct_images_per_gpu": len(jpegs),
             "images_timed_per_gpu": K * PB, "h2d_bytes_per_image": int(h2d_per_image),
             # what the link carries per GPU at this rate (it sustains ~56 GB/s from pinned memory,

@@ -343,11 +343,11 @@ typedef struct jga_pipeline_config {
                                 * frames fill a group to about the same pixel count (up to 16x
                                 * as many); jobs are grouped by geometry in arrival order */
   int unstuff;                 /* transport 2, where stuffing and RSTn markers are removed: 0 = auto (on
-                                * the GPU for groups whose jobs are all `pinned`, and for every group
-                                * when the host side has 8 cores or fewer to count on — the smaller of
-                                * the process's CPU grant and `nthreads`; else on the host: one core
-                                * unstuffs ~12 GB/s, as fast as it could copy), 1 = host,
-                                * 2 = GPU (jga_huff_set_device_unstuff) */
+                                * the GPU when the host side has 8 cores or fewer to count on — the
+                                * smaller of the process's CPU grant and `nthreads` — and then groups
+                                * whose jobs are all `pinned` are uploaded by DMA straight from the
+                                * callers' buffers; else on the host: one core unstuffs ~12 GB/s, as
+                                * fast as it could copy), 1 = host, 2 = GPU (jga_huff_set_device_unstuff) */
 } jga_pipeline_config;
 
 typedef struct jga_job {

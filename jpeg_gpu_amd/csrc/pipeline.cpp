@@ -88,10 +88,12 @@ struct jga_pipeline {
   // hold a core each, and a container may grant fewer cores than there are lanes: they poll and
   // sleep instead (host_wait.h; JGA_PIPE_SPIN=1 restores the spinning).
   int blocking = 1;
-  // cfg.unstuff = 0 (auto): the scan clean-up runs on the device for groups whose files are all
-  // pinned, and for any group when the host is short of cores — with 4 CPUs the device
-  // clean-up of pageable files runs 100 Gpixel/s against 80 (2 CPUs: 84 / 67; 16 CPUs: equal,
-  // the device being the limit either way; profiles/r2_host_waits.txt)
+  // cfg.unstuff = 0 (auto): the scan clean-up runs on the device when the host is short of
+  // cores — with 4 CPUs the device clean-up of pageable files runs 100 Gpixel/s against 80, of
+  // pinned files (DMA'd where they lie) 124; 2 CPUs: 84 / 67 / 114 — and on the host when it is
+  // not: there the device is the limit, and the extra kernels cost it 5-10 % (16 CPUs: 138 from
+  // pageable or pinned files with the host clean-up, 124-129 with the device's;
+  // profiles/r2_host_waits.txt)
   bool offload_cleanup = false;
 };
 
@@ -330,7 +332,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   {
     bool pinned = true;
     for (int i = 0; i < m; i++) pinned = pinned && (jobv[i]->pinned & 1) != 0;
-    const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && (pinned || pl->offload_cleanup));
+    const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pl->offload_cleanup);
     jga_huff_set_device_unstuff(l.hb, on_device);
     jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);

@@ -113,7 +113,7 @@ def test_two_ranks_started_by_bench_itself(gpu):
     assert abs(d["value"] - 2 * 8 * 3840 * 2160 / (d["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.01 * d["value"]
     assert "cpu_baseline" not in d                                 # N = 1 only
     e = d["e2e"]
-    assert e["north_star_host_huffman_to_rgb_hbm"]["ok"] and e["pinned_ingest_buffers_to_rgb_hbm"]["ok"]
+    assert e["north_star_host_huffman_to_rgb_hbm"]["ok"] and e["pageable_files_to_rgb_hbm"]["ok"]
     pin = d["config"]["cpu_pinning"]
     assert pin and 1 <= pin["cpus"] <= len(os.sched_getaffinity(0))
 

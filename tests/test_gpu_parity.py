@@ -370,8 +370,9 @@ def test_pipeline_pinned_destinations(gpu, orc, synth, transport):
 def test_pipeline_unstuff_modes_and_pinned_inputs(gpu, orc, synth, mode):
     """transport 2 with the scan clean-up on the host, on the GPU, and — for jobs whose files lie
     in pinned memory — on the GPU with the scans DMA'd straight out of the callers' buffers
-    (no host copy); a group that mixes pinned and pageable files takes the host route.  Same
-    pixels every way, damaged member reported alone."""
+    (no host copy; with four host threads `auto` means the device); a group that mixes pinned
+    and pageable files has its scans copied by the host.  Same pixels every way, damaged member
+    reported alone."""
     from jpeg_gpu_amd import abi
     datas = [synth.synthetic_jpeg(640, 360, "420", quality=60 + i, seed=i, restart_interval=(i % 3) * 20)
              for i in range(20)]
