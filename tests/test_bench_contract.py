@@ -76,7 +76,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert d["metric"].startswith("Mpixel/s end-to-end decode, 4K 4:2:0 baseline JPEG")
     cfg = d["config"]
-    assert "host RAM -> RGB8 in HBM" in cfg["workload"] and "model" not in cfg
+    assert "host RAM" in cfg["workload"] and "-> RGB8 in HBM" in cfg["workload"] and "model" not in cfg
+    assert cfg["scan_cleanup"] in ("host", "device")
     assert cfg["bit_exact_vs_oracle"] is True and cfg["images_timed_per_gpu"] == 8
     # value = pixels of the timed region / its wall time
     assert abs(d["value"] - 8 * 3840 * 2160 / (d["ms_per_step"] * 2 * 1e-3) / 1e6) < 0.01 * d["value"]
