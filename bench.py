@@ -75,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-other", action="store_true", help="skip the other-kernels leg")
     ap.add_argument("--no-gpu-entropy", action="store_true", help="skip the device-only breakdown leg")
     ap.add_argument("--prewarm", type=float, default=0.5,
-                    help="seconds of untimed kernel launches before the roofline leg (clock ramp)")
+                    help="seconds of untimed work before the headline and before the roofline leg (clock ramp)")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launches timed in the roofline leg")
     ap.add_argument("--cpu-rounds", type=int, default=5, help="cpu_baseline: best of this many rounds")
     ap.add_argument("--cpu-frames", type=int, default=6, help="cpu_baseline: frames per core per round")
@@ -416,6 +416,9 @@ def main():
     timed_jobs = lib.Pipeline.make_jobs(pcyc(K * B, 13), pinned=True)
     if pl.run_jobs(setup_jobs) != 0:
         raise SystemExit("bench.py: pipeline failed: " + lib.L.jga_last_error().decode())
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm:                # clocks settle (a cold GPU reads
+        pl.run_jobs(setup_jobs)                                      # ~4 % low: the same pipeline run later in this process did)
     if warm_jobs is not None:
         pl.run_jobs(warm_jobs)                                       # W untimed steps
     fence()
