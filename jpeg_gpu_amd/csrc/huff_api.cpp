@@ -97,7 +97,8 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   b->max_images = max_images;
   b->max_scan = max_scan_bytes;
   // (grow_batch covers streams cut into very many restart intervals)
-  b->sub_cap = (size_t)(max_scan_bytes >> hj_choose_sub_log2((uint64_t)max_scan_bytes)) + (size_t)max_images*4096 + 1024;
+  // (sized for the shortest subsequences a batch of this capacity can be given)
+  b->sub_cap = (size_t)(max_scan_bytes >> hj_choose_sub_log2((uint64_t)max_scan_bytes, 1)) + (size_t)max_images*4096 + 1024;
   if (const char *e = getenv("JGA_HUFF_SUB")) {               // tuning knob / tests: 32, 64 or 128
     const int v = atoi(e);
     b->force_sub_log2 = v == 32 ? 5 : v == 64 ? 6 : v == 128 ? 7 : v == 256 ? 8 : v == 512 ? 9 : 0;
@@ -243,7 +244,11 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
      "large) for the GPU entropy stage", irregular.load());
   }
   if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
-  b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(0);
+  {
+    uint64_t raw_total = 0;
+    for (int i = 0; i < n; i++) raw_total += prep[i].avail;
+    b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(raw_total, prep[0].im.nslots);
+  }
   std::vector<hj_unstuff_image> uimg((size_t)n);
   std::vector<uint32_t> sub0v((size_t)n), seg0v((size_t)n);
   size_t o = 0, total_sub = 0, total_seg = 0, total_chunks = 0;
@@ -414,7 +419,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       }
       if ((long long)o > b->max_scan + 64ll*n || o >= ((size_t)1 << 32)) fatal.store(2);   // (hj_image::scan_off is 32 bits)
       // subsequence length of this batch (the stuffed length is close enough to the clean one)
-      b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o);
+      b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o, prep[0].im.nslots);
       for (int i = 0; i < n; i++) prep[i].sub_log2 = b->sub_log2;
       b->off_scan = 0;
       b->scan_bytes = align_up(o, 256);

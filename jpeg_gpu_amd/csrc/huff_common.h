@@ -104,17 +104,20 @@ struct hj_segment {                  // one restart interval (or the whole scan)
   uint32_t nmcu;
 };
 
-// Subsequence length of a batch.  128 bytes unless JGA_HUFF_SUB says otherwise: measured on
-// MI355X, shorter subsequences do NOT make a small batch decode sooner.  What a single image
-// waits for is the serial distance a run needs to fall into step with the true symbol
-// sequence — for 4:2:0 ~1-1.5 KB, because the MCU slot has to line up as well as bit and
-// block boundaries — and that distance costs the same time whether it is walked as 12 runs
-// of 128 bytes or 48 of 32, while every hand-over adds its own overhead (1080p 4:2:0: 0.85 ms
-// at 128 B, 0.87 at 64 B, 1.09 at 32 B; 8 x 4K: 1.13 / 1.36 / 2.25 ms; only a lone 4:4:4
-// frame gains, 0.45 -> 0.39 ms at 64 B).
-HJ_HD int hj_choose_sub_log2(uint64_t scan_bytes) {
-  (void)scan_bytes;
-  return HJ_SUB_LOG2_MAX;
+// Subsequence length of a batch (JGA_HUFF_SUB overrides).  128 bytes, except for a small batch of
+// frames without subsampling.  What a lone frame waits for is the serial distance its
+// unluckiest run needs to fall into step with the true symbol sequence: for 4:2:0 ~1-1.5 KB,
+// because the MCU slot has to line up as well as bit and block boundaries, and that distance
+// costs the same time whether it is walked as 12 runs of 128 bytes or 48 of 32, while every
+// hand-over adds its own overhead — 1080p 4:2:0: 0.68 ms at 128 B, 0.80 at 64 B; one 4K frame:
+// 0.75 / 0.88 / 1.18 ms at 128 / 64 / 32 B.  Grey and 4:4:4 streams fall into step within a
+// few dozen bytes (97-99 % of the runs inside 128 B), so there the shorter runs win as long as
+// the GPU has lanes to spare: one 4K 4:4:4 frame 0.40 -> 0.33 ms, one grey 4K 0.44 -> 0.37, one
+// 1080p 4:4:4 0.40 -> 0.30; four 4K 4:4:4 frames are back at 0.50 vs 0.54
+// (profiles/r2_sub_size_lone_frames.txt).
+#define HJ_SMALL_BATCH_BYTES (8u << 20)
+HJ_HD int hj_choose_sub_log2(uint64_t scan_bytes, int nslots) {
+  return (nslots <= 3 && scan_bytes <= HJ_SMALL_BATCH_BYTES) ? HJ_SUB_LOG2_MAX - 1 : HJ_SUB_LOG2_MAX;
 }
 
 // state word: p (bit position inside the image's clean scan) << 16 | c << 8 | k
