@@ -678,6 +678,43 @@ def main():
             "d2h_GBps": round(n * g.rgb_bytes / te / 1e9, 1), "host_threads": nthreads}
         for p_ in pouts:
             p_.free()
+        # ... and on lighter content than the recipe's (N(0, 12) noise costs 3 bits per pixel): a
+        # smooth image with fine grain, q90, 0.6 bits per pixel; same pipeline
+        def photo_like(i):
+            r = np.random.default_rng(900 + i)
+            xx = np.linspace(0, 1, W, dtype=np.float32)[None, :, None]
+            yy = np.linspace(0, 1, H, dtype=np.float32)[:, None, None]
+            cc = np.arange(3, dtype=np.float32)[None, None, :]
+            img = 128 + 60 * np.sin((6 + i) * xx * (cc + 1)) * np.cos(4 * yy) + r.normal(0, 2, (H, W, 3)).astype(np.float32)
+            return synth.encode_pixels(np.clip(img, 0, 255).astype(np.uint8), SAMPLING, QUALITY)
+        with ThreadPoolExecutor(max_workers=max(1, min(8, my_cpus))) as ex:
+            light = list(ex.map(photo_like, range(8)))
+        p4 = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False,
+                          transport=2, batch=G, depth=args.lanes)
+        lj = lambda n, o=0: lib.Pipeline.make_jobs([light[(o + i) % len(light)] for i in range(n)])
+        p4.run_jobs(lj(args.lanes * G))
+        p4.run_jobs(lj(8 * B, 3))
+        jr = lj(K * B, 5)
+        fence()
+        t0 = time.perf_counter()
+        rc4 = p4.run_jobs(jr)
+        fence()
+        te = time.perf_counter() - t0
+        buf = lib.DeviceBuffer(g.rgb_bytes)
+        one = lj(1, 2)
+        one[0].dev_out = buf.ptr
+        import oracle
+        ok4 = rc4 == 0 and p4.run_jobs(one) == 0 and bool(np.array_equal(
+            buf.download(g.rgb_bytes), oracle.Oracle().decode_rgb(light[2 % len(light)])[1].reshape(-1)))
+        buf.free()
+        p4.close()
+        e2e["lighter_content_to_rgb_hbm"] = {
+            "value": round(K * B * W * H / te / 1e6, 1), "unit": "Mpixel/s", "images": K * B, "ok": ok4,
+            "bytes_per_pixel": round(sum(map(len, light)) / len(light) / (W * H), 3),
+            "h2d_GBps": round(sum(j.h2d_bytes for j in jr) / te / 1e9, 1),
+            "note": "as `value` on a smooth image with fine grain (sigma 2) instead of the recipe's "
+                    "sigma-12 noise, same size / sampling / quality: the link has room there and the "
+                    "rate follows the device's entropy + block-decode time"}
         e2e["note"] = "all PCIe- and host-inclusive; *_to_rgb_host also copies the pixels back into " \
                       "the callers' host buffers (the plugin's decode_image semantics), " \
                       "*_to_rgb_pinned_host into buffers the caller pinned (no host memcpy)"
