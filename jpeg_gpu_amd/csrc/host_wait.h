@@ -7,11 +7,13 @@
  * latency; wrong for a pipeline whose lanes wait several milliseconds per group on a host
  * that grants fewer cores than lanes (a lane burnt ~6 ms of CPU per group of 32 frames
  * doing nothing).  So the throughput paths poll the event and sleep in between: a few
- * queries back to back (many waits are over within tens of microseconds), then naps that
- * grow from 20 to 200 us.  Costs at most one nap of latency per wait. */
+ * queries back to back (many waits are over within tens of microseconds), then naps of 20 to
+ * 40 us (each ~50 us longer in practice: timer slack; longer naps measured 2 % slower and no
+ * cheaper, JGA_WAIT_NAP_US).  Costs at most one nap of latency per wait. */
 #ifndef JGA_HOST_WAIT_H
 #define JGA_HOST_WAIT_H (1)
 #include <hip/hip_runtime_api.h>
+#include <stdlib.h>
 #include <time.h>
 
 static inline hipError_t jga_event_wait_sleeping(hipEvent_t ev) {
@@ -20,13 +22,14 @@ static inline hipError_t jga_event_wait_sleeping(hipEvent_t ev) {
     e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
   }
+  static const long nap_cap = getenv("JGA_WAIT_NAP_US") ? atol(getenv("JGA_WAIT_NAP_US"))*1000 : 40000;   // tuning knob
   long nap_ns = 20000;
   for (;;) {
     timespec ts = {0, nap_ns};
     nanosleep(&ts, NULL);
     e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
-    if (nap_ns < 200000) nap_ns += nap_ns/2;
+    if (nap_ns < nap_cap) nap_ns += nap_ns/2;
   }
 }
 
