@@ -27,6 +27,7 @@
 #include <string.h>
 #include <thread>
 #include <time.h>
+#include <sys/prctl.h>
 #include <unordered_map>
 #include <vector>
 #include "jga_internal.h"
@@ -476,6 +477,9 @@ uint64_t geometry_key(const unsigned char *p, int size) {
 void run_lane(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *groups,
  std::atomic<int> *next, int threads) {
   if (!HOK(hipSetDevice(pl->cfg.device))) return;
+  // the naps of host_wait.h are tens of microseconds: the default 50 us of timer slack would
+  // more than double them
+  if (!getenv("JGA_PIPE_KEEP_TIMERSLACK")) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL);
   for (;;) {
     const int gi = next->fetch_add(1);
     if (gi >= (int)groups->size()) break;
