@@ -222,6 +222,9 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     if (nt > 64) nt = 64;
   }
   if (nt > n) nt = n;
+  // files that stay where they are leave ~10 us of host work per image (marker parse, tables):
+  // starting and joining a thread team costs more than it saves until the batch is large
+  if (b->inputs_pinned && n <= 128) nt = 1;
   b->qtab.assign((size_t)n*192, 0);
   b->verdict.assign((size_t)n, 0);
   b->nimages = 0;
