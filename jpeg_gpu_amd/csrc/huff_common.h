@@ -243,6 +243,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
     // only taken whole if all of it lies before the stop
     const bool packed = HJ_P_BITS(e) != 0 && k + HJ_P_PREFIX(e) < 64 && br.room9();
     br.skip(packed ? HJ_P_BITS(e) : HJ_E_TOT(e));
+#ifndef HJ_EXP_NODC                                       /* timing probe: what the DC sums cost the rounds */
     if (!LITE && isdc) {                                   // DC difference, extended
       const int s = HJ_E_S(e), len = HJ_E_TOT(e) - s;
       const int v = hj_value(w, len, s);
@@ -250,6 +251,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
       dc1 += comp == 1 ? v : 0;
       dc2 += comp == 2 ? v : 0;
     }
+#endif
     const int kn = k + (packed ? HJ_P_ADV(e) : HJ_E_ADV(e));   // DC: 1; AC: past the run(s); EOB: >= 64
     const int done = kn >= 64;
     if (!LITE) nblocks += (uint32_t)done;

@@ -625,6 +625,45 @@ struct hj_block_out {
     }
     if (waiting) next_block(slot);
   }
+  // Every lane of the wave calls this together: the blocks of the lanes with `have` leave their
+  // buffers.  A block that is `partial` (shared with a neighbouring lane: begun before this run,
+  // or unfinished at its end) leaves as 2-byte stores of its non-zeros onto the pre-zeroed planes
+  // (disjoint positions: the lanes need no ordering between them), a whole one as a 128-byte
+  // line; either way 8 lanes handle one block, 16 bytes each, and the buffers are zero afterwards.
+  __device__ __forceinline__ void flush_blocks(bool have, bool partial, bool complete, int slot) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long mask = __ballot(have);
+    if (mask == 0ull) return;
+    if (have) {
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      rank_lane[r] = (uint8_t)lane;
+      blk[32] = offset(slot)*2u | (partial ? 1u : 0u);       // (byte offsets of blocks are multiples of 128)
+    }
+    const bool pieces = __ballot(have && partial) != 0ull;
+    const uint32_t cnt = (uint32_t)__popcll(mask), part = lane & 7u;
+    typedef __attribute__((address_space(1))) hj_v4u global_v4u;
+    for (uint32_t k = lane >> 3; k < cnt; k += 8) {
+      uint32_t *src = wave_blk + (uint32_t)rank_lane[k]*HJ_BLK_STRIDE;
+      const uint32_t off = src[32];
+      hj_v4u v;
+      v.x = src[4*part]; v.y = src[4*part + 1]; v.z = src[4*part + 2]; v.w = src[4*part + 3];
+      src[4*part] = 0; src[4*part + 1] = 0; src[4*part + 2] = 0; src[4*part + 3] = 0;
+      if (!pieces || !(off & 1u)) {
+        __builtin_nontemporal_store(v, (global_v4u *)((uintptr_t)coef + (off & ~1u)) + part);
+      }
+      else {
+        int16_t *dst = reinterpret_cast<int16_t *>((uintptr_t)coef + (off & ~1u)) + 8*part;
+        const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (d4[q] & 0xffffu) dst[2*q] = (int16_t)(d4[q] & 0xffffu);
+          if (d4[q] >> 16) dst[2*q + 1] = (int16_t)(d4[q] >> 16);
+        }
+      }
+    }
+    if (have && complete) next_block(slot);                 // on to the next block's place
+  }
   __device__ __forceinline__ void flush_partial(int slot, bool) { scatter(slot); }
 };
 
@@ -690,6 +729,182 @@ __global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(c
   if (err) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 
+// ---- the write pass, second edition (round 3) --------------------------------------------------
+// Same job, same block buffers and the same wave-collective write-out as hj_write<true>, with the
+// per-symbol path rebuilt around what the counters said about the first one (54 scalar + 16
+// branch instructions per 100 vector ones: exec-mask bookkeeping of a loop in which every "rare"
+// case is taken by some lane of the wave on nearly every trip):
+//   * the tables are re-encoded while they are staged (hj_wtables): DC and AC entries are both
+//     32 bits wide, so a symbol's lookup is ONE ds_read_b32 from a table base selected by k == 0;
+//     an EOB advances 127, so that "k + adv has bit 7 set" means EOB and "64 < (k + adv) & 127"
+//     means an AC run past coefficient 63; bit 16 marks bit patterns that are no code.  The
+//     error tests become an OR and a MAX per symbol, looked at once after the run;
+//   * the magnitude is cut out with v_bfe_u32 / v_bfe_i32 (width 0 gives 0: no "s == 0" case);
+//   * only the CURRENT component's DC predictor is updated per symbol (a select), the three
+//     predictors are swapped when the slot changes, i.e. at a write-out;
+//   * every symbol stores its value: the de-zigzag table is extended so that the positions an
+//     EOB / a bad run computes (>= 64) land in the spare half-dword behind the block buffer, and a
+//     ZRL stores a zero where a zero is — no "is there a value" branch;
+//   * pieces of blocks shared with a neighbouring lane ride the same collective write-out as
+//     whole blocks (8 lanes per block, 16 bytes each) with 2-byte stores of their non-zeros,
+//     instead of a 32-dword serial loop per lane that every lane of the wave sat through.
+// What is left under a branch: the level-2 lookup of codes longer than 9 bits and the scan
+// dword refill.
+struct hj_wtables {
+  uint32_t dc[2][1 << HJ_FAST_BITS];
+  uint32_t ac[2][1 << HJ_FAST_BITS];
+  uint16_t l2[HJ_L2_BLOCKS*128];
+};
+#define HJ_W_NOCODE 0x10000u
+static __device__ __forceinline__ uint32_t hj_wentry(uint32_t e) {      // e: a 16-bit hj_tables entry
+  if (HJ_IS_ESCAPE(e)) return e;
+  if (HJ_E_ADV(e) == 64) e |= 127u << 5;                                 // EOB: 64 -> 127
+  if (HJ_E_LEN(e) > 16) e |= HJ_W_NOCODE;
+  return e;
+}
+#ifndef HJ_WRITE2_UNROLL
+#define HJ_WRITE2_UNROLL 4
+#endif
+#define HJ_DEZZ_EXT 192              /* k + adv - 1 <= 63 + 127 */
+
+__global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
+  constexpr int NB = HJ_WRITE_BLOCK;
+  __shared__ __attribute__((aligned(16))) hj_wtables lds_tabs;
+  __shared__ uint32_t lds_blk[NB*HJ_BLK_STRIDE];
+  __shared__ hj_image s_im;
+  __shared__ uint32_t s_dezz[HJ_DEZZ_EXT];           // BYTE offset of zig-zag position i in a block buffer (dwords: the
+                                                     // loaded value is used as it comes, a symbol later)
+  __shared__ uint8_t s_rank[NB];
+  const hj_image im0 = A.images[blockIdx.y];
+  if (blockIdx.x*NB >= im0.nsub) return;              // grid.x covers the largest image
+  hj_stage_image(&s_im, A.images + blockIdx.y);
+  if (threadIdx.x < HJ_DEZZ_EXT) s_dezz[threadIdx.x] = threadIdx.x < 64 ? 2u*HJ_DEZZ[threadIdx.x] : 128u;
+  {
+    const hj_tables *T = A.tables + blockIdx.y;
+    for (int i = threadIdx.x; i < 2 << HJ_FAST_BITS; i += NB) {
+      (&lds_tabs.dc[0][0])[i] = hj_wentry((&T->dc[0][0])[i]);
+      (&lds_tabs.ac[0][0])[i] = hj_wentry((&T->ac[0][0])[i] & 0xffffu);
+    }
+    for (int i = threadIdx.x; i < HJ_L2_BLOCKS*128; i += NB) {
+      const uint32_t e = T->l2[i];
+      lds_tabs.l2[i] = (uint16_t)(HJ_E_ADV(e) == 64 ? e | (127u << 5) : e);     // (no-code is tested when read)
+    }
+  }
+  // lane context (as hj_prologue, without its staging)
+  const uint32_t li = blockIdx.x*NB + threadIdx.x;
+  const bool on = li < im0.nsub;
+  uint32_t g = 0, si = 0, i_in_seg = 0, seg_end = 0, seg_nsub = 0, seg_mcu0 = 0, seg_nmcu = 0, my_start = 0;
+  if (on) {
+    g = im0.sub0 + li;
+    si = A.sub_seg[g];
+    const hj_segment sg = A.segs[im0.seg0 + si];
+    i_in_seg = li - sg.sub0;
+    seg_end = sg.end; seg_nsub = sg.nsub; seg_mcu0 = sg.mcu0; seg_nmcu = sg.nmcu;
+    my_start = sg.start + (i_in_seg << A.sub_log2);
+  }
+  uint32_t *blk = lds_blk + threadIdx.x*HJ_BLK_STRIDE;
+#pragma unroll
+  for (int q = 0; q < 32; q++) blk[q] = 0;                  // own buffer only
+  __syncthreads();                                           // tables, s_im, s_dezz
+  const hj_image &im = s_im;
+  const uint32_t total = seg_nmcu*(uint32_t)im.nslots;
+  const uint32_t b0 = on ? A.B[g] : 0u;
+  const bool live = on && b0 < total;
+  const uint32_t sidx = g + im.seg0 + si;
+  const uint64_t start = live ? A.S[sidx] : 0ull;
+  const uint64_t stop = !live ? 0ull : i_in_seg + 1 < seg_nsub ? hj_pos(A.S[sidx + 1]) : (uint64_t)seg_end*8;
+  hj_block_out out;
+  out.im = &im;
+  out.coef = A.coef + (long long)blockIdx.y*A.coef_stride;
+  out.blk = blk;
+  out.wave_blk = lds_blk + (threadIdx.x & ~63u)*HJ_BLK_STRIDE;
+  out.rank_lane = s_rank + (threadIdx.x & ~63u);
+  out.init(seg_mcu0 + b0/(uint32_t)im.nslots);
+  out.flush_lanes = A.flush_lanes;
+  const uint32_t max_blocks = live ? total - b0 : 0u;
+  int p0 = live ? A.D[3*g + 0] : 0, p1 = live ? A.D[3*g + 1] : 0, p2 = live ? A.D[3*g + 2] : 0;
+
+  uint32_t slot_comp_bits = 0, slot_tbl_bits = 0;
+  for (int q = 0; q < im.nslots; q++) {
+    slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+    slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
+  }
+  const int nslots = im.nslots;
+  hj_gmem_src gsrc;
+  gsrc.scan32 = reinterpret_cast<const uint32_t *>(A.scan + im0.scan_off);
+  gsrc.dw0 = my_start >> 2;
+  gsrc.ndw = ((im0.scan_len + 16 + 15) & ~15u) >> 2;
+  hj_gmem_src::reader br;
+  br.init(gsrc, hj_pos(start), stop);
+  int k = hj_k(start), c = hj_slot(start);
+  bool head = k == 0, waiting = false;
+  uint32_t n = 0, errbits = 0;
+  int errm = 0;
+  int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+  int tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
+  int predc = comp == 0 ? p0 : comp == 1 ? p1 : p2;
+  const uint32_t *tb_dc = lds_tabs.dc[tbl & 1], *tb_ac = lds_tabs.ac[tbl >> 1];
+  uint8_t *blk8 = reinterpret_cast<uint8_t *>(blk);
+  uint32_t pz = 128;
+  int pv = 0;
+  for (;;) {
+    bool running = !waiting && br.before_stop() && n < max_blocks;
+    if (!out.any(running || waiting)) break;
+#pragma unroll
+    for (int u = 0; u < HJ_WRITE2_UNROLL; u++) {
+      if (u) running = !waiting && br.before_stop() && n < max_blocks;
+      if (!running) continue;
+      const uint32_t w = br.window();
+      const bool isdc = k == 0;
+      const uint32_t *tb = isdc ? tb_dc : tb_ac;
+      uint32_t e = tb[w >> (32 - HJ_FAST_BITS)];
+      if ((e & 31u) == 0u) {                                 // a code longer than 9 bits
+        e = lds_tabs.l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+        if (HJ_E_LEN(e) > 16) e |= HJ_W_NOCODE;
+      }
+      const uint32_t tot = e & 31u, s = (e >> 12) & 15u;
+      const uint32_t off = 32u - tot;
+      const int vu = (int)__builtin_amdgcn_ubfe(w, off, s);
+      const int vs = __builtin_amdgcn_sbfe((int)w, off, s);  // < 0 iff the top magnitude bit is set (value >= 0)
+      int v = vu - (vs < 0 ? 0 : (int)((1u << s) - 1u));     // T.81 F.2.2.1 EXTEND; s = 0 gives 0
+      const int pn = predc + v;
+      predc = isdc ? pn : predc;
+      v = isdc ? (int)(int16_t)pn : v;                       // wraps like xjpeg.c:480
+      const int kn = k + (int)((e >> 5) & 127u);             // one past this coefficient's zig-zag index
+      // The value is stored one symbol LATE: its de-zigzagged position is asked for here and
+      // used after the next symbol's table entry has been asked for, so that a symbol costs the
+      // wave one LDS round trip, not two in a row.
+      *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;
+      pz = s_dezz[kn - 1];                                   // (>= 64: the spare half-dword)
+      pv = v;
+      errbits |= e;
+      errm = max(errm, kn & 127);
+      br.skip((int)tot);
+      waiting = kn >= 64;
+      k = waiting ? 0 : kn;
+    }
+    *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;     // the store still owed
+    pz = 128;
+    if (out.flush_due(waiting, running && !waiting)) {
+      out.flush_blocks(waiting, !head, true, c);
+      if (waiting) {
+        n++;
+        p0 = comp == 0 ? predc : p0; p1 = comp == 1 ? predc : p1; p2 = comp == 2 ? predc : p2;
+        c = c + 1 == nslots ? 0 : c + 1;
+        comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+        tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
+        predc = comp == 0 ? p0 : comp == 1 ? p1 : p2;
+        tb_dc = lds_tabs.dc[tbl & 1]; tb_ac = lds_tabs.ac[tbl >> 1];
+        head = true;
+        waiting = false;
+      }
+    }
+  }
+  // blocks left unfinished (a later lane holds the rest): their coefficients so far
+  out.flush_blocks(k != 0 && n < max_blocks, true, false, c);
+  if ((errbits & HJ_W_NOCODE) || errm > 64) atomicOr(&A.errors[blockIdx.y], 2u);
+}
+
 // Start states, segment numbers and "never ran" marks of every subsequence, written on the device instead of
 // uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
 // (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
@@ -747,9 +962,11 @@ extern "C" size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs) {
   return 16*(total_segs + (total_subs >> HJ_SCAN_CHUNK_LOG2) + 2);
 }
 extern "C" int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream) {
+  static const bool first_edition = getenv("JGA_HUFF_WRITE2") && atoi(getenv("JGA_HUFF_WRITE2")) == 0;   // (A/B knob)
   if (gmem) {
     dim3 grid((max_nsub + HJ_WRITE_BLOCK - 1)/HJ_WRITE_BLOCK, A->nimages);
-    hipLaunchKernelGGL(hj_write<true>, grid, dim3(HJ_WRITE_BLOCK), 0, (hipStream_t)stream, *A);
+    if (first_edition) hipLaunchKernelGGL(hj_write<true>, grid, dim3(HJ_WRITE_BLOCK), 0, (hipStream_t)stream, *A);
+    else hipLaunchKernelGGL(hj_write2, grid, dim3(HJ_WRITE_BLOCK), 0, (hipStream_t)stream, *A);
   }
   else {
     dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
