@@ -31,6 +31,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>   /* (memset in jga_pipeline_config_init) */
 
 #ifdef __cplusplus
 extern "C" {
@@ -327,6 +328,10 @@ int jga_time_idct_batch(const jga_geom *g, int nimages, const short *d_coef,
 typedef struct jga_pipeline jga_pipeline;
 
 typedef struct jga_pipeline_config {
+  int struct_size;             /* sizeof(jga_pipeline_config) and sizeof(jga_job) of the header the CALLER was */
+  int job_size;                /* built against (jga_pipeline_config_init fills them in): jga_pipeline_create
+                                * turns a caller from another revision away instead of walking its job
+                                * array with the wrong stride */
   int device;                  /* HIP device ordinal */
   int nthreads;                /* host entropy threads (0 = hardware default) */
   int depth;                   /* transport 2: lanes (groups in flight), 0 = 6.  Transports 0/1
@@ -364,6 +369,10 @@ typedef struct jga_job {
                                 * buffer, no host memcpy) — jga_host_malloc_pinned / jga_host_register */
 } jga_job;
 
+/* Zero the configuration (every 0 is a documented default) and stamp it with this header's
+ * struct sizes.  A macro on purpose: it must expand in the CALLER's translation unit. */
+#define jga_pipeline_config_init(cfg) do { memset((cfg), 0, sizeof(jga_pipeline_config)); \
+  (cfg)->struct_size = (int)sizeof(jga_pipeline_config); (cfg)->job_size = (int)sizeof(jga_job); } while (0)
 jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);
 /* Decode jobs[0..n) ; returns when all are complete (outputs valid). */
 int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);

@@ -79,7 +79,8 @@ class jga_geom(C.Structure):
 
 
 class jga_pipeline_config(C.Structure):
-    _fields_ = [("device", C.c_int), ("nthreads", C.c_int), ("depth", C.c_int),
+    _fields_ = [("struct_size", C.c_int), ("job_size", C.c_int),
+                ("device", C.c_int), ("nthreads", C.c_int), ("depth", C.c_int),
                 ("out", C.c_int), ("copy_back", C.c_int),
                 ("max_coef_shorts", C.c_longlong), ("max_out_bytes", C.c_longlong),
                 ("transport", C.c_int), ("batch", C.c_int), ("unstuff", C.c_int)]

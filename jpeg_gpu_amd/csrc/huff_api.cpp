@@ -619,6 +619,10 @@ static hipError_t wait_stream(jga_huff_batch *b, hipStream_t st) {
 JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  void *stream) {
   hipStream_t st = (hipStream_t)stream;
+  // verdicts of an earlier decode must not outlive it: a launch failure below would otherwise
+  // be read as "some members were damaged" by callers that look at jga_huff_image_errors()
+  b->image_errors = 0;
+  for (int i = 0; i < b->max_images; i++) b->h_ran[HJ_MAX_ROUNDS + i] = 0;
   if (!b->nimages) return jga_fail("huff: nothing prepared");
   if (coef_stride < b->geom.coef_shorts) return jga_fail("huff: coef_stride too small");
   const int rc = decode_batch(b, d_coef, coef_stride, st);

@@ -160,7 +160,15 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
       for (int w = 0; w < 2 && !rc; w++) {
         const int id = w ? 4 + d->ta[c] : d->td[c];
         int slot_of = -1;
-        for (int q = 0; q < nslot[w]; q++) if (slot_id[w][q] == id) slot_of = q;
+        // (by CONTENT, not by id: an encoder that writes one DHT per component with the same
+        // bits + values under three ids still needs two slots, not three)
+        for (int q = 0; q < nslot[w]; q++) {
+          const int other = slot_id[w][q];
+          if (other == id || (memcmp(d->dht_bits[other], d->dht_bits[id], sizeof(d->dht_bits[id])) == 0
+           && memcmp(d->dht_vals[other], d->dht_vals[id], sizeof(d->dht_vals[id])) == 0)) {
+            slot_of = q;
+          }
+        }
         if (slot_of < 0) {
           if (nslot[w] >= 2) { rc = 2; break; }
           slot_of = nslot[w]++;

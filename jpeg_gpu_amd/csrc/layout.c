@@ -67,25 +67,87 @@ int jga_fail(const char *fmt, ...) {
 const char *jga_last_error(void) { return jga_err; }
 const char *jga_version(void) { return "jpeg_gpu_amd 0.1 (gfx950)"; }
 
+/* quota / period of one cgroup directory: cgroup v2 "cpu.max" ("quota period" or "max period"),
+ * v1 "cpu.cfs_quota_us" + "cpu.cfs_period_us" (-1 = unlimited).  Returns CPUs' worth of run time,
+ * 0 when the directory sets no limit or cannot be read. */
+static double cgroup_dir_quota(const char *dir) {
+  char path[512];
+  double quota = 0, period = 0;
+  FILE *f;
+  snprintf(path, sizeof(path), "%s/cpu.max", dir);
+  f = fopen(path, "r");
+  if (f) {
+    const int got = fscanf(f, "%lf %lf", &quota, &period);      /* "max ..." scans nothing */
+    fclose(f);
+    return (got == 2 && quota > 0 && period > 0) ? quota/period : 0.0;
+  }
+  snprintf(path, sizeof(path), "%s/cpu.cfs_quota_us", dir);
+  f = fopen(path, "r");
+  if (!f) return 0.0;
+  if (fscanf(f, "%lf", &quota) != 1) quota = 0;
+  fclose(f);
+  snprintf(path, sizeof(path), "%s/cpu.cfs_period_us", dir);
+  f = fopen(path, "r");
+  if (!f) return 0.0;
+  if (fscanf(f, "%lf", &period) != 1) period = 0;
+  fclose(f);
+  return (quota > 0 && period > 0) ? quota/period : 0.0;
+}
+
+/* The tightest CPU quota that applies to this process: its own cgroup (from /proc/self/cgroup:
+ * "0::/path" on v2, "N:cpu,cpuacct:/path" on v1) and every ancestor up to the mount point —
+ * a limit anywhere on the way up binds.  0 = none found. */
+static double cgroup_cpu_quota(void) {
+  static const char *roots[2] = {"/sys/fs/cgroup", "/sys/fs/cgroup/cpu"};
+  char line[512], rel[2][400] = {"", ""};
+  double best = 0.0;
+  int k;
+  FILE *f = fopen("/proc/self/cgroup", "r");
+  if (f) {
+    while (fgets(line, sizeof(line), f)) {
+      char *c1 = strchr(line, ':'), *c2 = c1 ? strchr(c1 + 1, ':') : NULL, *nl;
+      if (!c2) continue;
+      nl = strchr(c2, '\n');
+      if (nl) *nl = 0;
+      *c2 = 0;
+      if (c1[1] == 0) snprintf(rel[0], sizeof(rel[0]), "%s", c2 + 1);                    /* v2: "0::/path" */
+      else if (strstr(c1 + 1, "cpu") && !strstr(c1 + 1, "cpuset")) snprintf(rel[1], sizeof(rel[1]), "%s", c2 + 1);
+    }
+    fclose(f);
+  }
+  for (k = 0; k < 2; k++) {
+    char dir[512];
+    snprintf(dir, sizeof(dir), "%s%s", roots[k], strcmp(rel[k], "/") ? rel[k] : "");
+    for (;;) {
+      const double q = cgroup_dir_quota(dir);
+      char *slash;
+      if (q > 0 && (best == 0.0 || q < best)) best = q;
+      if (strlen(dir) <= strlen(roots[k])) break;
+      slash = strrchr(dir, '/');
+      if (!slash) break;
+      *slash = 0;
+    }
+  }
+  return best;
+}
+
 /* CPUs this process can really keep busy: the affinity mask, cut down to the container's
- * cgroup grant (cpu.max = "quota period"; a box may show 256 CPUs and grant 16, and threads
- * beyond the grant only get the whole group throttled).  Default thread counts come from
- * here, never from the raw CPU count. */
+ * cgroup grant (a box may show 256 CPUs and grant 16, and threads beyond the grant only get
+ * the whole group throttled).  Default thread counts come from here, never from the raw CPU
+ * count.  JGA_CPU_BUDGET overrides (a launcher that knows the rank's share passes it on). */
 int jga_cpu_budget(void) {
   cpu_set_t set;
   int n = 0;
-  FILE *f;
+  const char *e = getenv("JGA_CPU_BUDGET");
+  if (e && atoi(e) > 0) return atoi(e);
   if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
   if (n < 1) n = (int)sysconf(_SC_NPROCESSORS_ONLN);
   if (n < 1) n = 1;
-  f = fopen("/sys/fs/cgroup/cpu.max", "r");
-  if (f) {
-    double quota = 0, period = 0;
-    if (fscanf(f, "%lf %lf", &quota, &period) == 2 && quota > 0 && period > 0) {
-      const int grant = (int)(quota/period + 0.5);
-      if (grant >= 1 && grant < n) n = grant;
-    }
-    fclose(f);
+  {
+    const double q = cgroup_cpu_quota();
+    const int grant = (int)(q + 0.5);
+    if (q > 0 && grant >= 1 && grant < n) n = grant;
+    else if (q > 0 && grant < 1) n = 1;
   }
   return n;
 }

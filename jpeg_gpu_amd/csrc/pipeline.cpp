@@ -164,9 +164,10 @@ bool ensure_slot(slot &s, long long coef_shorts, long long out_bytes, bool copy_
 }
 
 // Wait for the slot's GPU work and hand the result to the job.
-void retire(slot &s, bool copy_back) {
+void retire(slot &s, bool copy_back, bool blocking) {
   if (!s.job) return;
-  if (!HOK(jga_event_wait_sleeping(s.done))) s.job->status = EXIT_FAILURE;     // (usually over already)
+  // (usually over already; JGA_PIPE_SPIN=1 trades the nap's latency for a spinning core)
+  if (!HOK(blocking ? jga_event_wait_sleeping(s.done) : hipEventSynchronize(s.done))) s.job->status = EXIT_FAILURE;
   else if (copy_back && s.job->host_out && !(s.job->pinned & 2)) memcpy(s.job->host_out, s.h_out, (size_t)s.out_bytes);
   s.job = nullptr;
 }
@@ -185,7 +186,7 @@ void run_worker(jga_pipeline *pl, worker *w, jga_job *jobs, int n,
     slot &s = w->slots[cur];
     jpeg_header hdr;
     jga_geom g;
-    retire(s, copy_back);                     // slot reuse: previous image done?
+    retire(s, copy_back, pl->blocking != 0);  // slot reuse: previous image done?
     job->status = EXIT_FAILURE;
     if (jga_parse_header(job->jpeg, job->size, &hdr) != EXIT_SUCCESS) continue;
     if (jga_geom_from_header(&g, &hdr) != EXIT_SUCCESS) continue;
@@ -250,8 +251,8 @@ void run_worker(jga_pipeline *pl, worker *w, jga_job *jobs, int n,
     s.out_bytes = out_bytes;
     cur ^= 1;
   }
-  retire(w->slots[0], copy_back);
-  retire(w->slots[1], copy_back);
+  retire(w->slots[0], copy_back, pl->blocking != 0);
+  retire(w->slots[1], copy_back, pl->blocking != 0);
 }
 
 
@@ -351,14 +352,38 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     }
     host_entropy = true;
   }
+  // From here on the lane's stream may hold copies that read the callers' JPEG buffers (pinned
+  // inputs are DMA'd where they lie) or write their pixel buffers (pinned destinations): no
+  // return may leave them in flight — the caller is free to release both the moment
+  // jga_pipeline_run() is back.
+  struct drain_on_failure {
+    hipStream_t st;
+    bool armed = true;
+    ~drain_on_failure() { if (armed) (void)hipStreamSynchronize(st); }
+  } guard{l.stream};
   const long long cstride = (g.coef_shorts + 127) & ~127ll;
   const long long out_bytes = rgb ? g.rgb_bytes : g.yuv_bytes;
   const long long ostride = (out_bytes + 255) & ~255ll;
+  // Where the pixels go: the lane's own buffer, or the callers'.  Destinations that lie evenly
+  // spaced (dev_out[i] = dev_out[0] + i*pitch — a caller that keeps every output hands the
+  // pipeline slices of one big buffer) take one launch like the lane's buffer does; anything
+  // else one launch per image.
+  bool scattered = false, all_given = true, strided = false;
+  long long pitch = ostride;
+  for (int i = 0; i < m; i++) {
+    scattered = scattered || jobv[i]->dev_out != nullptr;
+    all_given = all_given && jobv[i]->dev_out != nullptr;
+  }
+  if (all_given) {
+    if (m > 1) pitch = (long long)(jobv[1]->dev_out - jobv[0]->dev_out);
+    strided = pitch >= out_bytes && pitch % 16 == 0 && ((uintptr_t)jobv[0]->dev_out) % 16 == 0;
+    for (int i = 1; i < m && strided; i++) strided = jobv[i]->dev_out == jobv[0]->dev_out + pitch*i;
+  }
   if (!grow((void **)&l.d_coef, &l.cap_coef, cstride*2*m, false)
    || !grow((void **)&l.d_q, &l.cap_q, 384ll*m, false)) {
     return EXIT_FAILURE;
   }
-  if (!grow((void **)&l.d_out, &l.cap_out, ostride*m, false)
+  if ((!all_given && !grow((void **)&l.d_out, &l.cap_out, ostride*m, false))
    || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*m, true))) {
     return EXIT_FAILURE;
   }
@@ -387,11 +412,11 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   }
   const auto t_c = std::chrono::steady_clock::now();
   const double c_c = trace ? thread_cpu_ms() : 0.0;
-  bool scattered = false;
-  for (int i = 0; i < m; i++) scattered = scattered || jobv[i]->dev_out != nullptr;
-  if (!scattered) {
-    if ((rgb ? jga_idct_rgb_batch(&g, m, l.d_coef, cstride, l.d_q, 1, l.d_out, ostride, l.stream)
-     : jga_idct_yuv_batch(&g, m, l.d_coef, cstride, l.d_q, 1, l.d_out, ostride, l.stream)) != EXIT_SUCCESS) {
+  if (!scattered || strided) {
+    unsigned char *base = strided ? jobv[0]->dev_out : l.d_out;
+    const long long step = strided ? pitch : ostride;
+    if ((rgb ? jga_idct_rgb_batch(&g, m, l.d_coef, cstride, l.d_q, 1, base, step, l.stream)
+     : jga_idct_yuv_batch(&g, m, l.d_coef, cstride, l.d_q, 1, base, step, l.stream)) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
     }
   }
@@ -415,6 +440,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   if (!HOK(pl->blocking ? jga_stream_wait_sleeping(l.stream, l.done) : hipStreamSynchronize(l.stream))) {
     return EXIT_FAILURE;
   }
+  guard.armed = false;                 // the stream is empty
   turn.give();
   if (trace) {
     const auto t_d = std::chrono::steady_clock::now();
@@ -509,6 +535,14 @@ void run_lane(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *g
 extern "C" {
 
 JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
+  // (read the two size fields before anything else: a caller built against another revision of
+  // the header has something else — or nothing — where the later fields are)
+  if (cfg->struct_size != (int)sizeof(jga_pipeline_config) || cfg->job_size != (int)sizeof(jga_job)) {
+    jga_fail("pipeline: caller built against another revision of jpeg_gpu_amd.h (config %d bytes, job %d; "
+     "this library: %d, %d) - use jga_pipeline_config_init()", cfg->struct_size, cfg->job_size,
+     (int)sizeof(jga_pipeline_config), (int)sizeof(jga_job));
+    return nullptr;
+  }
   jga_pipeline *pl = new jga_pipeline();
   pl->cfg = *cfg;
   if (pl->cfg.transport < 0 || pl->cfg.transport > 2) {

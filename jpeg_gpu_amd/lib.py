@@ -379,7 +379,8 @@ class PinnedBytes:
 class Pipeline:
     def __init__(self, device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
                  max_coef_shorts=0, max_out_bytes=0, transport=0, batch=0, depth=0, unstuff=0):
-        cfg = abi.jga_pipeline_config(device, nthreads, depth, out, int(copy_back),
+        cfg = abi.jga_pipeline_config(C.sizeof(abi.jga_pipeline_config), C.sizeof(abi.jga_job),
+                                      device, nthreads, depth, out, int(copy_back),
                                       max_coef_shorts, max_out_bytes, int(transport), int(batch),
                                       int(unstuff))
         self.ptr = L.jga_pipeline_create(C.byref(cfg))

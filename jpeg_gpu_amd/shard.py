@@ -107,25 +107,55 @@ def rank_cpu_share(local_rank, gpu_nodes, allowed, node_cpus, cores_of=None):
     return sorted(c for core in mine for c in core)
 
 
-def cpu_quota(cgroup="/sys/fs/cgroup"):
-    """CPUs' worth of run time the container may use per unit of wall time (cgroup v2 cpu.max
-    = "quota period", v1 cpu.cfs_quota_us / cpu.cfs_period_us), or None when unlimited.  A box can
-    show 256 CPUs and grant 16: threads beyond the grant only get the whole group throttled,
-    so thread counts have to be sized by this, not by the CPU count."""
+def _dir_quota(d):
+    """quota / period of one cgroup directory (v2 cpu.max, v1 cpu.cfs_*), None = no limit there."""
     try:
-        with open(cgroup + "/cpu.max") as f:
+        with open(d + "/cpu.max") as f:
             quota, period = f.read().split()[:2]
         return None if quota == "max" else float(quota) / float(period)
     except (OSError, ValueError):
         pass
     try:
-        with open(cgroup + "/cpu/cpu.cfs_quota_us") as f:
+        with open(d + "/cpu.cfs_quota_us") as f:
             quota = float(f.read())
-        with open(cgroup + "/cpu/cpu.cfs_period_us") as f:
+        with open(d + "/cpu.cfs_period_us") as f:
             period = float(f.read())
-        return None if quota <= 0 else quota / period
+        return None if quota <= 0 or period <= 0 else quota / period
     except (OSError, ValueError):
         return None
+
+
+def cpu_quota(cgroup="/sys/fs/cgroup", proc="/proc/self/cgroup"):
+    """CPUs' worth of run time the process may use per unit of wall time, or None when
+    unlimited: the tightest limit of its own cgroup (resolved from /proc/self/cgroup, v2
+    "0::/path" or v1 "N:cpu,cpuacct:/path") and of every ancestor up to the mount point —
+    the same walk csrc/layout.c:jga_cpu_budget() does, so bench.py and the library agree.  A
+    box can show 256 CPUs and grant 16: threads beyond the grant only get the whole group
+    throttled, so thread counts have to be sized by this, not by the CPU count."""
+    rel = {"": "", "cpu": ""}
+    try:
+        with open(proc) as f:
+            for line in f:
+                parts = line.rstrip("\n").split(":", 2)
+                if len(parts) != 3:
+                    continue
+                if parts[1] == "":
+                    rel[""] = parts[2]
+                elif "cpu" in parts[1].split(",") or "cpuacct" in parts[1].split(","):
+                    rel["cpu"] = parts[2]
+    except OSError:
+        pass
+    best = None
+    for root, r in ((cgroup, rel[""]), (cgroup + "/cpu", rel["cpu"])):
+        d = root + (r if r != "/" else "")
+        while True:
+            q = _dir_quota(d)
+            if q is not None and (best is None or q < best):
+                best = q
+            if len(d) <= len(root):
+                break
+            d = d.rsplit("/", 1)[0]
+    return best
 
 
 def rank_cpu_budget(ncpus, world, quota="auto"):

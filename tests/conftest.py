@@ -104,10 +104,13 @@ def gpu(lib):
     return lib
 
 
-def three_table_variant(data):
+def three_table_variant(data, distinct=True):
     """The same image with its Cr component on a THIRD pair of Huffman tables: the chroma DHTs are
-    repeated under table id 2 and the SOS points Cr there.  Decodes to the same coefficients;
-    the GPU entropy stage's table format (two DC + two AC tables per frame) cannot hold it."""
+    repeated under table id 2 and the SOS points Cr there.  Decodes to the same coefficients.
+    distinct: the DC copy also gets one more (never used) 16-bit code, so that the frame really
+    has three different DC tables — more than the GPU entropy stage's table format (two DC + two
+    AC tables per frame) holds; without it the copies are byte-identical to the chroma tables
+    and the device stage shares their slots."""
     d = bytearray(data)
     i, dhts, sos = 2, [], None
     while i < len(d):
@@ -127,6 +130,9 @@ def three_table_variant(data):
             if d[p] & 15 == 1:                          # a chroma table (id 1): repeat it as id 2
                 seg = bytearray(d[p:p + 17 + cnt])
                 seg[0] = (seg[0] & 0xF0) | 2
+                if distinct and seg[0] >> 4 == 0:       # DC class: one more code at length 16
+                    seg[16] += 1
+                    seg.append(0x0F)
                 extra += b"\xff\xc4" + bytes([(len(seg) + 2) >> 8, (len(seg) + 2) & 255]) + seg
             p += 17 + cnt
     assert extra and d[sos + 4] == 3                    # three components in the scan

@@ -677,6 +677,50 @@ def test_irregular_huffman_tables_take_the_host_entropy_stage(gpu, orc, synth):
         pl.close()
 
 
+def test_tables_repeated_under_a_third_id_stay_on_the_gpu_entropy_stage(gpu, orc, synth):
+    """An encoder that writes one DHT per component gives Cr tables byte-identical to Cb's under
+    an id of their own: the device format tells tables apart by content, so the frame keeps
+    the GPU entropy stage (same planes as the oracle), alone and next to ordinary files."""
+    import oracle
+    from conftest import three_table_variant
+    base = synth.synthetic_jpeg(320, 200, "420", quality=85, seed=4)
+    same = three_table_variant(base, distinct=False)
+    assert same != base
+    g, got, _ = gpu.gpu_entropy_decode([same, base])
+    m = gpu.real_coef_mask(g)
+    want = orc.decode(same, oracle.QUANT)[1]
+    assert np.array_equal(got[0][m], want[m]) and np.array_equal(got[1][m], want[m])
+
+
+def test_pipeline_writes_evenly_spaced_destinations_in_one_launch(gpu, orc, synth):
+    """Jobs whose dev_out pointers are slices of one buffer at a fixed pitch (a caller that keeps
+    every output) are written by the group's single launch, like the lane's own buffer; unevenly
+    placed ones one by one.  Same pixels either way, nothing outside the slices is touched."""
+    from jpeg_gpu_amd import abi
+    files = [synth.synthetic_jpeg(200, 120, "420", quality=70 + i, seed=50 + i) for i in range(6)]
+    nb = 200 * 120 * 3
+    pitch = gpu._align(nb) + 256
+    big = gpu.DeviceBuffer(pitch * 6)
+    odd = gpu.DeviceBuffer(pitch * 7)
+    pl = gpu.Pipeline(device=0, nthreads=2, out=abi.JPEG_DECODE_RGB, copy_back=False, transport=2,
+                      batch=6, depth=1)
+    try:
+        for buf, ptrs in ((big, [big.ptr + i * pitch for i in range(6)]),
+                          (odd, [odd.ptr + (i + (i > 2)) * pitch for i in range(6)])):   # a gap after the third
+            buf.fill(0xA5)
+            rc, jobs = pl.run(files, dev_outs=ptrs)
+            assert rc == 0 and all(j.status == 0 for j in jobs)
+            raw = buf.download()
+            for i, f in enumerate(files):
+                o = ptrs[i] - buf.ptr
+                assert np.array_equal(raw[o:o + nb], orc.decode_rgb(f)[1].reshape(-1)), i
+                assert np.all(raw[o + nb:o + pitch] == 0xA5)
+    finally:
+        pl.close()
+        big.free()
+        odd.free()
+
+
 @pytest.mark.parametrize("sampling", SAMPLINGS)
 @pytest.mark.parametrize("size", [(17, 9), (100, 75), (642, 363)])
 def test_pass3_alone_matches_oracle(gpu, orc, synth, sampling, size):

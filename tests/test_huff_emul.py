@@ -168,6 +168,11 @@ def test_three_tables_of_a_class_go_to_the_host_stage(emul, lib, orc, synth):
     odd = three_table_variant(base)
     assert emul.huff_emul_prepare_head(base, len(base)) == 0
     assert emul.huff_emul_prepare_head(odd, len(odd)) == 2
+    # ... while a third id whose tables merely REPEAT the chroma ones (an encoder that writes one
+    # DHT per component) shares their slots: tables are told apart by content, not by id
+    same = three_table_variant(base, distinct=False)
+    assert emul.huff_emul_prepare_head(same, len(same)) == 0
+    assert np.array_equal(lib.entropy_decode(same, g if False else lib.geom_of(same)[1]), lib.entropy_decode(base, lib.geom_of(base)[1]))
     _, g = lib.geom_of(odd)
     want = lib.entropy_decode(base, g)
     assert np.array_equal(lib.entropy_decode(odd, g), want)

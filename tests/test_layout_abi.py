@@ -100,6 +100,7 @@ def test_exports_every_declared_symbol(lib):
     declared |= set(re.findall(r"extern const jpeg_decode_ctx_vtbl (\w+);", hdr))
     assert {"HIPJPEG_DECODE_CTX_VTBL", "LIBJPEG_DECODE_CTX_VTBL"} <= declared
     declared -= {"jga_plane_geom", "jga_geom", "jga_pipeline_config", "jga_job"}
+    declared -= set(re.findall(r"#define (jga_\w+)\(", hdr))           # macros expand in the caller
     assert declared == set(lib.EXPORTED)
     for name in sorted(declared):
         assert hasattr(lib.L, name), name
@@ -134,3 +135,39 @@ def test_frames_whose_padded_planes_overflow_image_h_are_refused(lib, synth):
         d.read_header()
         d.init_image()
         assert d.img.plane[0].width == 65520 and d.img.plane[1].width == 32760
+
+
+def test_pipeline_create_turns_away_a_caller_from_another_header_revision(lib):
+    """jga_pipeline_config leads with the caller's sizeof(config) / sizeof(jga_job): a binary built
+    against another revision of the header is refused before its job array is walked with the
+    wrong stride (no device is touched before the check: runs without a GPU)."""
+    import ctypes as C
+    from jpeg_gpu_amd import abi
+    for cs, js in ((0, 0), (C.sizeof(abi.jga_pipeline_config) - 4, C.sizeof(abi.jga_job)),
+                   (C.sizeof(abi.jga_pipeline_config), C.sizeof(abi.jga_job) - 8)):
+        cfg = abi.jga_pipeline_config(cs, js, 0, 1, 1, abi.JPEG_DECODE_RGB, 0, 0, 0, 2, 4, 0)
+        assert not lib.L.jga_pipeline_create(C.byref(cfg))
+        assert b"another revision" in lib.L.jga_last_error()
+
+
+def test_cpu_quota_walks_the_process_cgroup_and_its_ancestors(tmp_path):
+    """The CPU grant is the tightest limit between the process's own cgroup and the mount point,
+    cgroup v2 (cpu.max) or v1 (cpu.cfs_*): what csrc/layout.c:jga_cpu_budget() does too."""
+    from jpeg_gpu_amd import shard
+    v2 = tmp_path / "v2"
+    (v2 / "a" / "b").mkdir(parents=True)
+    (v2 / "a" / "cpu.max").write_text("400000 100000\n")
+    (v2 / "a" / "b" / "cpu.max").write_text("max 100000\n")
+    (tmp_path / "p2").write_text("0::/a/b\n")
+    assert shard.cpu_quota(str(v2), str(tmp_path / "p2")) == 4.0
+    (v2 / "cpu.max").write_text("150000 100000\n")                    # the root is tighter still
+    assert shard.cpu_quota(str(v2), str(tmp_path / "p2")) == 1.5
+    v1 = tmp_path / "v1"
+    (v1 / "cpu" / "x").mkdir(parents=True)
+    (v1 / "cpu" / "x" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "x" / "cpu.cfs_period_us").write_text("100000\n")
+    (tmp_path / "p1").write_text("3:cpu,cpuacct:/x\n2:memory:/y\n")
+    assert shard.cpu_quota(str(v1), str(tmp_path / "p1")) == 2.5
+    (v1 / "cpu" / "x" / "cpu.cfs_quota_us").write_text("-1\n")        # unlimited
+    assert shard.cpu_quota(str(v1), str(tmp_path / "p1")) is None
+    assert shard.rank_cpu_budget(64, 8, 16.0) == 2 and shard.rank_cpu_budget(64, 8, None) == 64
