@@ -11,18 +11,26 @@ The metric is BASELINE.json's: Mpixel/s END-TO-END — from JPEG file bytes in h
 pixels in HBM (what a frame is in the reference: src/jpeg_gpu.c:1231-1237,
 its cpu/gpu split 1437-1458) — on 3840x2160 4:2:0 q90 baseline files.  A "step" is ONE
 batch of `--batch` (128) images per GPU through the pipelined decoder (jga_pipeline,
-transport 2, which works on them in groups of `--group` = 32): host threads parse markers and unstuff the scans into pinned memory, the
-compressed bytes cross PCIe, the GPU does the Huffman decode and the fused dequantise + IDCT
-+ upsample + RGB kernel.  The timed region is exactly K such batches per rank, streamed
-through the rank's lanes, bracketed by barrier + device synchronise; `value` = pixels of
-all ranks / max-over-ranks wall time.  Images are independent: each rank owns its own
-images, its own share of the host cores (those of its GPU's NUMA node) and there is no
-data-path collective (weak scaling); RCCL carries the barrier and the MAX only.
+transport 2, which works on them in groups of `--group` = 32): host threads parse markers and
+unstuff the scans into pinned memory, the compressed bytes cross PCIe, the GPU does the Huffman
+decode and the fused dequantise + IDCT + upsample + RGB kernel.  The timed region is exactly K
+such batches per rank, streamed through the rank's lanes, bracketed by barrier + device
+synchronise; `value` = pixels of all ranks / max-over-ranks wall time.  EVERY image of the timed
+region keeps its pixels (slices of one HBM buffer) and is compared with the oracle's pixels of
+its file after the clock stops (`config.images_verified`); a single differing byte fails the run.
+`value` is measured on files lying in ordinary PAGEABLE host memory; `value_pinned_ingest` (same
+run, same check) on files lying in pinned ingest buffers.  Images are independent: each rank
+owns its own images, its own share of the host cores (those of its GPU's NUMA node) and there
+is no data-path collective (weak scaling); RCCL carries the barrier and the MAX only (gloo
+if RCCL cannot be brought up: said in the line).
 
 Rank 0 prints ONE JSON line.  Beside the contract keys:
   roofline      the fused IDCT+RGB kernel alone on coefficient planes resident in HBM:
                 algorithmic bytes / launch time from HIP events on the launch stream
-                (`kernel_Mpixel_s` is that kernel's pixel rate — NOT the end-to-end value)
+                (`kernel_Mpixel_s` is that kernel's pixel rate — NOT the end-to-end value);
+                `traffic` from rocprofv3 --pmc child passes of this run when the tool is here
+  per_rank      every rank's own rate, GPU, NUMA node, CPUs and scan clean-up route (+ min / max)
+  configs       (N = 1) every BASELINE.json config beside its CPU path (tools/configs_bench.py)
   e2e           the same end-to-end measurement with the other transports: the north-star
                 design (host Huffman threads + pinned hipMemcpyAsync + kernel), with the pixels
                 copied back to host RAM, PACK words over PCIe
@@ -38,13 +46,13 @@ import os
 import socket
 import subprocess
 import sys
-import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for _p in (ROOT, os.path.join(ROOT, "tools")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 W, H, SAMPLING, QUALITY = 3840, 2160, "420", 90
@@ -74,14 +82,21 @@ def parse_args(argv=None):
     ap.add_argument("--no-pack", action="store_true", help="skip the PACK expansion leg")
     ap.add_argument("--no-other", action="store_true", help="skip the other-kernels leg")
     ap.add_argument("--no-gpu-entropy", action="store_true", help="skip the device-only breakdown leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-BASELINE-config leg")
+    ap.add_argument("--quick-configs", action="store_true", help="per-config leg on small counts (tests)")
     ap.add_argument("--prewarm", type=float, default=0.5,
                     help="seconds of untimed work before the headline and before the roofline leg (clock ramp)")
     ap.add_argument("--kernel-reps", type=int, default=50, help="launches timed in the roofline leg")
     ap.add_argument("--cpu-rounds", type=int, default=5, help="cpu_baseline: best of this many rounds")
     ap.add_argument("--cpu-frames", type=int, default=6, help="cpu_baseline: frames per core per round")
-    ap.add_argument("--measure-traffic", action="store_true",
-                    help="collect roofline.traffic now (rocprofv3 --pmc child passes) instead of "
-                         "quoting profiles/pmc_latest.json")
+    ap.add_argument("--measure-traffic", dest="measure_traffic", action="store_true", default=None,
+                    help="collect roofline.traffic now with rocprofv3 --pmc child passes (the default "
+                         "at N = 1 when rocprofv3 is on the box)")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false",
+                    help="quote profiles/pmc_latest.json instead (with its provenance)")
+    ap.add_argument("--max-keep-GB", type=float, default=96.0,
+                    help="HBM the timed region's retained outputs may take (every image is kept and "
+                         "verified when they fit: 64 GB at the defaults)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, report who they are and which CPUs they own, exit "
                          "(gloo; needs no GPU)")
@@ -112,8 +127,10 @@ def dry_launch(args, rank, local_rank, world):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     pin = {} if args.no_pin else shard.pin_rank_to_gpu_node(local_rank, world)
+    quota = shard.cpu_quota()
     me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
-          "cpus": sorted(os.sched_getaffinity(0)), "pin": pin}
+          "cpus": sorted(os.sched_getaffinity(0)), "pin": pin,
+          "cpu_budget": shard.rank_cpu_budget(len(os.sched_getaffinity(0)), world, quota)}
     everyone = [me]
     if world > 1:
         everyone = [None] * world
@@ -125,13 +142,115 @@ def dry_launch(args, rank, local_rank, world):
     return 0
 
 
+# ---- ranks talk over RCCL where it comes up, gloo where it does not -------------------------------
+
+class Comm:
+    """The job's control plane.  The data path needs no collective, so all the ranks exchange is
+    the timing barrier, a MAX / SUM of scalars and the per-rank report.  The default group is
+    gloo (CPU tensors: always works, carries all_gather_object); an RCCL group (backend "nccl")
+    is created on top and used for the barrier and the reductions when every rank could bring it
+    up — decided together, so that nobody waits on a collective the others never enter."""
+
+    def __init__(self, torch, dist, rank, world, gpu, share):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.group, self.device, self.backend, self.note = None, "cpu", "none", None
+        if world <= 1:
+            return
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.backend = "gloo"
+        if share or os.environ.get("JGA_BENCH_NO_RCCL") == "1":
+            self.note = ("ranks share devices (JGA_BENCH_SHARE_GPUS): RCCL refuses two ranks per GPU" if share
+                         else "JGA_BENCH_NO_RCCL=1")
+            return
+        ok, why, grp = 1, "", None
+        try:
+            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120),
+                                 device_id=torch.device("cuda", gpu))
+            t = torch.ones(1, device="cuda")
+            dist.all_reduce(t, group=grp)
+            torch.cuda.synchronize()
+            ok = int(t.item() == world)
+            why = "" if ok else "first all-reduce returned %r" % t.item()
+        except Exception as e:                      # RCCL / IPC not usable on this box
+            ok, why = 0, "%s: %s" % (type(e).__name__, str(e)[:200])
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                 # (gloo)
+        if int(flag.item()) == 1:
+            self.group, self.device, self.backend = grp, "cuda", "nccl (RCCL)"
+        else:
+            self.note = "RCCL group not usable (%s): barrier and reductions over gloo" % (why or "another rank failed")
+            log("rank %d: %s" % (rank, self.note))
+
+    def barrier(self):
+        if self.world > 1:
+            if self.group is not None:
+                self.dist.barrier(group=self.group)
+            else:
+                self.dist.barrier()
+
+    def reduce(self, value, op):
+        if self.world <= 1:
+            return float(value)
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op), group=self.group)
+        return float(t.item())
+
+    def throughput(self, units, seconds):
+        """Whole-job units/s: sum of units over ranks / max of time over ranks."""
+        t = self.reduce(seconds, "MAX")
+        return self.reduce(units, "SUM") / t, t
+
+    def gather(self, obj):
+        if self.world <= 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)                        # (gloo)
+        return out
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
 # ---- inputs -----------------------------------------------------------------------------------
 
-def make_inputs(synth, n, rank, threads):
-    seeds = [1234 + rank * 1000 + i for i in range(n)]
-    with ThreadPoolExecutor(max_workers=max(1, min(n, threads))) as ex:
-        return list(ex.map(lambda s: synth.synthetic_jpeg(W, H, SAMPLING, QUALITY, seed=s),
-                           seeds))
+def make_inputs(synth, n, rank, world, threads, comm):
+    """The rank's `n` distinct files (SURVEY.md §8(d) recipe).  Synthesised ONCE per box: each rank
+    makes its share (seed i with i % world == rank) into a cache under /dev/shm, keyed by the
+    recipe and the seed, and after a barrier every rank reads all of them — each into its own
+    memory, in its own rotation, so no two ranks decode the same file at the same moment.  Eight
+    ranks on a 16-CPU grant used to synthesise 8 x 64 files; now 64."""
+    seeds = [1234 + i for i in range(n)]
+    cache = os.environ.get("JGA_BENCH_CACHE", "/dev/shm/jga_bench_%d" % os.getuid())
+    name = lambda s: os.path.join(cache, "%dx%d_%s_q%d_s%d.jpg" % (W, H, SAMPLING, QUALITY, s))
+    try:
+        os.makedirs(cache, exist_ok=True)
+        usable = os.access(cache, os.W_OK)
+    except OSError:
+        usable = False
+    if not usable:
+        if world > 1:
+            comm.barrier()
+        with ThreadPoolExecutor(max_workers=max(1, min(n, threads))) as ex:
+            files = list(ex.map(lambda s: synth.synthetic_jpeg(W, H, SAMPLING, QUALITY, seed=s), seeds))
+        return files[rank % n:] + files[:rank % n], "synthesised by every rank (no /dev/shm)"
+
+    def make(s):
+        if not os.path.exists(name(s)):
+            data = synth.synthetic_jpeg(W, H, SAMPLING, QUALITY, seed=s)
+            tmp = name(s) + ".%d.tmp" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(data)
+            os.replace(tmp, name(s))
+    mine = [s for i, s in enumerate(seeds) if i % world == rank]
+    with ThreadPoolExecutor(max_workers=max(1, min(len(mine) or 1, threads))) as ex:
+        list(ex.map(make, mine))
+    comm.barrier()
+    files = [open(name(s), "rb").read() for s in seeds]
+    k = (rank * max(1, n // max(world, 1))) % n
+    return files[k:] + files[:k], "%d files synthesised once per box (%s), each rank reads them all" % (n, cache)
 
 
 def device_facts(torch, dev):
@@ -141,131 +260,25 @@ def device_facts(torch, dev):
             "clock_MHz": getattr(p, "clock_rate", 0) // 1000 or None}
 
 
-def cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except OSError:
-        pass
-    return "?"
-
-
 # ---- CPU baselines ----------------------------------------------------------------------------
-
-def all_core_rate(make_worker, threads, frames, rounds):
-    """`threads` frame loops side by side, each `frames` frames per round, started together;
-    best round of `rounds` (the first one also warms caches and buffers).  make_worker(i)
-    returns the loop of thread i as a callable taking the frame count."""
-    loops = [make_worker(i) for i in range(threads)]
-    closers = [getattr(l, "close", None) for l in loops]
-    best = None
-    for _ in range(rounds):
-        gate = threading.Barrier(threads + 1)
-        done = []
-
-        def body(loop):
-            gate.wait()
-            loop(frames)
-            done.append(time.perf_counter())
-        ts = [threading.Thread(target=body, args=(l,)) for l in loops]
-        for t in ts:
-            t.start()
-        gate.wait()
-        t0 = time.perf_counter()
-        for t in ts:
-            t.join()
-        dt = max(done) - t0
-        best = dt if best is None or dt < best else best
-    for c in closers:
-        if c:
-            c()
-    return threads * frames * W * H / best / 1e6, best
-
 
 def cpu_baseline(jpegs, rounds, frames, cpus=None, quota=None):
     """north_star: "the xjpeg/libjpeg-turbo CPU path timed on the same box's host cores in the
-    same run (core count stated)".  One frame loop per CPU the box really grants — all of
-    `cpus` (the whole box, not one rank's NUMA share), or the cgroup's cpu.max grant when that
-    is smaller: more loops than granted CPUs only get the group throttled (measured: 16 loops
-    2.0 Gpixel/s, 64 loops 1.6, 256 loops 1.5 on a 16-CPU grant) — every loop on its own
-    image; warm; best of `rounds`."""
-    import numpy as np
-    import oracle
-    from jpeg_gpu_amd import abi, lib
+    same run (core count stated)" — tools/cpu_paths.py: one frame loop per CPU the box really
+    grants (all of `cpus`, the whole box, not one rank's NUMA share; or the cgroup's grant when
+    that is smaller), every loop on its own image; warm; best of `rounds`."""
+    import cpu_paths
     mine = os.sched_getaffinity(0)
     if cpus:
         os.sched_setaffinity(0, cpus)            # the loops' threads inherit it
-    ncpu = len(os.sched_getaffinity(0))
-    threads = max(1, min(ncpu, int(quota + 0.5))) if quota else ncpu
-    res = {"unit": "Mpixel/s", "cores": threads, "cpu_model": cpu_model(),
+    threads, ncpu = cpu_paths.granted_threads(None, quota)
+    res = {"unit": "Mpixel/s", "cores": threads, "cpu_model": cpu_paths.cpu_model(),
            "visible_cpus": ncpu, "cgroup_cpu_quota": quota,
            "method": "one frame loop per granted CPU (reset -> header -> decode, as "
                      "src/jpeg_gpu.c:1231-1237), %d frames per loop per round, best of %d rounds, "
                      "each loop on its own 3840x2160 4:2:0 q90 file" % (frames, rounds)}
     t_all = time.perf_counter()
-
-    # (1) the reference's own code, compiled from its sources: xjpeg + dct.c, YUV stage
-    if oracle.Reference.available() and hasattr(oracle.Reference().lib, "ref_frames_yuv"):
-        ref = oracle.Reference()
-        rate, dt = all_core_rate(lambda i: (lambda n, d=jpegs[i % len(jpegs)]: ref.frames_yuv(d, n)),
-                                 threads, frames, rounds)
-        t0 = time.perf_counter()
-        ref.frames_yuv(jpegs[0], 2)
-        one = 2 * W * H / (time.perf_counter() - t0) / 1e6
-        res["reference_xjpeg_yuv"] = {
-            "value": round(rate, 1), "single_core_value": round(one, 1), "seconds": round(dt, 3),
-            "note": "the reference's xjpeg.c + dct.c compiled unmodified (oracle/_ref): Huffman + "
-                    "dequantise + float IDCT + clamp into Y/Cb/Cr planes (it has no CPU RGB stage)"}
-    # (2) libjpeg-turbo behind the reference's other plugin table, RGB stage
-    if lib.L.jga_libjpeg_available():
-        def lj_worker(i):
-            d = lib.Decoder(jpegs[i % len(jpegs)], lib.LIBJPEG_VTBL)
-            d.read_header()
-            d.init_image()
-
-            def loop(n):
-                for _ in range(n):
-                    d.reset()
-                    d.read_header()
-                    d.decode(abi.JPEG_DECODE_RGB)
-            loop.close = d.close                    # 62 MB of image buffers per loop
-            return loop
-        rate, dt = all_core_rate(lj_worker, threads, frames, rounds)
-        d1 = lj_worker(0)
-        d1(1)
-        t0 = time.perf_counter()
-        d1(2)
-        one = 2 * W * H / (time.perf_counter() - t0) / 1e6
-        d1.close()
-        res["libjpeg_turbo_rgb"] = {
-            "value": round(rate, 1), "single_core_value": round(one, 1), "seconds": round(dt, 3),
-            "note": "system libjpeg.so.8 (libjpeg-turbo) through LIBJPEG_DECODE_CTX_VTBL: ISLOW "
-                    "IDCT, plain upsampling, RGB out (src/jpeg_wrap.c:196-222); a different "
-                    "integer IDCT, so a speed reference, not the parity oracle"}
-    else:
-        res["libjpeg_turbo_rgb"] = {"value": None, "note": "libjpeg.so.8 not installed on this box"}
-    # (3) the oracle port of the whole path (Huffman + float IDCT + clamp + upsample + RGB)
-    orc = oracle.Oracle()
-    info = orc.parse(jpegs[0])
-    need = sum(info.hblocks[i] * info.vblocks[i] * 64 for i in range(info.ncomps))
-
-    def port_worker(i):
-        sc, out = np.empty(need, np.uint8), np.empty((H, W, 3), np.uint8)
-        d = jpegs[i % len(jpegs)]
-
-        def loop(n):
-            for _ in range(n):
-                orc.decode_rgb(d, sc, out)
-        return loop
-    rate, dt = all_core_rate(port_worker, threads, frames, rounds)
-    p1 = port_worker(0)
-    t0 = time.perf_counter()
-    p1(2)
-    one = 2 * W * H / (time.perf_counter() - t0) / 1e6
-    res["oracle_port_rgb"] = {
-        "value": round(rate, 1), "single_core_value": round(one, 1), "seconds": round(dt, 3),
-        "note": "oracle/oracle.c restatement of the whole path incl. upsample + RGB"}
+    res.update(cpu_paths.time_paths(jpegs, W, H, threads, frames, rounds, port=True))
     # the headline CPU number: the reference's own path where its build is here, else the port
     if "reference_xjpeg_yuv" in res:
         res["kind"], res["value"] = "reference", res["reference_xjpeg_yuv"]["value"]
@@ -291,14 +304,20 @@ def git_head():
         return None
 
 
-def measure_traffic(batch):
+def rocprof_here():
+    import shutil
+    return bool(shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"))
+
+
+def measure_traffic(batch, budget_s=300):
     """rocprofv3 --pmc passes over a child that launches the fused kernel on a resident batch
     (tools/pmc_traffic.py; counters and corrections as MI355X_MICROARCH.md prescribes).  Writes
-    profiles/pmc_latest.json and returns it, or None when the tool is not on the box."""
+    profiles/pmc_latest.json and returns it, or None when the tool is not on the box / runs out
+    of its time budget."""
     tool = os.path.join(ROOT, "tools", "pmc_traffic.py")
     try:
         r = subprocess.run([sys.executable, tool, "--batch", str(batch)], stdout=subprocess.PIPE,
-                           stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+                           stderr=subprocess.PIPE, text=True, timeout=budget_s, cwd=ROOT)
         line = [l for l in r.stdout.splitlines() if l.startswith("PMC ")]
         if r.returncode == 0 and line:
             return json.loads(line[0][4:])
@@ -322,6 +341,50 @@ def quoted_traffic(batch):
             "from": pmc.get("source")}
     valu = {k: pmc[k] for k in ("valu_insts_per_wave", "valu_busy_4clk") if k in pmc}
     return pmc.get("hbm_bytes_per_launch"), dict(provenance=prov, valu=valu)
+
+
+# ---- every image of a timed region, against the oracle -------------------------------------------
+
+class KeptOutputs:
+    """One HBM buffer holding the pixels of every image of a timed region (slot k at k*pitch:
+    evenly spaced, so the pipeline writes a group with one launch), and the check of all of
+    them against the oracle's pixels after the clock has stopped."""
+
+    def __init__(self, torch, n_images, out_bytes, group, max_bytes):
+        self.torch, self.out_bytes = torch, out_bytes
+        self.pitch = (out_bytes + 255) // 256 * 256
+        free, _ = torch.cuda.mem_get_info()
+        room = int(min(max_bytes, free - (12 << 30)))               # leave the lanes their buffers
+        slots = max(group, min(n_images, room // self.pitch))
+        self.slots = n_images if slots >= n_images else slots // group * group
+        self.n_images = n_images
+        self.buf = torch.empty(self.slots * self.pitch, dtype=torch.uint8, device="cuda")
+
+    def ptrs(self):
+        base = self.buf.data_ptr()
+        return [base + (k % self.slots) * self.pitch for k in range(self.n_images)]
+
+    def verify(self, file_of_job, reference_of_file):
+        """file_of_job[k] = which distinct file job k decoded; reference_of_file[f] = the oracle's
+        pixels of it (a cuda uint8 tensor).  Slots hold the LAST job written to them.  Returns
+        (images verified, indices of the jobs whose pixels differ)."""
+        torch = self.torch
+        last = {}
+        for k in range(self.n_images):
+            last[k % self.slots] = k
+        bad = []
+        inject = os.environ.get("JGA_BENCH_CORRUPT")
+        if inject is not None:                                       # tests: one flipped byte must fail the run
+            self.buf[(int(inject) % self.slots) * self.pitch + 4321] ^= 0xFF
+        for slot, k in sorted(last.items()):
+            got = self.buf[slot * self.pitch: slot * self.pitch + self.out_bytes]
+            if not torch.equal(got, reference_of_file[file_of_job[k]]):
+                bad.append(k)
+        return len(last), bad
+
+    def free(self):
+        self.buf = None
+        self.torch.cuda.empty_cache()
 
 
 # ---- main -------------------------------------------------------------------------------------
@@ -357,7 +420,6 @@ def main():
         raise SystemExit("bench.py: %d HIP device(s) visible, %d needed (no CPU fallback exists)"
                          % (ndev, world))
     gpu = local_rank % ndev
-    red_dev = "cpu" if share else "cuda"
     # this rank's host cores: those of its GPU's NUMA node, shared with the ranks next door
     pin = None
     orig_cpus = os.sched_getaffinity(0)
@@ -369,26 +431,21 @@ def main():
     # CPUs and grant 16); threads beyond the grant get everybody throttled
     quota = shard.cpu_quota()
     budget = shard.rank_cpu_budget(my_cpus, world, quota)
+    if world > 1:
+        os.environ["JGA_CPU_BUDGET"] = str(budget)     # the library's defaults: this rank's share, not the box's
     torch.cuda.set_device(gpu)
     lib.check(lib.L.jga_set_device(gpu))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", gpu))
+    comm = Comm(torch, dist, rank, world, gpu, share)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        comm.barrier()
         torch.cuda.synchronize()
         lib.check(lib.L.jga_stream_sync(None))
 
-    # ---- inputs: distinct synthetic files in host RAM (214 MB per rank at the defaults: they
+    # ---- inputs: distinct synthetic files in host RAM (196 MB per rank at the defaults: they
     # do not fit any cache level, so the host side reads them from DRAM like real traffic)
     t_setup = time.perf_counter()
-    jpegs = make_inputs(synth, args.distinct, rank, min(my_cpus, 64))
+    jpegs, inputs_note = make_inputs(synth, args.distinct, rank, world, max(1, min(budget, 64)), comm)
     hdr, g = lib.geom_of(jpegs[0])
     B, K, Wm = args.batch, args.steps, args.warmup
     G = max(1, min(args.group, B))
@@ -401,97 +458,87 @@ def main():
         ", cpus %s of node %s" % (pin["cpu_list"], pin["numa_node"]) if pin else "",
         ", cgroup grants %.1f CPUs" % quota if quota else ""))
 
-    # ---- headline: JPEG bytes in host RAM -> RGB8 in HBM, K batches of B images per rank ----
-    # The files lie in PINNED ingest buffers (jga_host_malloc_pinned: where a reader would put
-    # them): with cores to spare the host cleans the scans up exactly as it does
-    # for pageable files (same rate, measured below at every N); with few cores per GPU the
-    # library DMAs them where they lie and cleans up on the device (csrc/unstuff_kernels.hip).
+    # ---- the oracle's pixels of every distinct file, resident in HBM for the checks (checker
+    # side: computed before any timed region, on this rank's cores)
+    import oracle
+    orc = oracle.Oracle()
+    t_or = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, min(budget, 32))) as ex:
+        refs_host = list(ex.map(lambda j: orc.decode_rgb(j)[1].reshape(-1), jpegs))
+    refs = [torch.from_numpy(r).cuda() for r in refs_host]
+    log("rank %d: oracle pixels of %d files in %.1f s" % (rank, len(refs), time.perf_counter() - t_or))
+
+    # ---- headline: JPEG bytes in host RAM -> RGB8 in HBM, K batches of B images per rank, twice:
+    # files in ordinary PAGEABLE memory (`value`: the host copies every scan, cleaning it up on the
+    # way or leaving that to the GPU when cores are few) and files in PINNED ingest buffers
+    # (jga_host_malloc_pinned: where a reader would put them; with few cores per
+    # GPU the library DMAs them where they lie and cleans up on the device).  Every image of both
+    # timed regions keeps its pixels and is checked.
     pins = [lib.PinnedBytes(j) for j in jpegs]
-    pl = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
-                      copy_back=False, transport=2, batch=G, depth=args.lanes)
     cyc = lambda n, o=0: [jpegs[(o + i) % len(jpegs)] for i in range(n)]
     pcyc = lambda n, o=0: [pins[(o + i) % len(pins)].array for i in range(n)]
-    setup_jobs = lib.Pipeline.make_jobs(pcyc(args.lanes * G), pinned=True)   # lanes allocate their buffers
-    warm_jobs = lib.Pipeline.make_jobs(pcyc(Wm * B, 7), pinned=True) if Wm > 0 else None
-    timed_jobs = lib.Pipeline.make_jobs(pcyc(K * B, 13), pinned=True)
-    if pl.run_jobs(setup_jobs) != 0:
-        raise SystemExit("bench.py: pipeline failed: " + lib.L.jga_last_error().decode())
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm:                # clocks settle (a cold GPU reads
-        pl.run_jobs(setup_jobs)                                      # ~4 % low: the same pipeline run later in this process did)
-    if warm_jobs is not None:
-        pl.run_jobs(warm_jobs)                                       # W untimed steps
-    fence()
-    t0 = time.perf_counter()
-    rc = pl.run_jobs(timed_jobs)                                     # exactly K steps; returns when
-    fence()                                                          # every output is complete
-    dt = time.perf_counter() - t0
-    if rc != 0 or any(j.status != 0 for j in timed_jobs):
-        raise SystemExit("bench.py: a job of the timed region failed: " + lib.L.jga_last_error().decode())
-    h2d_per_image = sum(j.h2d_bytes for j in timed_jobs) // len(timed_jobs)
-    rate, _, dt = shard.aggregate_throughput(K * B * W * H, dt, dist if world > 1 else None,
-                                             device=red_dev)
-    # the pixels it produces, against the oracle (outside the timed region): two files, decoded
-    # by the same pipeline into buffers of ours
-    ok = True
-    if rank == 0:
-        import oracle
-        orc = oracle.Oracle()
-        bufs = [lib.DeviceBuffer(g.rgb_bytes) for _ in range(2)]
-        chk = lib.Pipeline.make_jobs(pcyc(2, 5), dev_outs=[b.ptr for b in bufs], pinned=True)
-        ok = pl.run_jobs(chk) == 0
-        for i, b in enumerate(bufs):
-            want = orc.decode_rgb(jpegs[(5 + i) % len(jpegs)])[1].reshape(-1)
-            ok = ok and bool(np.array_equal(b.download(g.rgb_bytes), want))
-            b.free()
-        if not ok:
-            raise SystemExit("bench.py: pipeline output differs from the oracle")
-    pl.close()
+    kept = KeptOutputs(torch, K * B, g.rgb_bytes, G, int(args.max_keep_GB * 2**30))
+    file_of_job = [(13 + i) % len(jpegs) for i in range(K * B)]
 
-    # ---- the same measurement with the files in ordinary PAGEABLE memory (Python bytes): the host
-    # (or, short of cores, the device) cleans the scans up out of a copy the host makes.  Equal to
-    # `value` where cores are plentiful; the difference is what pinned ingest buffers buy where
-    # they are not (profiles/r2_host_waits.txt).  Also two forced variants of the pinned run at
-    # N = 1, so that the line shows both clean-ups whatever `auto` chose.
-    pageable_leg = None
+    def headline_run(pinned, **kw):
+        src = pcyc if pinned else cyc
+        mk = lambda n, o, **k2: lib.Pipeline.make_jobs(src(n, o), pinned=pinned, **k2)
+        pl = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False,
+                          transport=2, batch=G, depth=args.lanes, **kw)
+        setup_jobs = mk(args.lanes * G, 0)                           # lanes allocate their buffers
+        warm_jobs = mk(Wm * B, 7) if Wm > 0 else None
+        timed_jobs = mk(K * B, 13, dev_outs=kept.ptrs())
+        if pl.run_jobs(setup_jobs) != 0:
+            raise SystemExit("bench.py: pipeline failed: " + lib.L.jga_last_error().decode())
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < args.prewarm:            # clocks settle (a cold GPU reads
+            pl.run_jobs(setup_jobs)                                  # ~4 % low)
+        if warm_jobs is not None:
+            pl.run_jobs(warm_jobs)                                   # W untimed steps
+        kept.buf.zero_()
+        fence()
+        t0 = time.perf_counter()
+        rc = pl.run_jobs(timed_jobs)                                 # exactly K steps; returns when
+        fence()                                                      # every output is complete
+        dt_local = time.perf_counter() - t0
+        pl.close()
+        if rc != 0 or any(j.status != 0 for j in timed_jobs):
+            raise SystemExit("bench.py: a job of the timed region failed: " + lib.L.jga_last_error().decode())
+        nver, bad = kept.verify(file_of_job, refs)
+        if bad:
+            raise SystemExit("bench.py: rank %d: %d of %d images of the timed region differ from the oracle "
+                             "(first: job %d, file %d)" % (rank, len(bad), nver, bad[0], file_of_job[bad[0]]))
+        rate, dt = comm.throughput(K * B * W * H, dt_local)
+        return {"rate": rate, "dt": dt, "dt_local": dt_local, "verified": nver,
+                "h2d": sum(j.h2d_bytes for j in timed_jobs) // len(timed_jobs)}
+
+    page = headline_run(False)
+    pinn = headline_run(True)
+    rate, dt = page["rate"], page["dt"]
+    h2d_per_image = page["h2d"]
+    ok = True
     forced = {}
-    if not args.no_e2e:
-        def timed_run(jobs_of, **kw):
-            p_ = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB,
-                              copy_back=False, transport=2, batch=G, depth=args.lanes, **kw)
-            p_.run_jobs(jobs_of(args.lanes * G, 0))
-            if Wm > 0:
-                p_.run_jobs(jobs_of(Wm * B, 7))
-            jobs = jobs_of(K * B, 13)
-            fence()
-            t0 = time.perf_counter()
-            rc_ = p_.run_jobs(jobs)
-            fence()
-            r_, _, t_ = shard.aggregate_throughput(K * B * W * H, time.perf_counter() - t0,
-                                                   dist if world > 1 else None, device=red_dev)
-            ok_ = rc_ == 0
-            if rank == 0:                               # its pixels too, against the oracle
-                import oracle
-                buf = lib.DeviceBuffer(g.rgb_bytes)
-                one = jobs_of(1, 9)
-                one[0].dev_out = buf.ptr
-                ok_ = ok_ and p_.run_jobs(one) == 0
-                ok_ = ok_ and bool(np.array_equal(buf.download(g.rgb_bytes),
-                                                  oracle.Oracle().decode_rgb(jpegs[9 % len(jpegs)])[1].reshape(-1)))
-                buf.free()
-            p_.close()
-            return {"value": round(r_ / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * B,
-                    "ok": ok_, "ms_per_step": round(t_ / K * 1e3, 4)}
-        pageable_leg = timed_run(lambda n, o: lib.Pipeline.make_jobs(cyc(n, o)))
-        pageable_leg["note"] = ("as `value`, but the files are ordinary pageable buffers: the host copies "
-                                "every scan (cleaning it up on the way, or leaving that to the GPU when "
-                                "cores are few); aggregated over ranks")
-        if world == 1:
-            for name, mode in (("pinned_files_host_cleanup", 1), ("pinned_files_device_cleanup", 2)):
-                forced[name] = timed_run(lambda n, o: lib.Pipeline.make_jobs(pcyc(n, o), pinned=True),
-                                         unstuff=mode)
+    if world == 1 and not args.no_e2e:
+        # both scan clean-ups forced on the pinned files, so that the line shows each whatever `auto` chose
+        for name, mode in (("pinned_files_host_cleanup", 1), ("pinned_files_device_cleanup", 2)):
+            r_ = headline_run(True, unstuff=mode)
+            forced[name] = {"value": round(r_["rate"] / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * B,
+                            "images_verified": r_["verified"], "ok": True,
+                            "ms_per_step": round(r_["dt"] / K * 1e3, 4)}
+    kept_slots = kept.slots
+    kept.free()
     for p_ in pins:
         p_.free()
+    cleanup_route = "device" if min(nthreads, my_cpus, int(quota / world) if quota else my_cpus) \
+        <= int(os.environ.get("JGA_PIPE_OFFLOAD_AT", "8")) else "host"
+    me = {"rank": rank, "gpu": gpu, "pci": (lib.device_pci_bus_id(gpu) if ndev else None),
+          "numa_node": pin["numa_node"] if pin else None, "cpus": my_cpus,
+          "cpu_list": pin["cpu_list"] if pin else None, "cpu_budget": budget, "host_threads": nthreads,
+          "Mpixel_s": round(K * B * W * H / page["dt_local"] / 1e6, 1),
+          "ms_per_step": round(page["dt_local"] / K * 1e3, 4),
+          "Mpixel_s_pinned_ingest": round(K * B * W * H / pinn["dt_local"] / 1e6, 1),
+          "images_verified": page["verified"] + pinn["verified"], "scan_cleanup": cleanup_route}
+    per_rank = comm.gather(me)
     PB, B = B, args.kernel_batch       # from here on B = images per launch of the stand-alone kernel legs
 
     # ---- roofline: the fused kernel alone, coefficient planes resident in HBM ----
@@ -519,20 +566,19 @@ def main():
         launch(20)
     launch(5)
     ev_ms = launch(args.kernel_reps)                      # HIP events on `stream` around the launches
-    if world > 1:
-        e = torch.tensor([ev_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        ev_ms = float(e.item())
-    if rank == 0:
-        import oracle
-        want = oracle.Oracle().decode_rgb(jpegs[0])[1].reshape(-1)
-        if not np.array_equal(d_out.download(g.rgb_bytes, offset=0), want):
-            raise SystemExit("bench.py: kernel output differs from the oracle")
+    ev_ms = comm.reduce(ev_ms, "MAX")
+    for i in range(min(B, ncoef)):                        # every distinct image of the launch
+        if not np.array_equal(d_out.download(g.rgb_bytes, offset=i * ostride), refs_host[i]):
+            raise SystemExit("bench.py: rank %d: kernel output differs from the oracle (image %d)" % (rank, i))
     alg_bytes = B * (g.coef_blocks * 128 + g.rgb_bytes)
     achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
     traffic, extra = quoted_traffic(B)
-    if args.measure_traffic and rank == 0 and world == 1:
+    want_traffic = args.measure_traffic if args.measure_traffic is not None else rocprof_here()
+    if want_traffic and rank == 0 and world == 1:
+        t_pmc = time.perf_counter()
         pmc = measure_traffic(B)
+        log("bench.py: roofline.traffic %s in %.0f s" % ("measured" if pmc else "NOT measured (quoting the committed file)",
+                                                          time.perf_counter() - t_pmc))
         if pmc:
             traffic = pmc.get("hbm_bytes_per_launch")
             extra = dict(provenance={"source": "rocprofv3 --pmc child passes of this run "
@@ -543,8 +589,14 @@ def main():
     # ---- the north-star transport at every N: host Huffman threads -> pinned hipMemcpyAsync ->
     # fused kernel (entropy.c on this rank's cores; 24.9 MB of planes per image over PCIe)
     e2e = {}
-    if pageable_leg:
-        e2e["pageable_files_to_rgb_hbm"] = pageable_leg
+    e2e["pageable_files_to_rgb_hbm"] = {
+        "value": round(page["rate"] / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * PB, "ok": True,
+        "images_verified": page["verified"], "ms_per_step": round(page["dt"] / K * 1e3, 4),
+        "note": "= `value`: the files are ordinary pageable buffers; aggregated over ranks"}
+    e2e["pinned_files_to_rgb_hbm"] = {
+        "value": round(pinn["rate"] / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * PB, "ok": True,
+        "images_verified": pinn["verified"], "ms_per_step": round(pinn["dt"] / K * 1e3, 4),
+        "note": "= `value_pinned_ingest`: the files lie in pinned ingest buffers (jga_host_malloc_pinned)"}
     e2e.update(forced)
     if not args.no_e2e:
         # Huffman threads also block on their slot's event: ~3 per granted CPU measured best
@@ -559,8 +611,7 @@ def main():
         t0 = time.perf_counter()
         rc0 = pl0.run_jobs(j_run)
         fence()
-        r0, _, t_ns = shard.aggregate_throughput(n0 * W * H, time.perf_counter() - t0,
-                                                 dist if world > 1 else None, device=red_dev)
+        r0, t_ns = comm.throughput(n0 * W * H, time.perf_counter() - t0)
         pl0.close()
         e2e["north_star_host_huffman_to_rgb_hbm"] = {
             "value": round(r0 / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": n0,
@@ -575,19 +626,29 @@ def main():
         "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
+        # the same K steps on files lying in pinned ingest buffers (the faster of the two where host
+        # cores are few; `value` is the conservative one: ordinary pageable files)
+        "value_pageable": round(page["rate"] / 1e6, 1),
+        "value_pinned_ingest": round(pinn["rate"] / 1e6, 1),
+        "ms_per_step_pinned_ingest": round(pinn["dt"] / K * 1e3, 4),
         "config": {
-            "workload": "3840x2160 4:2:0 q90 baseline JPEG files in host RAM (pinned ingest buffers) -> "
-                        "RGB8 in HBM (end to end); step = one batch of %d images per GPU through the "
+            "workload": "3840x2160 4:2:0 q90 baseline JPEG files in host RAM (ordinary pageable buffers) -> "
+                        "RGB8 in HBM (end to end), every output kept and compared with the oracle; "
+                        "step = one batch of %d images per GPU through the "
                         "pipelined decoder: host marker parse, scan clean-up (unstuffing) on the host "
-                        "into pinned memory - or, when the rank has 8 cores or fewer, on the GPU with "
-                        "the scans DMA'd where they lie - compressed bytes over PCIe, GPU Huffman "
+                        "into pinned memory - or, when the rank has 8 cores or fewer, on the GPU - "
+                        "compressed bytes over PCIe, GPU Huffman "
                         "decode + fused dequant/IDCT/upsample/RGB kernel; %d steps streamed through "
                         "%d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
             # (the library's rule, csrc/pipeline.cpp: the smaller of the CPU grant and nthreads)
-            "scan_cleanup": "device" if min(nthreads, my_cpus, int(quota) if quota else my_cpus)
-                            <= int(os.environ.get("JGA_PIPE_OFFLOAD_AT", "8")) else "host",
+            "scan_cleanup": cleanup_route,
             "batch_per_gpu": PB, "pipeline_group": G, "distinct_images_per_gpu": len(jpegs),
-            "images_timed_per_gpu": K * PB, "h2d_bytes_per_image": int(h2d_per_image),
+            "images_timed_per_gpu": K * PB, "images_verified": page["verified"],
+            "images_verified_pinned_ingest": pinn["verified"],
+            "outputs_kept_GB": round(kept_slots * ((g.rgb_bytes + 255) // 256 * 256) / 2**30, 1),
+            "h2d_bytes_per_image": int(h2d_per_image),
+            "inputs": inputs_note,
+            "ranks_talk_over": comm.backend, **({"ranks_talk_note": comm.note} if comm.note else {}),
             # what the link carries per GPU at this rate (it sustains ~56 GB/s from pinned memory,
             # tools/h2d_probe.py): `value` sits within ~10 % of the PCIe ceiling for this content
             "h2d_GBps_per_gpu_at_value": round(rate / world / (W * H) * h2d_per_image / 1e9, 1),
@@ -596,8 +657,16 @@ def main():
             "host_cpus": {"visible_to_rank": my_cpus, "cgroup_cpu_quota": quota,
                           "budget_per_rank": budget},
             "bit_exact_vs_oracle": ok,
+            "rgb_stage_note": "planes are bit-exact against the reference's CPU path (src/dct.c); the "
+                              "upsample + RGB rounding is this build's definition (SURVEY.md A.5: the "
+                              "reference has no executable one), pinned by the oracle",
             "device": device_facts(torch, gpu),
         },
+        "per_rank": {"ranks": per_rank,
+                     "min_Mpixel_s": min(r["Mpixel_s"] for r in per_rank),
+                     "max_Mpixel_s": max(r["Mpixel_s"] for r in per_rank),
+                     "note": "each rank's own wall clock around its own K steps (pageable files); "
+                             "`value` = all pixels / the slowest rank's time"},
         "roofline": {
             "kernel": lib.L.jga_kernel_name(C.byref(g), 1).decode(),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
@@ -619,7 +688,7 @@ def main():
     if rank == 0:
         # what a plain device-to-device copy of the same volume reaches on this box (SURVEY.md
         # 8d: "state the measured copy ceiling next to the spec"): bytes read + bytes written
-        src = torch.empty(alg_bytes // 2, dtype=torch.uint8, device=red_dev)
+        src = torch.empty(alg_bytes // 2, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(src)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         dst.copy_(src)
@@ -846,11 +915,50 @@ def main():
             "prepare_ms_host_parse_unstuff_h2d": round(t_prep * 1e3, 2),
         }
 
+    if solo and not args.no_configs:
+        # Every BASELINE.json config beside its CPU path (row d' of the judge's table: "throughput on
+        # synthetic JPEGs of the named resolutions ... next to the ... CPU path").  Configs 2-5 are
+        # measured by tools/configs_bench.py; the headline entry is this run's own legs.
+        import configs_bench
+        import cpu_paths
+        t_cfg = time.perf_counter()
+        cpu_threads, _ = cpu_paths.granted_threads(orig_cpus, quota)
+        cfgs = configs_bench.run_configs(nthreads, cpu_threads, lanes=args.lanes, group=G,
+                                         quick=args.quick_configs, log=log,
+                                         cpu_affinity=orig_cpus)     # (the CPU paths get the whole grant, as cpu_baseline does)
+        cb = out.get("cpu_baseline", {})
+        ge = out.get("gpu_entropy", {})
+        hl = {"what": "3840x2160 4:2:0 q90 (the configuration the metric is quoted on), %d distinct files" % len(jpegs),
+              "file_bytes": len(jpegs[0]),
+              "to_rgb_hbm": {"Mpixel_s": out["value"], "Mpixel_s_pinned_files": out["value_pinned_ingest"],
+                             "stream_images": K * PB, "h2d_bytes_per_image": int(h2d_per_image)},
+              "to_host_pixels": {k: e2e[k] for k in ("gpu_entropy_to_rgb_host", "gpu_entropy_to_rgb_pinned_host")
+                                 if k in e2e},
+              "device": {"kernel": out["roofline"]["kernel"], "kernel_ms": out["roofline"]["kernel_ms_per_launch"],
+                         "kernel_GBps": out["roofline"]["achieved"], "kernel_hbm_frac": out["roofline"]["frac"],
+                         "images_per_launch": B,
+                         **({"entropy_plus_kernel_ms": round(ge["huffman_ms"] + ge["idct_rgb_ms"], 3),
+                             "huffman_ms": ge["huffman_ms"], "idct_rgb_ms": ge["idct_rgb_ms"]} if ge else {})},
+              "bit_exact_vs_oracle": ok,
+              "cpu": {k: cb[k] for k in ("reference_xjpeg_yuv", "libjpeg_turbo_rgb", "cores") if k in cb}}
+        # one 4K frame alone, like the single-image configs
+        try:
+            lat = configs_bench._pipeline_latency(lib, abi, jpegs[0], nthreads)
+            hl["to_rgb_hbm"]["latency_ms"] = round(lat * 1e3, 3)
+            hl["to_host_pixels"]["plugin"] = configs_bench._plugin(lib, abi, jpegs[0], 10)
+        except Exception as e:                                   # (supplementary)
+            log("bench.py: headline latency leg failed: %s" % e)
+        out["configs"] = dict(headline_4k_420=hl, **cfgs)
+        out["configs"]["note"] = ("Mpixel/s end to end per BASELINE.json config on ONE MI355X, host RAM -> RGB8 in HBM "
+                                  "(to_rgb_hbm) and -> the caller's host pixels (to_host_pixels: the plugin's "
+                                  "decode_image semantics), device-only times, and the reference's xjpeg + "
+                                  "libjpeg-turbo on the same files and the same %d granted cores; %.0f s"
+                                  % (cpu_threads, time.perf_counter() - t_cfg))
+
     if rank == 0:
         print(json.dumps(out), flush=True)
     lib.L.jga_stream_destroy(stream)
-    if world > 1:
-        dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == "__main__":

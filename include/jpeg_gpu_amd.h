@@ -426,6 +426,9 @@ void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on);
  * spinning in hipStreamSynchronize — for pipelines whose lanes outnumber the CPUs they may use
  * (a wait on a hipEventBlockingSync event spins just the same on this stack: csrc/host_wait.h). */
 void jga_huff_set_blocking_waits(jga_huff_batch *b, int on);
+/* prepare() queues its uploads on `copy_stream` (NULL = its own stream) and makes its own stream wait
+ * for them: batches sharing a copy stream upload in the order they were prepared. */
+void jga_huff_set_copy_stream(jga_huff_batch *b, void *copy_stream);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);
 

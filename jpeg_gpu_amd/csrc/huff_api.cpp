@@ -48,6 +48,8 @@ struct jga_huff_batch {
   hipEvent_t ev_begin, ev_zeroed;
   hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
   int blocking_waits;
+  hipStream_t copy_stream;     // uploads go here (in the order they are queued), the caller's stream waits for them
+  hipEvent_t ev_up;
   size_t sub_cap;
   // current batch
   int nimages;
@@ -121,7 +123,8 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_zeroed, hipEventDisableTiming) == hipSuccess
-   && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming) == hipSuccess;
+   && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming) == hipSuccess
+   && hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     jga_fail("huff: allocation failed (%d images, %lld scan bytes)", max_images, max_scan_bytes);
     jga_huff_destroy(b);
@@ -147,6 +150,7 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->ev_begin) (void)hipEventDestroy(b->ev_begin);
   if (b->ev_zeroed) (void)hipEventDestroy(b->ev_zeroed);
   if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
+  if (b->ev_up) (void)hipEventDestroy(b->ev_up);
   delete b;
 }
 
@@ -337,18 +341,23 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->unstuffed_on_device = 1;
   b->shadow.clear();
   hipStream_t st = (hipStream_t)stream;
+  hipStream_t up = b->copy_stream ? b->copy_stream : st;       // (see jga_huff_set_copy_stream)
   const auto t_1 = std::chrono::steady_clock::now();
   if (zero_copy) {
     // the files lie in pinned memory: the DMA engine reads the scans where they are (the host
     // never touches an entropy-coded byte); descriptors + tables go up from the blob as usual
     for (int i = 0; i < n; i++) {
       HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
-       prep[i].avail, hipMemcpyHostToDevice, st));
+       prep[i].avail, hipMemcpyHostToDevice, up));
     }
     HOK(hipMemcpyAsync(b->d_blob + b->off_images, b->h_blob + b->off_images, b->upload_size - b->off_images,
-     hipMemcpyHostToDevice, st));
+     hipMemcpyHostToDevice, up));
   }
-  else HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, st));
+  else HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, up));
+  if (up != st) {
+    HOK(hipEventRecord(b->ev_up, up));
+    HOK(hipStreamWaitEvent(st, b->ev_up, 0));
+  }
   HOK(hipMemsetAsync(b->d_blob + b->off_info, 0xFF, sizeof(hj_unstuff_info)*(size_t)n, st));
   HOK(hipMemsetAsync(b->d_blob + b->off_perr, 0, 4*(size_t)n, st));
   hj_unstuff_args U;
@@ -507,7 +516,12 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   // stream (+16 pad) and the next image's start are never read
   const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
   const auto t_h = std::chrono::steady_clock::now();
-  HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (b->copy_stream && b->copy_stream != (hipStream_t)stream) {
+    HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, b->copy_stream));
+    HOK(hipEventRecord(b->ev_up, b->copy_stream));
+    HOK(hipStreamWaitEvent((hipStream_t)stream, b->ev_up, 0));
+  }
+  else HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, (hipStream_t)stream));
   if (trace) {
     fprintf(stderr, "  prepare: host %.2f ms, hipMemcpyAsync call %.2f ms (%zu MB)\n",
      std::chrono::duration<double, std::milli>(t_h - t_p0).count(),
@@ -532,6 +546,12 @@ JGA_EXPORT void jga_huff_set_device_unstuff(jga_huff_batch *b, int on) { b->devi
 JGA_EXPORT void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on) { b->inputs_pinned = on != 0; }
 // 1: jga_huff_decode's host waits sleep (blocking event) instead of spinning on a core.
 JGA_EXPORT void jga_huff_set_blocking_waits(jga_huff_batch *b, int on) { b->blocking_waits = on != 0; }
+// prepare() queues its uploads on `copy_stream` (a hipStream_t; NULL = on prepare()'s own stream)
+// and makes its own stream wait for them.  Several batches that share one copy stream upload
+// one after the other, in the order they were prepared — the first one's decode starts when ITS
+// bytes have arrived, not when everybody's have (copies on separate streams share the link evenly
+// and all finish together).
+JGA_EXPORT void jga_huff_set_copy_stream(jga_huff_batch *b, void *copy_stream) { b->copy_stream = (hipStream_t)copy_stream; }
 
 // Host threads prepare() may use (0 = up to 64, one per image).
 JGA_EXPORT void jga_huff_set_threads(jga_huff_batch *b, int nthreads) { b->prepare_threads = nthreads; }

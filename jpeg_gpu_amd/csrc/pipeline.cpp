@@ -96,6 +96,14 @@ struct jga_pipeline {
   // pageable or pinned files with the host clean-up, 124-129 with the device's;
   // profiles/r2_host_waits.txt)
   bool offload_cleanup = false;
+  // Uploads of the lanes' groups go through a few shared copy streams, round robin, so that they
+  // cross the link in the order the groups were prepared (two at a time: one stream alone moves
+  // 33 GB/s, two 56): the first group's kernels start when ITS bytes are there.  With a copy
+  // stream per lane the DMA engines share the link evenly, every group of a short job arrives at
+  // the same moment and the device idles until then (JGA_PIPE_COPY_STREAMS=0: the old way).
+  std::vector<hipStream_t> copy_streams;
+  std::atomic<unsigned> copy_next{0};
+  int groups_per_lane = 4, min_group_eq = 4;      // group sizing for jobs too short to reach a steady state
 };
 
 namespace {
@@ -338,6 +346,8 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     jga_huff_set_device_unstuff(l.hb, on_device);
     jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
+    jga_huff_set_copy_stream(l.hb, pl->copy_streams.empty() ? nullptr
+     : pl->copy_streams[pl->copy_next.fetch_add(1)%pl->copy_streams.size()]);
   }
   // A lone image whose Huffman tables do not fit the device lookup format takes the host
   // entropy stage (csrc/entropy.c) instead; everything after it is the same.
@@ -578,6 +588,20 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     if (const char *e = getenv("JGA_PIPE_DEVICE_SLOTS")) pl->dev_slots = atoi(e) > 0 ? atoi(e) : 1;   // tuning knob
     if (pl->dev_slots > (int)pl->lanes.size()) pl->dev_slots = (int)pl->lanes.size();
     if (const char *e = getenv("JGA_PIPE_SPIN")) pl->blocking = atoi(e) == 0;         // tuning knob
+    {
+      int ncopy = getenv("JGA_PIPE_COPY_STREAMS") ? atoi(getenv("JGA_PIPE_COPY_STREAMS")) : 2;   // tuning knob
+      if (ncopy > 8) ncopy = 8;
+      for (int i = 0; i < ncopy; i++) {
+        hipStream_t cs = nullptr;
+        if (!hip_ok(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate")) {
+          jga_pipeline_destroy(pl);
+          return nullptr;
+        }
+        pl->copy_streams.push_back(cs);
+      }
+      if (const char *e = getenv("JGA_PIPE_GROUPS_PER_LANE")) pl->groups_per_lane = atoi(e) > 0 ? atoi(e) : 1;
+      if (const char *e = getenv("JGA_PIPE_MIN_GROUP")) pl->min_group_eq = atoi(e) > 0 ? atoi(e) : 1;
+    }
     for (auto &l : pl->lanes) {
       if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")
        || !hip_ok(hipEventCreateWithFlags(&l.done, hipEventDisableTiming), "hipEventCreate")) {
@@ -607,12 +631,26 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     const int nl = (int)pl->lanes.size();
     int per = pl->cfg.nthreads/nl;
     if (per < 1) per = 1;
-    // bucket the jobs by geometry, in arrival order, `batch` to a group
+    // bucket the jobs by geometry, in arrival order.  `batch` counts 4K frames; smaller frames fill
+    // a group to about the same number of pixels (a launch takes at least one run's latency however
+    // little it decodes).  A job too short to keep every lane busy for several groups (1024 1080p
+    // files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
+    // entropy stage and block decode of different groups overlap: about groups_per_lane groups
+    // per lane, none below min_group_eq frame equivalents.
     std::vector<std::vector<jga_job *>> groups;
     {
+      std::unordered_map<uint64_t, long long> pixels;            // geometry -> pixels of all its jobs
+      std::vector<uint64_t> keys((size_t)n);
+      for (int i = 0; i < n; i++) {
+        keys[(size_t)i] = geometry_key(jobs[i].jpeg, jobs[i].size);
+        if (keys[(size_t)i]) {
+          pixels[keys[(size_t)i]] += (long long)((keys[(size_t)i] >> 48) & 0xffff)*(long long)((keys[(size_t)i] >> 32) & 0xffff);
+        }
+      }
+      const long long frame = 3840ll*2160;
       std::unordered_map<uint64_t, size_t> open;      // geometry -> its group still filling up
       for (int i = 0; i < n; i++) {
-        const uint64_t key = geometry_key(jobs[i].jpeg, jobs[i].size);
+        const uint64_t key = keys[(size_t)i];
         auto it = key ? open.find(key) : open.end();
         if (it == open.end()) {
           groups.emplace_back();
@@ -621,12 +659,13 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
           else { groups.back().push_back(&jobs[i]); continue; }      // unparsable: fails on its own
         }
         groups[it->second].push_back(&jobs[i]);
-        // `batch` counts 4K frames; smaller frames fill a group to about the same number of
-        // pixels (a launch takes at least one run's latency however little it decodes)
         const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
-        long long scale = px > 0 ? (3840ll*2160 + px/2)/px : 1;
-        scale = scale < 1 ? 1 : scale > 16 ? 16 : scale;
-        if ((long long)groups[it->second].size() >= batch*scale) open.erase(it);
+        long long eq = (pixels[key]/frame + (long long)pl->groups_per_lane*nl - 1)/((long long)pl->groups_per_lane*nl);
+        if (eq < pl->min_group_eq) eq = pl->min_group_eq;
+        if (eq > batch) eq = batch;
+        long long cap = px > 0 ? (eq*frame + px/2)/px : eq;          // images of this size per group
+        cap = cap < 1 ? 1 : cap > 16ll*batch ? 16ll*batch : cap;
+        if ((long long)groups[it->second].size() >= cap) open.erase(it);
       }
     }
     for (int t = 0; t < nl; t++) {
@@ -649,6 +688,7 @@ JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {
   if (!pl) return;
   (void)hipSetDevice(pl->cfg.device);
   for (auto &l : pl->lanes) free_lane(l);
+  for (auto cs : pl->copy_streams) (void)hipStreamDestroy(cs);
   for (auto &w : pl->workers) {
     free_slot(w.slots[0]);
     free_slot(w.slots[1]);

@@ -23,7 +23,7 @@ EXPORTED = [
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
     "jga_huff_decode", "jga_huff_prepare_verdict", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
-    "jga_huff_set_threads", "jga_huff_set_device_unstuff", "jga_huff_set_inputs_pinned", "jga_huff_set_blocking_waits",
+    "jga_huff_set_threads", "jga_huff_set_device_unstuff", "jga_huff_set_inputs_pinned", "jga_huff_set_blocking_waits", "jga_huff_set_copy_stream",
     "jga_host_register", "jga_host_unregister",
 ]
 
@@ -117,6 +117,8 @@ L.jga_huff_set_inputs_pinned.argtypes = [_vp, _i]
 L.jga_huff_set_inputs_pinned.restype = None
 L.jga_huff_set_blocking_waits.argtypes = [_vp, _i]
 L.jga_huff_set_blocking_waits.restype = None
+L.jga_huff_set_copy_stream.argtypes = [_vp, _vp]
+L.jga_huff_set_copy_stream.restype = None
 L.jga_host_register.argtypes = [_vp, C.c_size_t]
 L.jga_host_unregister.argtypes = [_vp]
 L.jga_huff_qtabs.argtypes = [_vp]

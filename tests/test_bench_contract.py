@@ -40,6 +40,60 @@ def test_gpus_n_run_plainly_starts_n_ranks():
     assert one["n_gpus"] == 1 and len(one["ranks"]) == 1
 
 
+def test_eight_ranks_dry_launch():
+    """The shape of the driver's 8-GPU run, without the GPUs: eight ranks rendezvous on 127.0.0.1,
+    split the host CPUs among themselves (disjoint shares when there are at least eight) and each
+    reports the share of the CPU grant it will size its threads by."""
+    d = run_bench("--gpus", "8", "--dry-launch", timeout=600)
+    ranks = d["ranks"]
+    assert d["n_gpus"] == 8 and [r["rank"] for r in ranks] == list(range(8))
+    assert len({r["pid"] for r in ranks}) == 8
+    allowed = set(os.sched_getaffinity(0))
+    for r in ranks:
+        assert r["cpus"] and set(r["cpus"]) <= allowed and r["cpu_budget"] >= 1
+    if len(allowed) >= 8:
+        seen = set()
+        for r in ranks:
+            assert not (seen & set(r["cpus"]))
+            seen |= set(r["cpus"])
+
+
+def test_inputs_are_synthesised_once_per_box(tmp_path, synth):
+    """make_inputs(): rank r makes the files whose index is r modulo the world size into a cache
+    keyed by recipe + seed, every rank reads them all in its own rotation; a second call makes
+    nothing.  (One process plays both ranks here: the barrier is a no-op.)"""
+    import bench
+
+    class NoComm:
+        def barrier(self):
+            pass
+    os.environ["JGA_BENCH_CACHE"] = str(tmp_path)
+    saved = bench.W, bench.H
+    bench.W, bench.H = 64, 48
+    try:
+        made = []
+        real = synth.synthetic_jpeg
+
+        class Spy:
+            SAMPLING = synth.SAMPLING
+
+            @staticmethod
+            def synthetic_jpeg(*a, **k):
+                made.append(k.get("seed"))
+                return real(*a, **k)
+        with pytest.raises(FileNotFoundError):                         # rank 1 of 2 makes seeds 1235, 1237 —
+            bench.make_inputs(Spy, 4, 1, 2, 2, NoComm())               # and finds rank 0's share missing
+        assert sorted(made) == [1235, 1237] and len(os.listdir(tmp_path)) == 2
+        f0, note = bench.make_inputs(Spy, 4, 0, 2, 2, NoComm())        # rank 0 makes the other two
+        assert sorted(made) == [1234, 1235, 1236, 1237] and "once per box" in note
+        assert sorted(f0) == sorted(real(64, 48, "420", 90, seed=s) for s in (1234, 1235, 1236, 1237))
+        f1, _ = bench.make_inputs(Spy, 4, 1, 2, 2, NoComm())           # everything cached now
+        assert len(made) == 4 and sorted(f1) == sorted(f0) and f1 != f0    # same files, another rotation
+    finally:
+        bench.W, bench.H = saved
+        del os.environ["JGA_BENCH_CACHE"]
+
+
 def test_rank_cpu_shares():
     """Ranks on one NUMA node split that node's cores, SMT siblings together; without topology
     information they split everything evenly."""
@@ -66,11 +120,41 @@ def test_rank_cpu_shares():
 def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     d = run_bench("--steps", "2", "--warmup", "1", "--batch", "4", "--group", "2", "--distinct", "4", "--lanes", "2",
                   "--prewarm", "0", "--kernel-reps", "3", "--kernel-batch", "4", "--cpu-rounds", "1", "--cpu-frames", "1",
-                  "--no-e2e", "--no-pack", "--no-other", "--no-gpu-entropy")
+                  "--no-e2e", "--no-pack", "--no-other", "--no-gpu-entropy", "--quick-configs",
+                  "--no-measure-traffic", timeout=1500)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
-              "cpu_baseline"):
+              "cpu_baseline", "value_pageable", "value_pinned_ingest", "per_rank", "configs"):
         assert k in d, k
+    # `value` is the conservative variant (ordinary pageable files); the pinned-ingest rate sits beside it
+    assert d["value"] == d["value_pageable"] and d["value_pinned_ingest"] > 0
+    # EVERY image of the timed region kept its pixels and was compared with the oracle
+    assert d["config"]["images_verified"] == d["config"]["images_timed_per_gpu"] == 8
+    assert d["config"]["images_verified_pinned_ingest"] == 8
+    pr = d["per_rank"]
+    assert len(pr["ranks"]) == 1 and pr["ranks"][0]["rank"] == 0 and pr["ranks"][0]["Mpixel_s"] > 0
+    assert pr["min_Mpixel_s"] == pr["max_Mpixel_s"] == pr["ranks"][0]["Mpixel_s"]
+    for key in ("gpu", "numa_node", "cpus", "ms_per_step", "scan_cleanup", "images_verified"):
+        assert key in pr["ranks"][0], key
+    # every BASELINE.json config beside its CPU path
+    cf = d["configs"]
+    assert {"headline_4k_420", "config2_1080p_420_one_image", "config3_4k_444", "config4_batch_1080p_420",
+            "config5_8k_420_dri"} <= set(cf)
+    for name in ("config2_1080p_420_one_image", "config3_4k_444", "config5_8k_420_dri"):
+        e = cf[name]
+        assert e["bit_exact_vs_oracle"] is True, name
+        assert e["to_rgb_hbm"]["latency_ms"] > 0 and e["to_rgb_hbm"]["Mpixel_s"] > 0
+        assert e["to_host_pixels"]["ms_per_frame"] > 0
+        assert e["device"]["kernel_ms"] > 0 and 0 < e["device"]["kernel_hbm_frac"] < 1
+        assert e["device"]["one_frame"]["ms"] > 0
+        assert e["cpu"]["cores"] >= 1 and "libjpeg_turbo_rgb" in e["cpu"]
+    e4 = cf["config4_batch_1080p_420"]
+    assert e4["bit_exact_vs_oracle"] is True
+    assert any(k.startswith("all_") for k in e4["to_rgb_hbm"]) and "rank3_shard_of_8" in e4["to_rgb_hbm"]
+    for v in e4["to_rgb_hbm"].values():
+        assert v["pageable_files"]["Mpixel_s"] > 0 and v["pinned_files"]["Mpixel_s"] > 0
+    hl = cf["headline_4k_420"]
+    assert hl["to_rgb_hbm"]["Mpixel_s"] == d["value"] and hl["device"]["kernel_hbm_frac"] == d["roofline"]["frac"]
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
     assert d["unit"] == "Mpixel/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
@@ -97,6 +181,42 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
 
 
 @pytest.mark.gpu
+def test_one_wrong_byte_in_the_timed_regions_outputs_fails_the_bench(gpu):
+    """The pixels of every image of the timed region are compared with the oracle's: flip one byte of
+    one kept output (JGA_BENCH_CORRUPT = slot) and the run must exit non-zero, saying which job."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["JGA_BENCH_CORRUPT"] = "5"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--batch", "4",
+                        "--group", "2", "--distinct", "4", "--lanes", "2", "--prewarm", "0", "--no-cpu", "--no-e2e",
+                        "--no-pack", "--no-other", "--no-gpu-entropy", "--no-configs", "--no-measure-traffic"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert "differ from the oracle" in r.stderr and "job 5" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]      # no line is printed
+
+
+@pytest.mark.gpu
+def test_eight_ranks_sharing_the_one_gpu(gpu):
+    """The driver's N = 8 launch on a one-GPU box (JGA_BENCH_SHARE_GPUS: the ranks share the device and
+    talk over gloo; the rates mean nothing, the code path is the 8-rank one): inputs synthesised once
+    per box, every rank verifies its own images, and the line carries each rank's own numbers."""
+    os.environ["JGA_BENCH_SHARE_GPUS"] = "1"
+    try:
+        d = run_bench("--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "2", "--group", "2", "--distinct", "8",
+                      "--lanes", "1", "--prewarm", "0", "--kernel-reps", "2", "--kernel-batch", "2", "--no-e2e",
+                      timeout=1500)
+    finally:
+        del os.environ["JGA_BENCH_SHARE_GPUS"]
+    assert d["n_gpus"] == 8 and d["config"]["images_verified"] == 2
+    assert d["config"]["ranks_talk_over"] == "gloo" and "once per box" in d["config"]["inputs"]
+    ranks = d["per_rank"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and all(r["images_verified"] == 4 for r in ranks)
+    assert d["per_rank"]["min_Mpixel_s"] <= d["per_rank"]["max_Mpixel_s"]
+    assert abs(d["value"] - 8 * 2 * 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    assert "cpu_baseline" not in d and "configs" not in d
+
+
+@pytest.mark.gpu
 def test_two_ranks_started_by_bench_itself(gpu):
     """`python bench.py --gpus 2` with nobody's torchrun around it: two ranks, each with its own
     pipeline and its own share of the host cores, max-over-ranks timing, pixels of both summed.
@@ -115,6 +235,8 @@ def test_two_ranks_started_by_bench_itself(gpu):
     assert "cpu_baseline" not in d                                 # N = 1 only
     e = d["e2e"]
     assert e["north_star_host_huffman_to_rgb_hbm"]["ok"] and e["pageable_files_to_rgb_hbm"]["ok"]
+    assert e["pageable_files_to_rgb_hbm"]["value"] == d["value"] and d["config"]["images_verified"] == 8
+    assert [r["rank"] for r in d["per_rank"]["ranks"]] == [0, 1] and d["config"]["ranks_talk_over"] == "gloo"
     pin = d["config"]["cpu_pinning"]
     assert pin and 1 <= pin["cpus"] <= len(os.sched_getaffinity(0))
 

@@ -1,37 +1,69 @@
-"""BASELINE.json configs 2-5 on one MI355X (parity is in tests/; this prints rates).
-Usage: python tools/configs_bench.py"""
+"""Every BASELINE.json config on one MI355X, each beside its CPU path (bench.py's `configs` object;
+run alone: `python tools/configs_bench.py` prints the same object, one config per line).
+
+For each config (BASELINE.json `configs` 2-5; the headline 4K 4:2:0 entry is filled in by bench.py
+from its own legs):
+  to_rgb_hbm      JPEG file bytes in host RAM -> RGB8 in HBM through the product's batch decoder
+                  (jga_pipeline, transport 2): `latency_ms` of ONE frame with nothing else in flight
+                  (best of a few), and `Mpixel_s` of a stream of such frames (config 4: the batch
+                  itself, all 1024 files on one GPU, and rank 3's 128-file shard of an 8-GPU job)
+  to_host_pixels  the plugin's semantics (src/jpeg_gpu.c:1231-1237: reset -> header -> decode_image(RGB),
+                  pixels copied back into img->pixels): ms per frame and Mpixel/s
+  device          scan bytes resident in HBM -> GPU Huffman + fused kernel (no host, no PCIe): ms; the
+                  fused kernel alone on resident planes: ms, GB/s of algorithmic bytes, fraction of 8 TB/s
+  bit_exact_vs_oracle   every distinct file's pipeline output against the oracle's pixels
+  cpu             the reference's xjpeg + dct.c (compiled from its sources) and libjpeg-turbo on the same
+                  file(s) and the same granted cores, Mpixel/s
+"""
 import ctypes as C
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import numpy as np  # noqa: E402
-from jpeg_gpu_amd import abi, lib, synth  # noqa: E402
+for p in (ROOT, os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBPS = 8000.0
 
 
-def device_stage(jpegs, n, reps=20):
-    """coefficient planes resident -> RGB (HIP events), and scan bytes resident -> RGB."""
+def _kernel_alone(lib, np, jpegs, n, reps):
+    """Coefficient planes of n images resident -> RGB, HIP events on the launch stream."""
     hdr, g = lib.geom_of(jpegs[0])
     cs = (g.coef_shorts * 2 + 255) // 256 * 128
     os_ = (g.rgb_bytes + 255) // 256 * 256
     dc, do, dq = lib.DeviceBuffer(cs * 2 * n), lib.DeviceBuffer(os_ * n), lib.DeviceBuffer(384 * n)
+    coefs = [lib.entropy_decode(j, g) for j in jpegs[:min(len(jpegs), 6)]]
     for i in range(n):
-        dc.upload(lib.entropy_decode(jpegs[i % len(jpegs)], g), offset=i * cs * 2)
+        dc.upload(coefs[i % len(coefs)], offset=i * cs * 2)
     dq.upload(np.tile(lib.qtab_of(hdr).reshape(-1), n))
     ms = C.c_float()
-    for r in (3, reps):
-        lib.check(lib.L.jga_time_idct_batch(C.byref(g), n, dc.ptr, cs, dq.ptr, 1, do.ptr, os_, 1, r,
-                                            None, C.byref(ms)))
-    t_k = ms.value * 1e-3
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:                       # clocks
+        lib.check(lib.L.jga_time_idct_batch(C.byref(g), n, dc.ptr, cs, dq.ptr, 1, do.ptr, os_, 1, 5, None, C.byref(ms)))
+    lib.check(lib.L.jga_time_idct_batch(C.byref(g), n, dc.ptr, cs, dq.ptr, 1, do.ptr, os_, 1, reps, None, C.byref(ms)))
+    dc.free(); do.free(); dq.free()
+    ab = n * (g.coef_blocks * 128 + g.rgb_bytes)
+    return {"kernel": lib.L.jga_kernel_name(C.byref(g), 1).decode(), "kernel_ms": round(ms.value, 4),
+            "kernel_GBps": round(ab / ms.value / 1e6, 1),
+            "kernel_hbm_frac": round(ab / ms.value / 1e6 / HBM_PEAK_GBPS, 4), "images_per_launch": n}
+
+
+def _device_only(lib, jpegs, n, reps=5):
+    """Scan bytes resident in HBM -> GPU Huffman -> fused kernel -> RGB in HBM, best of reps."""
+    _, g = lib.geom_of(jpegs[0])
+    cs = (g.coef_shorts * 2 + 255) // 256 * 128
+    os_ = (g.rgb_bytes + 255) // 256 * 256
+    dc, do, dq = lib.DeviceBuffer(cs * 2 * n), lib.DeviceBuffer(os_ * n), lib.DeviceBuffer(384 * n)
     jobs = [jpegs[i % len(jpegs)] for i in range(n)]
     hb = lib.HuffBatch(n, sum(map(len, jobs)) + 4096 * n)
     hb.prepare(jobs)
     lib.check(lib.L.jga_stream_sync(None))
     dq.upload(hb.qtabs())
-    best = 1e9
-    for _ in range(5):
+    best, rounds = 1e9, 0
+    for _ in range(reps + 1):
         t0 = time.perf_counter()
         rounds = hb.decode(dc.ptr, cs)
         lib.check(lib.L.jga_idct_rgb_batch(C.byref(g), n, dc.ptr, cs, dq.ptr, 1, do.ptr, os_, None))
@@ -39,66 +71,172 @@ def device_stage(jpegs, n, reps=20):
         best = min(best, time.perf_counter() - t0)
     hb.close()
     dc.free(); do.free(); dq.free()
-    px = n * g.width * g.height
-    ab = n * (g.coef_blocks * 128 + g.rgb_bytes)
-    return {"kernel_ms": round(t_k * 1e3, 4), "kernel_Gpx_s": round(px / t_k / 1e9, 1),
-            "kernel_GBps": round(ab / t_k / 1e9, 1),
-            "gpu_entropy_plus_kernel_ms": round(best * 1e3, 3),
-            "gpu_entropy_plus_kernel_Gpx_s": round(px / best / 1e9, 2), "sync_rounds": rounds}
+    return {"ms": round(best * 1e3, 3), "images": n, "sync_rounds": rounds,
+            "Mpixel_s": round(n * g.width * g.height / best / 1e6, 1)}
 
 
-def plugin_latency(jpeg, reps=10):
+def _plugin(lib, abi, jpeg, reps):
+    """reset -> header -> decode_image(RGB) per frame, pixels in img->pixels (host)."""
     with lib.Decoder(jpeg) as d:
         d.read_header()
         d.init_image()
         d.decode(abi.JPEG_DECODE_RGB)
+        px = d.header.width * d.header.height
         t0 = time.perf_counter()
         for _ in range(reps):
             d.reset()
             d.read_header()
             d.decode(abi.JPEG_DECODE_RGB)
-        return (time.perf_counter() - t0) / reps
+        dt = (time.perf_counter() - t0) / reps
+    return {"ms_per_frame": round(dt * 1e3, 3), "Mpixel_s": round(px / dt / 1e6, 1),
+            "note": "plugin decode_image(RGB): GPU entropy stage + fused kernel + D2H into img->pixels"}
 
 
-def pipeline(jobs, transport, **kw):
-    pl = lib.Pipeline(device=0, out=abi.JPEG_DECODE_RGB, transport=transport, **kw)
-    pl.run(jobs)                                  # warm: every lane sized for its groups
-    t0 = time.perf_counter()
-    rc, _ = pl.run(jobs)
-    dt = time.perf_counter() - t0
+def _pipeline_stream(lib, abi, np, orc, jpegs, order, nthreads, group, lanes, reps=2, pinned=False):
+    """`order` = indices into jpegs, one job each.  Every output is kept (slices of one device
+    buffer) and compared with the oracle's pixels of its file afterwards.  -> (best seconds, ok)."""
+    _, g = lib.geom_of(jpegs[0])
+    n = len(order)
+    ostride = (g.rgb_bytes + 255) // 256 * 256
+    out = lib.DeviceBuffer(ostride * n)
+    pins = [lib.PinnedBytes(j) for j in jpegs] if pinned else None
+    src = [p.array for p in pins] if pinned else jpegs
+    pl = lib.Pipeline(device=0, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False, transport=2,
+                      batch=group, depth=lanes)
+    jobs = lib.Pipeline.make_jobs([src[i] for i in order], dev_outs=[out.ptr + k * ostride for k in range(n)],
+                                  pinned=pinned)
+    ok = pl.run_jobs(jobs) == 0                                   # warm: every lane sized for its groups
+    best = 1e9
+    for _ in range(reps):
+        lib.check(lib.L.jga_stream_sync(None))
+        t0 = time.perf_counter()
+        ok = pl.run_jobs(jobs) == 0 and ok
+        best = min(best, time.perf_counter() - t0)
     pl.close()
-    assert rc == 0
-    return dt
+    ok = ok and all(j.status == 0 for j in jobs)
+    with ThreadPoolExecutor(max_workers=max(1, min(16, nthreads))) as ex:
+        want = list(ex.map(lambda j: orc.decode_rgb(j)[1].reshape(-1), jpegs))
+    for k, i in enumerate(order):
+        if not ok:
+            break
+        ok = bool(np.array_equal(out.download(g.rgb_bytes, offset=k * ostride), want[i]))
+    out.free()
+    if pins:
+        for p in pins:
+            p.free()
+    return best, ok, sum(j.h2d_bytes for j in jobs) // n
 
 
-def host_entropy_ms(jpeg):
+def _pipeline_latency(lib, abi, jpeg, nthreads, reps=8):
+    """One frame through the batch decoder with nothing else in flight: wall time of
+    jga_pipeline_run (host parse, upload, GPU entropy stage, fused kernel, pixels in HBM)."""
     _, g = lib.geom_of(jpeg)
-    lib.entropy_decode(jpeg, g)
-    t0 = time.perf_counter()
-    lib.entropy_decode(jpeg, g)
-    return (time.perf_counter() - t0) * 1e3
+    out = lib.DeviceBuffer(g.rgb_bytes)
+    pl = lib.Pipeline(device=0, nthreads=max(1, min(nthreads, 4)), out=abi.JPEG_DECODE_RGB, copy_back=False,
+                      transport=2, batch=1, depth=1)
+    jobs = lib.Pipeline.make_jobs([jpeg], dev_outs=[out.ptr])
+    pl.run_jobs(jobs)
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        pl.run_jobs(jobs)
+        best = min(best, time.perf_counter() - t0)
+    pl.close()
+    out.free()
+    return best
 
 
-print("config 2: 1920x1080 4:2:0 q90, one image")
-j = [synth.synthetic_jpeg(1920, 1080, "420", quality=90, seed=1234)]
-print("  ", device_stage(j, 1), "| plugin decode_image(RGB) incl. D2H %.2f ms" % (plugin_latency(j[0]) * 1e3),
-      "| host entropy stage %.1f ms" % host_entropy_ms(j[0]))
-print("config 3: 3840x2160 4:4:4 q90, one image")
-j = [synth.synthetic_jpeg(3840, 2160, "444", quality=90, seed=1234)]
-print("  ", device_stage(j, 1), "| plugin decode_image(RGB) incl. D2H %.2f ms" % (plugin_latency(j[0]) * 1e3),
-      "| host entropy stage %.1f ms" % host_entropy_ms(j[0]))
-print("config 4: 1024 x 1080p 4:2:0 (seeds 0..15 repeated), ONE GPU takes all 1024 / its 128-image shard")
-j = [synth.synthetic_jpeg(1920, 1080, "420", quality=90, seed=s) for s in range(16)]
-print("   1024 resident:", device_stage(j, 1024, reps=5))
-print("    128 resident:", device_stage(j, 128, reps=10))
-jobs = [j[i % 16] for i in range(1024)]
-px = 1024 * 1920 * 1080
-for tr, kw in ((2, dict(nthreads=96, batch=32, depth=4)), (0, dict(nthreads=48))):
-    dt = pipeline(jobs, tr, **kw)
-    print("   pipeline transport %d: JPEG in host RAM -> RGB in HBM, 1024 images %.1f ms = %.1f Gpixel/s"
-          % (tr, dt * 1e3, px / dt / 1e9))
-print("config 5: 7680x4320 4:2:0 q90, DRI = one MCU row (480 MCUs)")
-j = [synth.synthetic_jpeg(7680, 4320, "420", quality=90, seed=1234, restart_interval=-1)]
-print("   1 image :", device_stage(j, 1), "| host entropy stage %.1f ms" % host_entropy_ms(j[0]),
-      "| plugin decode_image(RGB) incl. D2H %.2f ms" % (plugin_latency(j[0], 5) * 1e3))
-print("   8 images:", device_stage(j, 8, reps=5))
+def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_rounds=2, quick=False, log=None,
+                cpu_affinity=None):
+    """-> {"config2_...": {...}, ...} (BASELINE.json configs 2, 3, 4, 5).  nthreads: host threads of
+    the pipeline; cpu_threads: frame loops of the CPU paths (the granted CPUs)."""
+    import numpy as np
+    import oracle
+    import cpu_paths
+    from jpeg_gpu_amd import abi, lib, shard, synth
+    orc = oracle.Oracle()
+    say = log or (lambda *a: None)
+    out = {}
+
+    def cpu_rates(files, w, h, frames):
+        """The CPU paths on the whole CPU grant (the pipeline legs run on the rank's own cores)."""
+        mine = os.sched_getaffinity(0)
+        if cpu_affinity:
+            os.sched_setaffinity(0, cpu_affinity)
+        try:
+            return dict(cpu_paths.time_paths(files, w, h, cpu_threads, frames, cpu_rounds, single=False),
+                        cores=cpu_threads)
+        finally:
+            os.sched_setaffinity(0, mine)
+
+    def single(key, what, w, h, samp, ri, stream_n, kernel_n):
+        t_cfg = time.perf_counter()
+        n_files = 2 if quick else 4
+        files = [synth.synthetic_jpeg(w, h, samp, quality=90, seed=1234 + i, restart_interval=ri)
+                 for i in range(n_files)]
+        px = w * h
+        lat = _pipeline_latency(lib, abi, files[0], nthreads)
+        order = [i % n_files for i in range(stream_n)]
+        dt, ok, h2d = _pipeline_stream(lib, abi, np, orc, files, order, nthreads, group, lanes)
+        e = {"what": what, "file_bytes": len(files[0]),
+             "to_rgb_hbm": {"latency_ms": round(lat * 1e3, 3), "latency_Mpixel_s": round(px / lat / 1e6, 1),
+                            "stream_images": stream_n, "Mpixel_s": round(stream_n * px / dt / 1e6, 1),
+                            "h2d_bytes_per_image": int(h2d)},
+             "to_host_pixels": _plugin(lib, abi, files[0], 3 if quick else 10),
+             "device": dict(_kernel_alone(lib, np, files, kernel_n, 5 if quick else 20),
+                            one_frame=_device_only(lib, files, 1, 2 if quick else 5)),
+             "bit_exact_vs_oracle": ok,
+             "cpu": cpu_rates(files, w, h, cpu_frames)}
+        out[key] = e
+        say("configs: %s done in %.1f s" % (key, time.perf_counter() - t_cfg))
+
+    single("config2_1080p_420_one_image", "1920x1080 4:2:0 q90, one image (BASELINE.json configs[1])",
+           1920, 1080, "420", 0, 16 if quick else 256, 4 if quick else 128)
+    single("config3_4k_444", "3840x2160 4:4:4 q90 (configs[2]: no-upsample path)",
+           3840, 2160, "444", 0, 8 if quick else 96, 2 if quick else 24)
+
+    # config 4: a batch of 1024 x 1080p 4:2:0 sharded over 8 GPUs — here ONE GPU takes all of it, and
+    # rank 3's contiguous 128-file shard (what one GPU of the 8 gets)
+    t_cfg = time.perf_counter()
+    n4 = 64 if quick else 1024
+    distinct = 8 if quick else 16
+    files = [synth.synthetic_jpeg(1920, 1080, "420", quality=90, seed=s) for s in range(distinct)]
+    px = 1920 * 1080
+    e4 = {"what": "batch of %d x 1920x1080 4:2:0 q90 (configs[3]; %d distinct files repeated)" % (n4, distinct),
+          "file_bytes": len(files[0])}
+    oks = []
+    for name, order in (("all_%d_on_one_gpu" % n4, list(range(n4))),
+                        ("rank3_shard_of_8", list(shard.shard_range(n4, 3, 8)))):
+        for kind, pinned in (("pageable_files", False), ("pinned_files", True)):
+            dt, ok, h2d = _pipeline_stream(lib, abi, np, orc, files, [i % distinct for i in order], nthreads,
+                                           group, lanes, reps=3, pinned=pinned)
+            oks.append(ok)
+            e4.setdefault("to_rgb_hbm", {}).setdefault(name, {})[kind] = {
+                "images": len(order), "ms": round(dt * 1e3, 2),
+                "Mpixel_s": round(len(order) * px / dt / 1e6, 1), "h2d_bytes_per_image": int(h2d)}
+    e4["to_host_pixels"] = _plugin(lib, abi, files[0], 3 if quick else 10)
+    e4["device"] = dict(_kernel_alone(lib, np, files, n4, 3 if quick else 5),
+                        whole_batch=_device_only(lib, files, n4, 1 if quick else 3),
+                        shard_128=_device_only(lib, files, min(n4, 128), 1 if quick else 3))
+    e4["bit_exact_vs_oracle"] = all(oks)
+    e4["cpu"] = cpu_rates(files, 1920, 1080, max(cpu_frames, 4))
+    out["config4_batch_1080p_420"] = e4
+    say("configs: config4 done in %.1f s" % (time.perf_counter() - t_cfg))
+
+    single("config5_8k_420_dri", "7680x4320 4:2:0 q90, DRI = one MCU row (configs[4]: GPU-parallel Huffman variant)",
+           7680, 4320, "420", -1, 4 if quick else 32, 2 if quick else 8)
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    import __graft_entry__
+    __graft_entry__.build()
+    from jpeg_gpu_amd import shard
+    quota = shard.cpu_quota()
+    cpus = len(os.sched_getaffinity(0))
+    budget = shard.rank_cpu_budget(cpus, 1, quota)
+    nthreads = min(cpus, max(8, budget + budget // 2)) if quota else max(1, min(cpus, 96))
+    res = run_configs(nthreads, budget, quick="--quick" in sys.argv, log=lambda *a: print(*a, file=sys.stderr, flush=True))
+    for k, v in res.items():
+        print(k, json.dumps(v))
