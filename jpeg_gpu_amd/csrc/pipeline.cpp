@@ -85,6 +85,7 @@ struct jga_pipeline {
   std::mutex dev_mutex;
   std::condition_variable dev_cv;
   int dev_slots = 3;
+  int dev_capacity = 0, dev_free = 0;          // dev_slots x batch frame equivalents (device_turn)
   // Lanes wait for the device several times per group; spinning in hipStreamSynchronize would
   // hold a core each, and a container may grant fewer cores than there are lanes: they poll and
   // sleep instead (host_wait.h; JGA_PIPE_SPIN=1 restores the spinning).
@@ -287,21 +288,28 @@ bool grow(void **p, long long *cap, long long want, bool pinned) {
   return true;
 }
 
-struct device_turn {                 // one of jga_pipeline::dev_slots, held for a group's kernels
+// A share of the device, held for a group's kernels.  The budget is counted in 4K-frame
+// equivalents — dev_slots full-size groups (dev_slots x cfg.batch frames): the small groups a short
+// job is cut into are bound by the latency of their launches, not by the device's throughput,
+// so more of them may run side by side (a 128-file 1080p shard: eight groups of 16 files, all at
+// once, 5.1 -> 3.x ms).
+struct device_turn {
   jga_pipeline *pl;
-  bool held = false;
+  int held = 0;
   explicit device_turn(jga_pipeline *p) : pl(p) {}
-  void take() {
+  void take(int units) {
+    if (units < 1) units = 1;
+    if (units > pl->dev_capacity) units = pl->dev_capacity;
     std::unique_lock<std::mutex> lk(pl->dev_mutex);
-    pl->dev_cv.wait(lk, [this] { return pl->dev_slots > 0; });
-    pl->dev_slots--;
-    held = true;
+    pl->dev_cv.wait(lk, [this, units] { return pl->dev_free >= units; });
+    pl->dev_free -= units;
+    held = units;
   }
   void give() {
     if (!held) return;
-    { std::lock_guard<std::mutex> lk(pl->dev_mutex); pl->dev_slots++; }
-    pl->dev_cv.notify_one();
-    held = false;
+    { std::lock_guard<std::mutex> lk(pl->dev_mutex); pl->dev_free += held; }
+    pl->dev_cv.notify_all();
+    held = 0;
   }
   ~device_turn() { give(); }
 };
@@ -398,7 +406,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     return EXIT_FAILURE;
   }
   device_turn turn(pl);
-  turn.take();                        // (the group's upload is already in flight)
+  turn.take((int)(((long long)m*g.width*g.height + 3840ll*2160 - 1)/(3840ll*2160)));   // (the group's upload is already in flight)
   const auto t_b = std::chrono::steady_clock::now();
   const double c_b = trace ? thread_cpu_ms() : 0.0;
   if (host_entropy) {
@@ -587,9 +595,10 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->lanes.resize(pl->cfg.depth > 0 ? pl->cfg.depth : 6);
     if (const char *e = getenv("JGA_PIPE_DEVICE_SLOTS")) pl->dev_slots = atoi(e) > 0 ? atoi(e) : 1;   // tuning knob
     if (pl->dev_slots > (int)pl->lanes.size()) pl->dev_slots = (int)pl->lanes.size();
+    pl->dev_capacity = pl->dev_free = pl->dev_slots*(pl->cfg.batch > 0 ? pl->cfg.batch : 48);
     if (const char *e = getenv("JGA_PIPE_SPIN")) pl->blocking = atoi(e) == 0;         // tuning knob
     {
-      int ncopy = getenv("JGA_PIPE_COPY_STREAMS") ? atoi(getenv("JGA_PIPE_COPY_STREAMS")) : 2;   // tuning knob
+      int ncopy = getenv("JGA_PIPE_COPY_STREAMS") ? atoi(getenv("JGA_PIPE_COPY_STREAMS")) : 0;   // (measured: profiles/r3_pipe_sweep.txt)
       if (ncopy > 8) ncopy = 8;
       for (int i = 0; i < ncopy; i++) {
         hipStream_t cs = nullptr;
