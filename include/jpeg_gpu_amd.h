@@ -314,6 +314,14 @@ int   jga_set_device(int dev);
 int   jga_device_pci_bus_id(int dev, char *buf, int len);
 void *jga_stream_create(void);
 void  jga_stream_destroy(void *stream);
+/* jga_idct_rgb_batch / jga_idct_yuv_batch with coefficient 0 of every block taken from d_dc
+ * (jga_huff_decode_split's array; NULL = from the planes, i.e. the plain calls). */
+int jga_idct_rgb_batch_dc(const jga_geom *g, int nimages, const short *d_coef,
+ long long coef_stride, const short *d_dc, long long dc_stride, const unsigned short *d_qtab,
+ int dequant_on_device, unsigned char *d_rgb, long long rgb_stride, void *stream);
+int jga_idct_yuv_batch_dc(const jga_geom *g, int nimages, const short *d_coef,
+ long long coef_stride, const short *d_dc, long long dc_stride, const unsigned short *d_qtab,
+ int dequant_on_device, unsigned char *d_yuv, long long yuv_stride, void *stream);
 /* Time `reps` back-to-back launches of the rgb (or yuv) batch kernel with HIP
  * events on `stream`; returns average milliseconds per launch in *ms. */
 int jga_time_idct_batch(const jga_geom *g, int nimages, const short *d_coef,
@@ -393,6 +401,13 @@ int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *jpegs,
  const int *sizes, int n, jga_geom *geom, void *stream);
 int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  void *stream);
+/* The same decode for a caller that runs a block-decode kernel next: the planes' DC positions are
+ * left holding the DC DIFFERENCES (src/xjpeg.c:480 not applied), the DC values arrive in d_dc —
+ * image i at d_dc + i*dc_stride, one int16 per 128-byte slot of the image's coefficient buffer
+ * (dc_stride >= coef_shorts/64) — for jga_idct_rgb_batch_dc / jga_idct_yuv_batch_dc.  Saves the
+ * strided 2-byte pass over the planes that puts them in place. */
+int jga_huff_decode_split(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ short *d_dc, long long dc_stride, void *stream);
 /* Per-image outcome of the last jga_huff_prepare (also after it failed): 0 usable, 1 not
  * (damaged or unsupported file), 2 a valid file the device format cannot hold — Huffman
  * tables with too many long-code groups, or a frame beyond the kernels' 32-bit bit

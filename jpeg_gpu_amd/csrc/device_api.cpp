@@ -99,12 +99,26 @@ JGA_EXPORT int jga_device_count(void) {
   return n;
 }
 
+static int check_dc(const jga_geom *g, const short *d_dc, long long dc_stride) {
+  if (d_dc && dc_stride < g->coef_shorts/64) return jga_fail("dc_stride too small");
+  return EXIT_SUCCESS;
+}
+
 JGA_EXPORT int jga_idct_rgb_batch(const jga_geom *g, int nimages,
  const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
  int dequant_on_device, unsigned char *d_rgb, long long rgb_stride,
  void *stream) {
+  return jga_idct_rgb_batch_dc(g, nimages, d_coef, coef_stride, NULL, 0, d_qtab, dequant_on_device,
+   d_rgb, rgb_stride, stream);
+}
+
+JGA_EXPORT int jga_idct_rgb_batch_dc(const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const short *d_dc, long long dc_stride,
+ const unsigned short *d_qtab, int dequant_on_device, unsigned char *d_rgb, long long rgb_stride,
+ void *stream) {
   jga_kparams P;
   int rc;
+  if (check_dc(g, d_dc, dc_stride) != EXIT_SUCCESS) return EXIT_FAILURE;
   if (g->nplanes == 3 && !g->plane[0].xdec && !g->plane[0].ydec
    && (g->plane[1].xdec != g->plane[2].xdec || g->plane[1].ydec != g->plane[2].ydec)) {
     // Cb and Cr decimated differently (res/unyuv.fs.glsl takes u_xdec/u_ydec and v_xdec/v_ydec
@@ -116,7 +130,7 @@ JGA_EXPORT int jga_idct_rgb_batch(const jga_geom *g, int nimages,
     hipStream_t st = (hipStream_t)stream;
     if (rgb_stride < g->rgb_bytes) return jga_fail("rgb_stride too small");
     HIP_TRY(hipMalloc((void **)&tmp, (size_t)ystride*(size_t)nimages));
-    rc = jga_idct_yuv_batch(g, nimages, d_coef, coef_stride, d_qtab, dequant_on_device, tmp, ystride, stream);
+    rc = jga_idct_yuv_batch_dc(g, nimages, d_coef, coef_stride, d_dc, dc_stride, d_qtab, dequant_on_device, tmp, ystride, stream);
     if (rc == EXIT_SUCCESS) rc = jga_yuv_rgb_batch(g, nimages, tmp, ystride, d_rgb, rgb_stride, stream);
     {
       const hipError_t e = hipStreamSynchronize(st);
@@ -129,6 +143,8 @@ JGA_EXPORT int jga_idct_rgb_batch(const jga_geom *g, int nimages,
    dequant_on_device, d_rgb, rgb_stride, 1) != EXIT_SUCCESS) {
     return EXIT_FAILURE;
   }
+  P.dc = (const int16_t *)d_dc;
+  P.dc_stride = dc_stride;
   rc = jga_launch_rgb(&P, g->plane[1].xdec, g->plane[1].ydec, staged_loads(), stream);
   if (rc) return jga_fail("RGB kernel launch failed (HIP error %d)", rc);
   return EXIT_SUCCESS;
@@ -138,12 +154,23 @@ JGA_EXPORT int jga_idct_yuv_batch(const jga_geom *g, int nimages,
  const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
  int dequant_on_device, unsigned char *d_yuv, long long yuv_stride,
  void *stream) {
+  return jga_idct_yuv_batch_dc(g, nimages, d_coef, coef_stride, NULL, 0, d_qtab, dequant_on_device,
+   d_yuv, yuv_stride, stream);
+}
+
+JGA_EXPORT int jga_idct_yuv_batch_dc(const jga_geom *g, int nimages,
+ const short *d_coef, long long coef_stride, const short *d_dc, long long dc_stride,
+ const unsigned short *d_qtab, int dequant_on_device, unsigned char *d_yuv, long long yuv_stride,
+ void *stream) {
   jga_kparams P;
   int rc;
+  if (check_dc(g, d_dc, dc_stride) != EXIT_SUCCESS) return EXIT_FAILURE;
   if (fill_params(&P, g, nimages, d_coef, coef_stride, d_qtab,
    dequant_on_device, d_yuv, yuv_stride, 0) != EXIT_SUCCESS) {
     return EXIT_FAILURE;
   }
+  P.dc = (const int16_t *)d_dc;
+  P.dc_stride = dc_stride;
   rc = jga_launch_yuv(&P, staged_loads(), stream);
   if (rc) return jga_fail("YUV kernel launch failed (HIP error %d)", rc);
   return EXIT_SUCCESS;

@@ -32,9 +32,13 @@ struct jga_huff_batch {
   // device
   unsigned char *d_blob;
   uint64_t *d_last_in;
-  hj_run *d_R;
+  uint32_t *d_R;
   uint32_t *d_B;
-  int16_t *d_D;
+  int16_t *d_dc;               // DC differences (scan order) | DC values (by buffer slot) of the current batch
+  size_t dc_cap;               // entries of each half
+  uint32_t *d_dcpart;          // chunk totals of the DC prefix sums
+  size_t dcpart_cap;           // entries (uint32)
+  uint32_t max_seg_mcus, max_segs_image;
   uint32_t *d_ran, *d_errors;
   uint32_t *d_part;            // chunk totals of the prefix-sum pass
   int sub_log2, force_sub_log2;  // subsequence length of the current batch / JGA_HUFF_SUB
@@ -113,9 +117,8 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   bool ok = hipHostMalloc((void **)&b->h_blob, b->blob_cap, hipHostMallocDefault) == hipSuccess
    && hipMalloc((void **)&b->d_blob, b->blob_cap) == hipSuccess
    && hipMalloc((void **)&b->d_last_in, 8*b->sub_cap) == hipSuccess
-   && hipMalloc((void **)&b->d_R, sizeof(hj_run)*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_R, 4*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_B, 4*b->sub_cap) == hipSuccess
-   && hipMalloc((void **)&b->d_D, 6*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_part, hj_scan_part_bytes(b->sub_cap, b->sub_cap)) == hipSuccess
    && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS) == hipSuccess
    && hipMalloc((void **)&b->d_errors, 4*(size_t)max_images) == hipSuccess
@@ -143,7 +146,8 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_R) (void)hipFree(b->d_R);
   if (b->d_B) (void)hipFree(b->d_B);
   if (b->d_part) (void)hipFree(b->d_part);
-  if (b->d_D) (void)hipFree(b->d_D);
+  if (b->d_dc) (void)hipFree(b->d_dc);
+  if (b->d_dcpart) (void)hipFree(b->d_dcpart);
   if (b->d_ran) (void)hipFree(b->d_ran);
   if (b->d_errors) (void)hipFree(b->d_errors);
   if (b->side) (void)hipStreamDestroy(b->side);
@@ -164,13 +168,11 @@ static bool grow_batch(jga_huff_batch *b, size_t need_sub, size_t need_blob) {
     if (b->d_last_in) (void)hipFree(b->d_last_in);
     if (b->d_R) (void)hipFree(b->d_R);
     if (b->d_B) (void)hipFree(b->d_B);
-    if (b->d_D) (void)hipFree(b->d_D);
     if (b->d_part) (void)hipFree(b->d_part);
-    b->d_last_in = NULL; b->d_R = NULL; b->d_B = NULL; b->d_D = NULL; b->d_part = NULL; b->sub_cap = 0;
+    b->d_last_in = NULL; b->d_R = NULL; b->d_B = NULL; b->d_part = NULL; b->sub_cap = 0;
     if (hipMalloc((void **)&b->d_last_in, 8*cap) != hipSuccess
-     || hipMalloc((void **)&b->d_R, sizeof(hj_run)*cap) != hipSuccess
+     || hipMalloc((void **)&b->d_R, 4*cap) != hipSuccess
      || hipMalloc((void **)&b->d_B, 4*cap) != hipSuccess
-     || hipMalloc((void **)&b->d_D, 6*cap) != hipSuccess
      || hipMalloc((void **)&b->d_part, hj_scan_part_bytes(cap, cap)) != hipSuccess) {
       return false;
     }
@@ -338,6 +340,13 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->max_nsub = max_nsub;
   b->max_chunks = (int)max_chunks;
   b->geom = prep[0].geom;
+  b->max_seg_mcus = 0; b->max_segs_image = 0;
+  for (int i = 0; i < n; i++) {
+    const hj_unstuff_image &u = uimg[(size_t)i];
+    const uint32_t sm = u.ri && u.ri < u.total_mcus ? u.ri : u.total_mcus;
+    if (sm > b->max_seg_mcus) b->max_seg_mcus = sm;
+    if (u.nseg > b->max_segs_image) b->max_segs_image = u.nseg;
+  }
   b->unstuffed_on_device = 1;
   b->shadow.clear();
   hipStream_t st = (hipStream_t)stream;
@@ -465,6 +474,11 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       b->total_seg = (uint32_t)total_seg;
       b->max_nsub = max_nsub;
       b->geom = prep[0].geom;
+      b->max_seg_mcus = 0; b->max_segs_image = 0;
+      for (int i = 0; i < n; i++) {
+        for (const hj_segment &sg : prep[i].segs) if (sg.nmcu > b->max_seg_mcus) b->max_seg_mcus = sg.nmcu;
+        if (prep[i].segs.size() > b->max_segs_image) b->max_segs_image = (uint32_t)prep[i].segs.size();
+      }
       size_t o = b->scan_bytes;
       b->off_images = o; o += align_up(sizeof(hj_image)*n, 256);
       b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
@@ -624,7 +638,8 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
   return EXIT_SUCCESS;
 }
 
-static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, hipStream_t st);
+static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
+ hipStream_t st);
 
 // Wait for everything queued on `st`.  hipStreamSynchronize spins on a host core — the right
 // thing for one frame's latency, the wrong one for a pipeline whose lanes outnumber the CPUs
@@ -636,7 +651,7 @@ static hipError_t wait_stream(jga_huff_batch *b, hipStream_t st) {
   return jga_stream_wait_sleeping(st, b->ev_wait);
 }
 
-JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
+static int decode_checked(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
  void *stream) {
   hipStream_t st = (hipStream_t)stream;
   // verdicts of an earlier decode must not outlive it: a launch failure below would otherwise
@@ -645,7 +660,8 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   for (int i = 0; i < b->max_images; i++) b->h_ran[HJ_MAX_ROUNDS + i] = 0;
   if (!b->nimages) return jga_fail("huff: nothing prepared");
   if (coef_stride < b->geom.coef_shorts) return jga_fail("huff: coef_stride too small");
-  const int rc = decode_batch(b, d_coef, coef_stride, st);
+  if (d_dc && dc_stride < b->geom.coef_shorts/64) return jga_fail("huff: dc_stride too small");
+  const int rc = decode_batch(b, d_coef, coef_stride, d_dc, dc_stride, st);
   if (rc != EXIT_SUCCESS && !b->image_errors) {
     // a launch or copy failed part-way: the plane clear on the side stream (and whatever
     // rounds were queued) may still be running — the caller is free to reuse or release
@@ -656,13 +672,31 @@ JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_
   return rc;
 }
 
+// Finished QUANT-stage planes (DC prediction applied), as jga_entropy_decode() makes them on the host.
+JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ void *stream) {
+  return decode_checked(b, d_coef, coef_stride, NULL, 0, stream);
+}
+
+// The same decode for a caller that runs a block-decode kernel next (jga_idct_*_batch_dc): the
+// planes' DC positions are left holding the DC DIFFERENCES, the DC values come in d_dc — image i
+// at d_dc + i*dc_stride, one int16 per 128-byte slot of the image's coefficient buffer
+// (dc_stride >= coef_shorts/64) — and the strided 2-byte pass over the planes that would put them
+// in place is saved.
+JGA_EXPORT int jga_huff_decode_split(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ short *d_dc, long long dc_stride, void *stream) {
+  if (!d_dc) return jga_fail("huff: jga_huff_decode_split needs a DC array");
+  return decode_checked(b, d_coef, coef_stride, d_dc, dc_stride, stream);
+}
+
 static double thread_cpu_ms() {
   timespec ts;
   clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
   return (double)ts.tv_sec*1e3 + (double)ts.tv_nsec*1e-6;
 }
 
-static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, hipStream_t st) {
+static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
+ hipStream_t st) {
   static const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
   double c0 = trace ? thread_cpu_ms() : 0.0, c_launch = 0.0, c_wait = 0.0;
   auto lap = [&](double &acc) { if (trace) { const double c = thread_cpu_ms(); acc += c - c0; c0 = c; } };
@@ -677,7 +711,29 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   A.last_in = b->d_last_in;
   A.R = b->d_R;
   A.B = b->d_B;
-  A.D = b->d_D;
+  {
+    // DC differences (scan order) and, unless the caller brings its own array, DC values (by
+    // buffer slot); one stride for both: the caller's, or the slot count rounded up
+    const size_t stride = d_dc ? (size_t)dc_stride : (size_t)((b->geom.coef_shorts/64 + 127) & ~127ll);
+    const size_t need = stride*(size_t)b->nimages;
+    if (need > b->dc_cap) {
+      if (b->d_dc) (void)hipFree(b->d_dc);
+      b->d_dc = NULL; b->dc_cap = 0;
+      HOK(hipMalloc((void **)&b->d_dc, 2*sizeof(int16_t)*need));
+      b->dc_cap = need;
+    }
+    A.dc_chunks_per_image = hj_dc_chunks_per_image(b->geom.nhmb*b->geom.nvmb, (int)b->max_segs_image);
+    const size_t pneed = 3*(size_t)b->nimages*(size_t)A.dc_chunks_per_image;
+    if (pneed > b->dcpart_cap) {
+      if (b->d_dcpart) (void)hipFree(b->d_dcpart);
+      b->d_dcpart = NULL; b->dcpart_cap = 0;
+      HOK(hipMalloc((void **)&b->d_dcpart, 4*pneed));
+      b->dcpart_cap = pneed;
+    }
+    A.dc_diff = b->d_dc;
+    A.dc_val = d_dc ? (int16_t *)d_dc : b->d_dc + b->dc_cap;
+    A.dc_stride = (long long)stride;
+  }
   A.scan_part = b->d_part;
   A.ran = b->d_ran;
   A.errors = b->d_errors;
@@ -698,21 +754,22 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   HOK(hipEventRecord(b->ev_begin, st));
   HOK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
   HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
+  // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
+  HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
+  HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
   HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
   b->last_assisted = 0;
   b->image_errors = 0;
   // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
   struct knobs {
-    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = 1, write_gmem = 1, assist_after = 12;
+    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = 1, assist_after = 12;
     knobs() {
       const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group": in-group iterations, rounds per host check
       if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
       if (it0 < 1) it0 = 1;
       if (it1 < 1) it1 = 1;
       if (group < 1) group = 1;
-      e = getenv("JGA_HUFF_WRITE_GMEM");               // write pass reads the scan from global memory
-      if (e) write_gmem = atoi(e) != 0;
       e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel
       if (e) sparse_from = atoi(e);
       e = getenv("JGA_HUFF_ASSIST_AFTER");             // rounds before the host walks the unsettled stretches
@@ -725,8 +782,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   static const knobs K;
   const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;     // no LDS rows that long: global-memory readers only
   const int it0 = K.it0, it1 = K.it1, group = K.group, flush_lanes = K.flush_lanes,
-            sparse_from = long_subs ? 0 : K.sparse_from, write_gmem = long_subs ? 1 : K.write_gmem,
-            assist_after = K.assist_after;
+            sparse_from = long_subs ? 0 : K.sparse_from, assist_after = K.assist_after;
   A.flush_lanes = flush_lanes;
   A.sub_log2 = b->sub_log2;
   const int GROUP = group;
@@ -751,7 +807,11 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   b->assist_hint = b->last_assisted > 0;
   if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
   HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
-  if (hj_launch_write(&A, (int)b->max_nsub, write_gmem, st)) return jga_fail("huff: launch failed");
+  if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+  // DC differences -> DC values; into the planes too unless the caller takes the array itself
+  if (hj_launch_dc(&A, (int)b->total_seg, (int)b->max_seg_mcus, b->d_dcpart, d_dc ? 0 : (int)(b->geom.coef_shorts/64), st)) {
+    return jga_fail("huff: launch failed");
+  }
   HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
   lap(c_launch);
   HOK(wait_stream(b, st));

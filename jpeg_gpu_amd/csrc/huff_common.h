@@ -15,10 +15,15 @@
 //            Rounds repeat until no entry changes.  A fixed point is exact by
 //            induction (S[0] true, S[i+1] = decode(S[i])) — self-synchronisation
 //            only makes it arrive in 2-3 rounds instead of n.
-//   then   : per-subsequence block counts and DC-difference sums are prefix-
-//            summed per segment, and a last pass writes every coefficient to its
-//            slot of the packed coefficient planes, DC
-//            already integrated (xjpeg.c:480).
+//   then   : per-subsequence block counts are prefix-summed per segment, and a last
+//            pass writes every coefficient to its slot of the packed coefficient planes
+//            (SURVEY.md Appendix B).  DC prediction (xjpeg.c:480) is NOT part of the
+//            synchronisation: the write pass leaves every block's DC DIFFERENCE in a
+//            compact array in scan order, a prefix sum over it per restart interval and
+//            component gives the DC values (hj_dc_scan), and they go into the planes —
+//            or straight into the block-decode kernels, which take them as an input.
+//            (Round 3: carrying three DC sums through every synchronisation run cost the
+//            rounds a third of their per-symbol instructions, 0.3 of 2.4 ms per 48 x 4K.)
 //
 // Everything here is HOST+DEVICE code: the HIP kernels (huff_kernels.hip) and
 // the CPU emulation used by the not-gpu tests (tools/huff_emul.cpp) run the same
@@ -130,8 +135,6 @@ HJ_HD int hj_k(uint64_t s) { return (int)(s & 255); }
 struct hj_run {
   uint64_t end_state;                // state at the first symbol boundary >= stop bit
   uint32_t nblocks;                  // blocks completed in the run
-  int16_t dcsum[3];                  // sum of DC differences per component (mod 2^16)
-  uint16_t error;                    // coefficient index ran past 63 / bad code
 };
 
 // Bit source over plain memory (host emulation): 32 bits, MSB first, starting at bit p.
@@ -182,6 +185,19 @@ HJ_HD uint32_t hj_lookup(const hj_tables *T, int isdc, int tbl, uint32_t w) {
   if ((e & 31u) == 0u) e = T->l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];   // (a long code has no pack)
   return e;
 }
+// The same tables as the kernels keep them in LDS: DC entries widened to 32 bits and laid out
+// in front of the AC ones, so that a symbol's lookup is ONE 32-bit read from
+// (table number << 9 | index) whatever its kind — no DC / AC case in the per-symbol path.
+struct hj_ltables {
+  uint32_t tab[4][1 << HJ_FAST_BITS];        // dc[0], dc[1], ac[0], ac[1]
+  uint16_t l2[HJ_L2_BLOCKS*128];
+};
+HJ_HD uint32_t hj_lookup(const hj_ltables *T, int isdc, int tbl, uint32_t w) {
+  const uint32_t t = isdc ? (uint32_t)(tbl & 1) : 2u + (uint32_t)(tbl >> 1);
+  uint32_t e = (&T->tab[0][0])[(t << HJ_FAST_BITS) | (w >> (32 - HJ_FAST_BITS))];
+  if ((e & 31u) == 0u) e = T->l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+  return e;
+}
 #define HJ_PACK(bits, adv, prefix) ((uint32_t)((bits) | ((adv) << 4) | ((prefix) << 11)))   /* the high half */
 #define HJ_P_BITS(e32) ((int)(((e32) >> 16) & 15u))       /* 0: no pack */
 #define HJ_P_ADV(e32) ((int)(((e32) >> 20) & 127u))
@@ -203,35 +219,29 @@ HJ_HD int hj_value(uint32_t w, int len, int s) {
 }
 
 // Decode from `start` until the first symbol boundary whose bit position is >= stop_bit:
-// the synchronisation rounds' run.  Produces the hj_run (end state, blocks completed, DC
-// difference sums), no coefficient values except the DC differences.  `T` = the image's
-// tables (an LDS copy on the GPU); the component of MCU slot c sits in bits [2c, 2c+1]
-// of a register (an indexed private array would live in scratch).  Every lane of a wave executes
-// every instruction of a divergent loop, so the per-symbol instruction count is
-// what the rounds cost.
+// the synchronisation rounds' run.  Produces the hj_run (end state, blocks completed), no
+// coefficient values at all.  `T` = the image's tables (hj_tables on the host, the LDS copy
+// hj_ltables on the GPU); the table choice of MCU slot c sits in bits [2c, 2c+1] of a register
+// (an indexed private array would live in scratch).  Every lane of a wave executes every
+// instruction of a divergent loop, so the per-symbol instruction count is what the rounds cost.
 // `last`: the subsequence is the last one of its segment, so `stop_bit` is also where the
 // segment's data ends.  A symbol that reaches past it borrows bits of the next segment (or the
 // pad): a block it would complete does not count — the data ended early, as the host stage says
 // of such a stream (entropy.c, xjpeg.c:593-629).
-// LITE: only the end state is wanted (r.nblocks / r.dcsum are left 0) — the very first run of
-// a subsequence starts from a GUESS (bit 0 of the subsequence, slot 0), so everything but
-// where it ends is meaningless, and a third of the per-symbol instructions serve the counts.
-template <class Src, bool LITE = false>
-HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables *T,
+// LITE: only the end state is wanted (r.nblocks is left 0) — the very first run of a
+// subsequence starts from a GUESS (bit 0 of the subsequence, slot 0), so everything but where it
+// ends is meaningless.
+template <class Src, bool LITE = false, class Tab = hj_tables>
+HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
  uint64_t start, uint64_t stop_bit, bool last = false) {
-  uint32_t slot_comp_bits = 0, slot_tbl_bits = 0;
-  for (int q = 0; q < im.nslots; q++) {
-    slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
-    slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
-  }
+  uint32_t slot_tbl_bits = 0;
+  for (int q = 0; q < im.nslots; q++) slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
   const int nslots = im.nslots;
   typename hj_reader_of<Src>::type br;
   hj_run r;
   int k = hj_k(start), c = hj_slot(start);
-  int dcall = 0, dc1 = 0, dc2 = 0;                         // component 0's sum = all - 1 - 2
   uint32_t nblocks = 0;
   br.init(src, hj_pos(start), stop_bit);
-  int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
   int tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
   while (br.before_stop()) {
     const uint32_t w = br.window();
@@ -243,55 +253,35 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const hj_tables 
     // only taken whole if all of it lies before the stop
     const bool packed = HJ_P_BITS(e) != 0 && k + HJ_P_PREFIX(e) < 64 && br.room9();
     br.skip(packed ? HJ_P_BITS(e) : HJ_E_TOT(e));
-#ifndef HJ_EXP_NODC                                       /* timing probe: what the DC sums cost the rounds */
-    if (!LITE && isdc) {                                   // DC difference, extended
-      const int s = HJ_E_S(e), len = HJ_E_TOT(e) - s;
-      const int v = hj_value(w, len, s);
-      dcall += v;
-      dc1 += comp == 1 ? v : 0;
-      dc2 += comp == 2 ? v : 0;
-    }
-#endif
     const int kn = k + (packed ? HJ_P_ADV(e) : HJ_E_ADV(e));   // DC: 1; AC: past the run(s); EOB: >= 64
     const int done = kn >= 64;
     if (!LITE) nblocks += (uint32_t)done;
     c = done ? (c + 1 == nslots ? 0 : c + 1) : c;
-    comp = (int)((slot_comp_bits >> (2*c)) & 3u);
     tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
     k = done ? 0 : kn;
   }
   // (k == 0 with a block counted: the run's final symbol completed it)
   if (last && k == 0 && nblocks > 0 && br.tell() > stop_bit) nblocks--;   // ...with bits the segment does not have
   r.nblocks = nblocks;
-  r.error = 0;
-  r.dcsum[0] = (int16_t)(dcall - dc1 - dc2); r.dcsum[1] = (int16_t)dc1; r.dcsum[2] = (int16_t)dc2;
   r.end_state = hj_pack(br.tell(), c, k);
   return r;
 }
 
-// Final pass, lean like hj_sync_decode: every coefficient goes through `out`:
+// The final pass as the HOST states it (tools/huff_emul.cpp, tests/test_huff_emul.py): every
+// coefficient goes through `out`, DC values integrated from the predictors handed in, which are
+// handed back as they stand at the end of the run (the emulation walks the lanes of a segment in
+// order).  The kernel (huff_kernels.hip: hj_write) decodes the same symbols but leaves the DC
+// DIFFERENCES and lets hj_dc_scan integrate them; the GPU parity tests hold the two against the
+// same oracle planes.
 //   out.put(natural_index, value)       into the lane's block buffer
-//   out.flush_complete(waiting, slot, head)   called by EVERY lane of the wave at a write-out
-//       point: the lanes with `waiting` hold a block whose last coefficient was decoded
-//       here (`head`: its first one was too, so the buffer holds the whole block) and the
-//       wave writes those blocks out together; buffers must be zero again afterwards
+//   out.flush_complete(waiting, slot, head)   the lane holds a block whose last coefficient was
+//       decoded here (`head`: its first one was too, so the buffer holds the whole block)
 //   out.flush_partial(slot, head)       end of the run, block unfinished: its coefficients
 //       so far (a later lane holds the rest)
-//   out.any(x)                          does any lane of the wave have x? (host: x)
-//   out.flush_due(waiting, running)     wave-uniform: is this a write-out point?
-// Writing a block out costs far more instructions than decoding a symbol, and in a wave
-// every lane pays for every instruction any lane executes.  So a lane that completes a
-// block does not write it at once: it WAITS (decodes nothing) until the wave decides
-// that enough lanes are waiting, and then all of them write together — the write-out
-// code runs once per several symbols instead of once per symbol.
-// DC values are integrated from `pred` (predictors at the start of the run).
-#ifndef HJ_WRITE_UNROLL
-#define HJ_WRITE_UNROLL 2
-#endif
 template <class Src, class Out>
 HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T,
  const uint8_t *dezz, uint64_t start, uint64_t stop_bit, uint32_t max_blocks,
- int pred0, int pred1, int pred2, Out &out) {
+ int &pred0, int &pred1, int &pred2, Out &out) {
   uint32_t slot_comp_bits = 0, slot_tbl_bits = 0;
   for (int q = 0; q < im.nslots; q++) {
     slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
@@ -300,50 +290,38 @@ HJ_HD int hj_write_decode(const Src &src, const hj_image &im, const hj_tables *T
   const int nslots = im.nslots;
   typename hj_reader_of<Src>::type br;
   int k = hj_k(start), c = hj_slot(start), error = 0;
-  bool head = k == 0, waiting = false;
+  bool head = k == 0;
   uint32_t n = 0;
   br.init(src, hj_pos(start), stop_bit);
   int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
   int tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
-  for (;;) {
-    bool running = !waiting && br.before_stop() && n < max_blocks;
-    if (!out.any(running || waiting)) break;
-    // HJ_WRITE_UNROLL symbols between two looks at the write-out condition: the loop control
-    // and the wave votes are as many instructions as a symbol's decode
-#pragma unroll
-    for (int u = 0; u < HJ_WRITE_UNROLL; u++) {
-      if (u) running = !waiting && br.before_stop() && n < max_blocks;
-      if (!running) continue;
-      const uint32_t w = br.window();
-      const int isdc = k == 0;
-      const uint32_t e = hj_lookup(T, isdc, tbl, w) & 0xffffu;       // (every value is wanted: no packs)
-      const int s = HJ_E_S(e), len = HJ_E_TOT(e) - s, adv1 = HJ_E_ADV(e) - 1;
-      int v = hj_value(w, len, s);
-      br.skip(len + s);
-      if (isdc) {
-        pred0 += comp == 0 ? v : 0;
-        pred1 += comp == 1 ? v : 0;
-        pred2 += comp == 2 ? v : 0;
-        v = (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);    // wraps like xjpeg.c:480
-      }
-      const int kn = k + adv1 + 1;                         // one past this coefficient's zig-zag index
-      if (len > 16) error = 1;                             // a bit pattern that is no code
-      if (kn > 64 && adv1 != 63) error = 1;                // an AC run past coefficient 63
-      else if (isdc || s) out.put(dezz[kn - 1], v);
-      waiting = kn >= 64;                                  // block complete: wait for the write-out
-      k = waiting ? 0 : kn;
+  while (br.before_stop() && n < max_blocks) {
+    const uint32_t w = br.window();
+    const int isdc = k == 0;
+    const uint32_t e = hj_lookup(T, isdc, tbl, w) & 0xffffu;       // (every value is wanted: no packs)
+    const int s = HJ_E_S(e), len = HJ_E_TOT(e) - s, adv1 = HJ_E_ADV(e) - 1;
+    int v = hj_value(w, len, s);
+    br.skip(len + s);
+    if (isdc) {
+      pred0 += comp == 0 ? v : 0;
+      pred1 += comp == 1 ? v : 0;
+      pred2 += comp == 2 ? v : 0;
+      v = (int16_t)(comp == 0 ? pred0 : comp == 1 ? pred1 : pred2);    // wraps like xjpeg.c:480
     }
-    if (out.flush_due(waiting, running && !waiting)) {
-      out.flush_complete(waiting, c, head);
-      if (waiting) {
-        n++;
-        c = c + 1 == nslots ? 0 : c + 1;
-        comp = (int)((slot_comp_bits >> (2*c)) & 3u);
-        tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
-        head = true;
-        waiting = false;
-      }
+    const int kn = k + adv1 + 1;                           // one past this coefficient's zig-zag index
+    if (len > 16) error = 1;                               // a bit pattern that is no code
+    if (kn > 64 && adv1 != 63) error = 1;                  // an AC run past coefficient 63
+    else if (isdc || s) out.put(dezz[kn - 1], v);
+    if (kn >= 64) {                                        // block complete
+      out.flush_complete(true, c, head);
+      n++;
+      c = c + 1 == nslots ? 0 : c + 1;
+      comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+      tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
+      head = true;
+      k = 0;
     }
+    else k = kn;
   }
   if (k != 0 && n < max_blocks) out.flush_partial(c, head);     // a later lane finishes this block
   return error;

@@ -14,9 +14,12 @@ typedef struct hj_args {
   const uint8_t *scan;         /* all images' entropy-coded bytes */
   uint64_t *S;                 /* states: nsub + nseg entries per image */
   uint64_t *last_in;           /* start state of each lane's latest run */
-  hj_run *R;                   /* result of each lane's latest run */
+  uint32_t *R;                 /* blocks completed by each lane's latest run */
   uint32_t *B;                 /* blocks before the lane, within its segment */
-  int16_t *D;                  /* [3*sub] DC sums before the lane */
+  int16_t *dc_diff;            /* image i at dc_diff + i*dc_stride: DC difference of every block, scan order */
+  int16_t *dc_val;             /* image i at dc_val + i*dc_stride: DC value of every block, by coefficient-buffer slot */
+  long long dc_stride;         /* entries per image (>= coef_shorts/64) */
+  int dc_chunks_per_image;     /* hj_dc_chunks_per_image() */
   uint32_t *scan_part;         /* chunk totals of the prefix-sum pass (hj_scan_part_bytes) */
   uint32_t *ran;               /* [HJ_MAX_ROUNDS] non-zero if any lane ran in that round */
   uint32_t *errors;            /* [nimages] bit0 inconsistent stream, bit1 bad coefficient index */
@@ -36,8 +39,12 @@ int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, void *stream)
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);
-/* gmem != 0: the write pass reads the scan from global memory instead of an LDS copy */
-int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream);
+int hj_launch_write(const hj_args *A, int max_nsub, void *stream);
+/* DC differences (A->dc_diff, left by the write pass) -> DC values by buffer slot (A->dc_val);
+ * apply_slots > 0: also written into the planes' DC positions (slots per image).  `part`:
+ * 12 bytes x nimages x hj_dc_chunks_per_image(). */
+int hj_dc_chunks_per_image(int total_mcus, int max_segs_per_image);
+int hj_launch_dc(const hj_args *A, int total_segs, int max_seg_mcus, uint32_t *part, int apply_slots, void *stream);
 #ifdef __cplusplus
 }
 #endif

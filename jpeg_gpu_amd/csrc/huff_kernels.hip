@@ -4,17 +4,22 @@
 //                  A workgroup iterates internally (states handed lane-to-lane
 //                  through LDS) until none of its lanes moves, so most of the
 //                  propagation needs no extra launch.
-//   hj_scan        one workgroup per restart segment: exclusive prefix sums of
-//                  block counts and DC-difference sums over the segment's lanes
+//   hj_scan        per restart segment: exclusive prefix sums of the block counts over the
+//                  segment's lanes
 //   hj_write       one lane per subsequence: final decode.  Blocks are assembled in LDS;
 //                  a lane that finishes one waits until enough lanes of its wave have,
 //                  then the wave writes them out together as full 128-byte lines.  Only
-//                  the pieces of blocks that straddle lanes are scattered.
+//                  the pieces of blocks that straddle lanes are scattered.  DC DIFFERENCES
+//                  go to a compact array in scan order
+//   hj_dc_scan     per restart segment and component: prefix sums over that array = the DC
+//                  values (xjpeg.c:480), stored by coefficient-buffer slot
+//   hj_dc_apply    writes them into the planes (callers that want finished QUANT planes;
+//                  the block-decode kernels can take the array itself)
 // Integer/byte work.  Every subsequence of a workgroup gets its own LDS copy — 35
 // big-endian dwords (alignment + 128 bytes + look-ahead) at an odd stride, so lanes
 // walking their own copies hit different banks — next to the image's two-level Huffman
-// lookup (10 KB).  LDS is what bounds occupancy: 53.7 KB per sync workgroup (3 per CU),
-// 80.3 KB per write workgroup (2 per CU).
+// lookup (12 KB with the DC entries widened: hj_ltables).  LDS is what bounds occupancy: 54.2 KB
+// per sync workgroup (3 per CU), 81 KB per write workgroup (2 per CU).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -130,9 +135,21 @@ static __device__ __forceinline__ void hj_stage_image(hj_image *dst, const hj_im
 // Common prologue: lane context, tables and the group's subsequences staged in LDS.
 // Returns false for lanes beyond the image's last subsequence (they still took part
 // in staging).  lds_start[t] receives the clean-scan byte offset of subsequence t.
+// hj_tables (as uploaded: 16-bit DC entries) -> hj_ltables in LDS
+template <int NB>
+static __device__ __forceinline__ void hj_stage_tables(hj_ltables *dst, const hj_tables *src) {
+  for (int k = threadIdx.x; k < 2 << HJ_FAST_BITS; k += NB) {
+    (&dst->tab[0][0])[k] = (&src->dc[0][0])[k];
+    (&dst->tab[2][0])[k] = (&src->ac[0][0])[k];
+  }
+  const uint4 *l2s = reinterpret_cast<const uint4 *>(src->l2);
+  uint4 *l2d = reinterpret_cast<uint4 *>(dst->l2);
+  for (int k = threadIdx.x; k < (int)(sizeof(src->l2)/16); k += NB) l2d[k] = l2s[k];
+}
+
 template <bool STAGE_ROWS = true, int NB = HJ_BLOCK>
 static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_image &im,
- hj_tables *lds_tabs, uint32_t *lds_win, uint32_t *lds_start, hj_lane_ctx &L) {
+ hj_ltables *lds_tabs, uint32_t *lds_win, uint16_t *lds_start, uint32_t *lds_start0, hj_lane_ctx &L) {
   const uint32_t li = blockIdx.x*NB + threadIdx.x;
   const bool in_range = li < im.nsub;
   L.g = 0; L.si = 0; L.i = 0; L.stop_byte = 0;
@@ -149,13 +166,13 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
     L.stop_byte = my_start + (1u << A.sub_log2);
     if (L.stop_byte > sg.end) L.stop_byte = sg.end;
   }
-  lds_start[threadIdx.x] = my_start;
-  // tables of this image -> LDS (16-byte chunks)
-  {
-    const uint4 *tsrc = reinterpret_cast<const uint4 *>(A.tables + blockIdx.y);
-    uint4 *tdst = reinterpret_cast<uint4 *>(lds_tabs);
-    for (int k = threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += NB) tdst[k] = tsrc[k];
-  }
+  // (relative to the group's first subsequence: 256 x 128 bytes fit 16 bits, and the 512 bytes of
+  // LDS this saves keep the round at three workgroups per CU)
+  const uint32_t base0 = (uint32_t)__shfl((int)my_start, 0);   // wave 0 holds lane 0 of the group
+  if (threadIdx.x == 0) *lds_start0 = base0;
+  hj_stage_tables<NB>(lds_tabs, A.tables + blockIdx.y);
+  __syncthreads();
+  lds_start[threadIdx.x] = in_range ? (uint16_t)(my_start - *lds_start0) : (uint16_t)0;
   __syncthreads();
   // subsequence t: hj_sub_dwords() dwords from (start & ~3)
   const uint8_t *scan = A.scan + im.scan_off;
@@ -165,7 +182,7 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
   const uint32_t magic = 0xFFFFFFFFu/sdw + 1u;                 // c/sdw == umulhi(c, magic) for c < 2^16
   for (uint32_t c = threadIdx.x; STAGE_ROWS && c < nsubs*sdw; c += NB) {
     const uint32_t sub = __umulhi(c, magic), d = c - sub*sdw;
-    uint32_t a = (lds_start[sub] & ~3u) + 4*d;
+    uint32_t a = ((*lds_start0 + lds_start[sub]) & ~3u) + 4*d;
     if (a + 4 > padded) a = padded - 4;
     lds_win[sub*sdw + d] = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(scan + a));
   }
@@ -175,31 +192,27 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
 
 // Bit source of subsequence `sub` of the group.
 static __device__ __forceinline__ hj_lds_src hj_source(const uint32_t *lds_win,
- const uint32_t *lds_start, uint32_t sub, uint32_t sdw) {
+ const uint16_t *lds_start, uint32_t start0, uint32_t sub, uint32_t sdw) {
   hj_lds_src s;
   s.base = lds_win + sub*sdw;
-  s.bit0 = (lds_start[sub] & ~3u) << 3;
+  s.bit0 = ((start0 + lds_start[sub]) & ~3u) << 3;
   return s;
 }
 
-// Result of a run, packed for LDS.
-struct hj_run16 {                    // (the end state lives in lds_S / S)
-  uint16_t nblocks;
-  int16_t dcsum[3];
-};
 
 __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int round, int max_iters, int lite_first) {
-  __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
+  __shared__ __attribute__((aligned(16))) hj_ltables lds_tabs;
   __shared__ uint32_t lds_win_mem[1 + HJ_WIN_DWORDS];      // [0]: the dword "before" row 0 (hj_lds_src::reader)
   uint32_t *lds_win = lds_win_mem + 1;
   __shared__ uint64_t lds_S[HJ_BLOCK + 1];       // start state of each subsequence of the group
-  __shared__ hj_run16 lds_R[HJ_BLOCK];           // result of its latest run
+  __shared__ uint16_t lds_R[HJ_BLOCK];           // blocks completed by its latest run (the end state lives in lds_S / S)
   __shared__ uint32_t lds_stop[HJ_BLOCK];        // stop byte | bit 31: has a successor in its segment
   __shared__ uint32_t lds_sidx_last;             // entry of the group's last subsequence in the global S array
   __shared__ uint8_t lds_dirty[HJ_BLOCK], lds_ran[HJ_BLOCK];
-  __shared__ uint16_t lds_act[HJ_BLOCK];
+  __shared__ uint8_t lds_act[HJ_BLOCK];
   __shared__ uint32_t lds_wcnt[HJ_BLOCK/64];
-  __shared__ uint32_t lds_start[HJ_BLOCK];
+  __shared__ uint16_t lds_start[HJ_BLOCK];
+  __shared__ uint32_t lds_start0;
   __shared__ hj_image s_im;
   const hj_image im = A.images[blockIdx.y];      // scalar fields only; indexed ones via s_im
   const uint32_t t = threadIdx.x;
@@ -215,7 +228,8 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
   }
   hj_stage_image(&s_im, A.images + blockIdx.y);
   hj_lane_ctx L;
-  const bool on = hj_prologue(A, im, &lds_tabs, lds_win, lds_start, L);
+  const bool on = hj_prologue(A, im, &lds_tabs, lds_win, lds_start, &lds_start0, L);
+  const uint32_t start0 = lds_start0;
   const uint32_t sidx = L.g + im.seg0 + L.si;          // this subsequence's entry of S
   {
     const uint64_t st = on ? A.S[sidx] : 0;
@@ -245,7 +259,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
     }
     if (total == 0) break;
     if (need) {
-      lds_act[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
+      lds_act[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)t;
       lds_dirty[t] = 0;
     }
     __syncthreads();
@@ -266,18 +280,15 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
         uint64_t from = hj_pos(start);
         uint64_t skip = (uint64_t)(lite_first - 1)*8;
         if (from + 2*skip > stop_bit) skip = from < stop_bit ? (stop_bit - from)/2 : 0;
-        r = hj_sync_decode<hj_lds_src, true>(hj_source(lds_win, lds_start, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
+        r = hj_sync_decode<hj_lds_src, true, hj_ltables>(hj_source(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
          hj_pack(from + skip, hj_slot(start), hj_k(start)), stop_bit, (sb >> 31) == 0u);
         lds_ran[sub] = 2;                                    // ran, but nothing to publish
         lds_dirty[sub] = 1;                                  // (its own flag: no other lane writes it now)
       }
       else {
-        r = hj_sync_decode(hj_source(lds_win, lds_start, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
+        r = hj_sync_decode<hj_lds_src, false, hj_ltables>(hj_source(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
          (uint64_t)(sb & 0x7fffffffu)*8, (sb >> 31) == 0u);
-        hj_run16 r16;
-        r16.nblocks = (uint16_t)r.nblocks;
-        r16.dcsum[0] = r.dcsum[0]; r16.dcsum[1] = r.dcsum[1]; r16.dcsum[2] = r.dcsum[2];
-        lds_R[sub] = r16;
+        lds_R[sub] = (uint16_t)r.nblocks;
         lds_ran[sub] = 1;
       }
       if (sb & 0x80000000u) {
@@ -295,11 +306,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
     const uint64_t st = lds_S[t];
     if (t > 0 && st != A.S[sidx]) A.S[sidx] = st;
     if (lds_ran[t] == 1) {                        // (2: only a lite run — still "never ran")
-      const hj_run16 r16 = lds_R[t];
-      hj_run r;
-      r.end_state = 0; r.nblocks = r16.nblocks; r.error = 0;
-      r.dcsum[0] = r16.dcsum[0]; r.dcsum[1] = r16.dcsum[1]; r.dcsum[2] = r16.dcsum[2];
-      A.R[L.g] = r;
+      A.R[L.g] = lds_R[t];
       // clean: its latest run started from st.  dirty: the state moved after that run
       // began, so whatever last_in held before must not make it look settled.
       A.last_in[L.g] = lds_dirty[t] ? ~0ull : st;
@@ -326,10 +333,18 @@ static __device__ __forceinline__ void hj_wave_sync() {      // LDS hand-over in
 }
 __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_args A, int round, int max_iters) {
   constexpr int NG = HJ_SPARSE_GROUPS;
-  __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
+#ifndef HJ_SPARSE_WIDE_TABLES
+#define HJ_SPARSE_WIDE_TABLES 1      /* 0: the 10 KB tables as uploaded (16-bit DC entries, a DC / AC case per symbol) */
+#endif
+#if HJ_SPARSE_WIDE_TABLES
+  typedef hj_ltables sparse_tables;
+#else
+  typedef hj_tables sparse_tables;
+#endif
+  __shared__ __attribute__((aligned(16))) sparse_tables lds_tabs;
   __shared__ uint64_t lds_S_all[NG][HJ_BLOCK + 1];
   __shared__ uint8_t lds_dirty_all[NG][HJ_BLOCK], lds_ran_all[NG][HJ_BLOCK];
-  __shared__ uint16_t lds_act_all[NG][HJ_BLOCK];
+  __shared__ uint8_t lds_act_all[NG][HJ_BLOCK];
   __shared__ hj_image s_im;
   const hj_image im = A.images[blockIdx.y];
   const uint32_t lane = threadIdx.x & 63u;
@@ -337,7 +352,7 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
   const uint32_t group = blockIdx.x*NG + wave;               // this wave's 256 subsequences
   uint64_t *lds_S = lds_S_all[wave];
   uint8_t *lds_dirty = lds_dirty_all[wave], *lds_ran = lds_ran_all[wave];
-  uint16_t *lds_act = lds_act_all[wave];
+  uint8_t *lds_act = lds_act_all[wave];
   // lane l describes subsequences l, l+64, l+128, l+192 of the group
   uint32_t g[4], sidx[4];
   bool on[4], any = false;
@@ -362,11 +377,15 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
   const uint32_t sidx_last = (uint32_t)__shfl((int)sidx[3], 63);   // entry of the group's last subsequence
   if (!__syncthreads_or(any)) return;            // nothing moved in any of the four groups
   hj_stage_image(&s_im, A.images + blockIdx.y);
+#if HJ_SPARSE_WIDE_TABLES
+  hj_stage_tables<64*NG>(&lds_tabs, A.tables + blockIdx.y);
+#else
   {
     const uint4 *tsrc = reinterpret_cast<const uint4 *>(A.tables + blockIdx.y);
     uint4 *tdst = reinterpret_cast<uint4 *>(&lds_tabs);
     for (int k = (int)threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += 64*NG) tdst[k] = tsrc[k];
   }
+#endif
   __syncthreads();
   // from here on every wave is on its own: no workgroup barriers
   if (__ballot(any) == 0ull) return;
@@ -381,7 +400,7 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
       const bool need = lds_dirty[t] != 0;
       const unsigned long long m = __ballot(need);
       if (need) {
-        lds_act[total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)t;
+        lds_act[total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)t;
         lds_dirty[t] = 0;
       }
       total += (uint32_t)__popcll(m);
@@ -406,10 +425,9 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
           src.dw0 = first >> 2;
           src.ndw = padded >> 2;
         }
-        hj_run r = hj_sync_decode(src, s_im, &lds_tabs, start, (uint64_t)stop*8, i + 1 >= sg.nsub);
+        const hj_run r = hj_sync_decode<hj_gmem_src, false, sparse_tables>(src, s_im, &lds_tabs, start, (uint64_t)stop*8, i + 1 >= sg.nsub);
         const uint64_t end_state = r.end_state;
-        r.end_state = 0; r.error = 0;
-        A.R[gg] = r;                             // (a later run of the same subsequence overwrites it)
+        A.R[gg] = r.nblocks;                     // (a later run of the same subsequence overwrites it)
         lds_ran[sub] = 1;
         if (i + 1 < sg.nsub) {
           if (sub + 1 < HJ_BLOCK) {
@@ -441,18 +459,18 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
 #define HJ_SCAN_ITEMS 4             /* consecutive lanes summed by one thread */
 #define HJ_SCAN_CHUNK_LOG2 12       /* HJ_SCAN_BLOCK*HJ_SCAN_ITEMS lanes per workgroup */
 static_assert(HJ_SCAN_BLOCK*HJ_SCAN_ITEMS == 1 << HJ_SCAN_CHUNK_LOG2, "chunk size");
-// Exclusive prefix sums (blocks completed, DC differences per component) over the lanes of
-// every segment, in two launches so that a long segment is not one workgroup's serial loop
-// (one 4K 4:4:4 image without restart markers: 196 us -> 2 x ~10): a workgroup takes a chunk
-// of 4096 lanes (each thread sums four consecutive lanes, a shuffle scan runs over the
-// wavefront, the sixteen wave totals go through LDS);
-//   FINAL = false  stores the chunk's totals,
-//   FINAL = true   adds the totals of the chunks before it in the segment and writes B / D.
-// Chunk c of segment gs keeps its totals at scan_part[gs + (first lane of the segment >> 12)
+// Exclusive prefix sums of the blocks completed over the lanes of every segment, in two launches
+// so that a long segment is not one workgroup's serial loop (one 4K 4:4:4 image without restart
+// markers: 196 us -> 2 x ~10): a workgroup takes a chunk of 4096 lanes (each thread sums four
+// consecutive lanes, a shuffle scan runs over the wavefront, the sixteen wave totals go through
+// LDS);
+//   FINAL = false  stores the chunk's total,
+//   FINAL = true   adds the totals of the chunks before it in the segment and writes B.
+// Chunk c of segment gs keeps its total at scan_part[gs + (first lane of the segment >> 12)
 // + c]: distinct and increasing over the batch, below total_seg + total_sub/4096 + 1.
 template <bool FINAL>
 __global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
-  __shared__ uint32_t wtot[HJ_SCAN_BLOCK/64][4];
+  __shared__ uint32_t wtot[HJ_SCAN_BLOCK/64];
   // blockIdx.x = batch-global segment; find its image (few images: linear search)
   const uint32_t gs = blockIdx.x, c = blockIdx.y;
   int img = 0;
@@ -465,91 +483,64 @@ __global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
   const uint32_t total = sg.nmcu*(uint32_t)im.nslots;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t first = im.sub0 + sg.sub0;
-  uint32_t *part = A.scan_part + 4*(size_t)(gs + (first >> HJ_SCAN_CHUNK_LOG2) + c);
+  uint32_t *part = A.scan_part + (size_t)(gs + (first >> HJ_SCAN_CHUNK_LOG2) + c);
   const uint32_t i0 = c0 + threadIdx.x*HJ_SCAN_ITEMS;
   const uint32_t g0 = first + i0;
-  uint32_t v[HJ_SCAN_ITEMS][4];                              // [0] blocks, [1..3] DC sums (mod 2^16)
-  uint32_t slot[HJ_SCAN_ITEMS];
-  uint32_t mine[4] = {0, 0, 0, 0};
+  uint32_t v[HJ_SCAN_ITEMS], slot[HJ_SCAN_ITEMS];
+  uint32_t mine = 0;
 #pragma unroll
   for (int j = 0; j < HJ_SCAN_ITEMS; j++) {
-    v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0;
+    v[j] = 0;
     slot[j] = 0;
     if (i0 + j < sg.nsub) {
-      const hj_run r = A.R[g0 + j];
+      v[j] = A.R[g0 + j];
       if (FINAL) slot[j] = (uint32_t)hj_slot(A.S[g0 + j + im.seg0 + si]);
-      v[j][0] = r.nblocks;
-      v[j][1] = (uint32_t)(int)r.dcsum[0]; v[j][2] = (uint32_t)(int)r.dcsum[1]; v[j][3] = (uint32_t)(int)r.dcsum[2];
     }
-#pragma unroll
-    for (int f = 0; f < 4; f++) mine[f] += v[j][f];
+    mine += v[j];
   }
-  uint32_t run[4] = {0, 0, 0, 0};
+  uint32_t run = 0;
   if (FINAL) {                                               // chunks before this one
-    for (uint32_t k = 1; k <= c; k++) {
-#pragma unroll
-      for (int f = 0; f < 4; f++) run[f] += part[f - 4*(int)k];
-    }
+    for (uint32_t k = 1; k <= c; k++) run += part[-(int)k];
   }
-  uint32_t inc[4] = {mine[0], mine[1], mine[2], mine[3]};
+  uint32_t inc = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-    for (int f = 0; f < 4; f++) {
-      const uint32_t x = (uint32_t)__shfl_up((int)inc[f], d);
-      if ((int)lane >= d) inc[f] += x;
-    }
+    const uint32_t x = (uint32_t)__shfl_up((int)inc, d);
+    if ((int)lane >= d) inc += x;
   }
-  if (lane == 63u) {
-#pragma unroll
-    for (int f = 0; f < 4; f++) wtot[wave][f] = inc[f];
-  }
+  if (lane == 63u) wtot[wave] = inc;
   __syncthreads();
-  uint32_t tot[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int f = 0; f < 4; f++) run[f] += inc[f] - mine[f];
+  uint32_t tot = 0;
+  run += inc - mine;
   for (uint32_t w = 0; w < HJ_SCAN_BLOCK/64; w++) {
-#pragma unroll
-    for (int f = 0; f < 4; f++) {
-      const uint32_t x = wtot[w][f];
-      tot[f] += x;
-      if (w < wave) run[f] += x;
-    }
+    const uint32_t x = wtot[w];
+    tot += x;
+    if (w < wave) run += x;
   }
   if (!FINAL) {
-    if (threadIdx.x == 0) {
-#pragma unroll
-      for (int f = 0; f < 4; f++) part[f] = tot[f];
-    }
+    if (threadIdx.x == 0) part[0] = tot;
     return;
   }
   bool bad = false;
   // data ran out before the last MCU (seen by the segment's last chunk)
-  if (c0 + (1u << HJ_SCAN_CHUNK_LOG2) >= sg.nsub && threadIdx.x == 0 && run[0] + tot[0] < total) bad = true;
+  if (c0 + (1u << HJ_SCAN_CHUNK_LOG2) >= sg.nsub && threadIdx.x == 0 && run + tot < total) bad = true;
 #pragma unroll
   for (int j = 0; j < HJ_SCAN_ITEMS; j++) {
     if (i0 + j < sg.nsub) {
-      const uint32_t g = g0 + j;
-      A.B[g] = run[0];
-      A.D[3*g + 0] = (int16_t)run[1];
-      A.D[3*g + 1] = (int16_t)run[2];
-      A.D[3*g + 2] = (int16_t)run[3];
+      A.B[g0 + j] = run;
       // the slot a lane starts in must agree with the number of blocks before it
-      if (run[0] < total && slot[j] != run[0] % (uint32_t)im.nslots) bad = true;
+      if (run < total && slot[j] != run % (uint32_t)im.nslots) bad = true;
     }
-#pragma unroll
-    for (int f = 0; f < 4; f++) run[f] += v[j][f];
+    run += v[j];
   }
   if (bad) atomicOr(&A.errors[img], 1u);
 }
 
-// Output side of hj_write_decode.  Every coefficient lands in the lane's LDS block
-// buffer first.  At a write-out point the WAVE writes the finished blocks of its waiting
-// lanes together: the k-th waiting lane's block is handled by lanes 8k..8k+7 of a pass,
-// 16 bytes each, so every store instruction writes whole 128-byte lines (16-byte pieces
-// at a 128-byte stride per lane cost 2-4x more in the memory pipeline).  A piece of a
-// block shared with a neighbouring lane is scattered as 2-byte stores onto the pre-zeroed
-// planes (disjoint positions, so the lanes need no ordering between them).
+// Output side of the write pass.  Every coefficient lands in the lane's LDS block buffer first.
+// At a write-out point the WAVE writes the blocks of its waiting lanes together: the k-th
+// waiting lane's block is handled by lanes 8k..8k+7 of a pass, 16 bytes each, so every store
+// instruction writes whole 128-byte lines (16-byte pieces at a 128-byte stride per lane cost
+// 2-4x more in the memory pipeline).
 typedef int16_t __attribute__((may_alias)) hj_i16_alias;    // 16-bit view of the dword buffer
 typedef uint32_t hj_v4u __attribute__((ext_vector_type(4)));
 struct hj_block_out {
@@ -570,9 +561,6 @@ struct hj_block_out {
     const unsigned long long w = __ballot(waiting);
     return w != 0ull && ((int)__popcll(w) >= flush_lanes || __ballot(running) == 0ull);
   }
-  __device__ __forceinline__ void put(int idx, int v) {
-    reinterpret_cast<hj_i16_alias *>(blk)[idx] = (int16_t)v;
-  }
   // offset (shorts) of the current MCU's block `slot` in the image's planes
   // (inverse of the MCU loop nest + block placement of src/xjpeg.c:461-472, 556-561)
   __device__ __forceinline__ uint32_t offset(int slot) const {
@@ -584,46 +572,11 @@ struct hj_block_out {
     return (uint32_t)im->comp_coef_off[comp] + rs*(by >> xd) + (rs >> xd)*(by & ((1u << xd) - 1u))
      + (bx << 6);
   }
-  __device__ __forceinline__ void scatter(int slot) {
-    int16_t *dst = coef + offset(slot);
-    for (int q = 0; q < 32; q++) {
-      const uint32_t two = blk[q];
-      if (two & 0xffffu) dst[2*q] = (int16_t)(two & 0xffffu);
-      if (two >> 16) dst[2*q + 1] = (int16_t)(two >> 16);
-      blk[q] = 0;
-    }
-  }
   __device__ __forceinline__ void next_block(int slot) {
     if (slot + 1 == im->nslots) {
       mbx++;
       if (mbx == (uint32_t)im->nhmb) { mbx = 0; mby++; }
     }
-  }
-  // every lane of the wave calls this together
-  __device__ __forceinline__ void flush_complete(bool waiting, int slot, bool head) {
-    const uint32_t lane = threadIdx.x & 63u;
-    if (waiting && !head) scatter(slot);                     // tail of a block begun by an earlier lane
-    const bool full = waiting && head;
-    const unsigned long long mask = __ballot(full);
-    if (mask) {
-      if (full) {
-        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-         __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        rank_lane[r] = (uint8_t)lane;
-        blk[32] = offset(slot)*2u;
-      }
-      const uint32_t cnt = (uint32_t)__popcll(mask), part = lane & 7u;
-      for (uint32_t k = lane >> 3; k < cnt; k += 8) {        // (uniform trip count up to a partial last pass)
-        uint32_t *src = wave_blk + (uint32_t)rank_lane[k]*HJ_BLK_STRIDE;
-        const uint32_t off = src[32];
-        hj_v4u v;
-        v.x = src[4*part]; v.y = src[4*part + 1]; v.z = src[4*part + 2]; v.w = src[4*part + 3];
-        src[4*part] = 0; src[4*part + 1] = 0; src[4*part + 2] = 0; src[4*part + 3] = 0;
-        typedef __attribute__((address_space(1))) hj_v4u global_v4u;
-        __builtin_nontemporal_store(v, (global_v4u *)((uintptr_t)coef + off) + part);
-      }
-    }
-    if (waiting) next_block(slot);
   }
   // Every lane of the wave calls this together: the blocks of the lanes with `have` leave their
   // buffers.  A block that is `partial` (shared with a neighbouring lane: begun before this run,
@@ -653,7 +606,8 @@ struct hj_block_out {
         __builtin_nontemporal_store(v, (global_v4u *)((uintptr_t)coef + (off & ~1u)) + part);
       }
       else {
-        int16_t *dst = reinterpret_cast<int16_t *>((uintptr_t)coef + (off & ~1u)) + 8*part;
+        typedef __attribute__((address_space(1))) int16_t global_i16;
+        global_i16 *dst = (global_i16 *)((uintptr_t)coef + (off & ~1u)) + 8*part;
         const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -664,92 +618,31 @@ struct hj_block_out {
     }
     if (have && complete) next_block(slot);                 // on to the next block's place
   }
-  __device__ __forceinline__ void flush_partial(int slot, bool) { scatter(slot); }
 };
 
-// GMEM = true (default): the scan is read from global memory (hj_gmem_src) and a workgroup is
-// 512 lanes: 78 KB of LDS (block buffers + one copy of the tables), 2 x 8 waves per CU, 0.78 ms
-// per 48 x 4K; GMEM = false: rows staged in LDS like the sync rounds' (256 lanes, 80 KB, 2 x 4
-// waves per CU, ~1.3 ms; JGA_HUFF_WRITE_GMEM=0).  The dense sync round is the other way round
-// (1.14 ms from LDS, 1.33-1.50 ms from global memory): all its lanes run and it re-reads each
-// row ~2.4x.
-#define HJ_WRITE_BLOCK 512           /* write pass from global memory: 78 KB of LDS, 2 x 8 waves per CU */
-template <bool GMEM>
-__global__ __launch_bounds__((GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK)) void hj_write(const hj_args A) {
-  constexpr int NB = GMEM ? HJ_WRITE_BLOCK : HJ_BLOCK;
-  __shared__ __attribute__((aligned(16))) hj_tables lds_tabs;
-  __shared__ uint32_t lds_win_mem[GMEM ? 1 : 1 + HJ_WIN_DWORDS];   // [0]: the dword "before" row 0 (hj_lds_src::reader)
-  uint32_t *lds_win = lds_win_mem + (GMEM ? 0 : 1);
-  __shared__ uint32_t lds_blk[NB*HJ_BLK_STRIDE];
-  __shared__ hj_image s_im;
-  __shared__ uint8_t s_dezz[64];
-  __shared__ uint8_t s_rank[NB];
-  const hj_image im0 = A.images[blockIdx.y];
-  if (blockIdx.x*NB >= im0.nsub) return;              // grid.x covers the largest image
-  hj_stage_image(&s_im, A.images + blockIdx.y);
-  if (threadIdx.x < 64) s_dezz[threadIdx.x] = HJ_DEZZ[threadIdx.x];
-  // the subsequence start offsets are only needed while staging: they borrow the first
-  // 1 KB of the block buffers, which are zeroed afterwards
-  uint32_t *lds_start = lds_blk;
-  hj_lane_ctx L;
-  const bool on = hj_prologue<!GMEM, NB>(A, im0, &lds_tabs, lds_win, lds_start, L);   // syncs: s_im ready
-  hj_lds_src src = hj_source(lds_win, lds_start, threadIdx.x, hj_sub_dwords(A));
-  hj_gmem_src gsrc;
-  {
-    gsrc.scan32 = reinterpret_cast<const uint32_t *>(A.scan + im0.scan_off);
-    gsrc.dw0 = lds_start[threadIdx.x] >> 2;
-    gsrc.ndw = ((im0.scan_len + 16 + 15) & ~15u) >> 2;
-  }
-  __syncthreads();
-  uint32_t *blk = lds_blk + threadIdx.x*HJ_BLK_STRIDE;
-#pragma unroll
-  for (int k = 0; k < 32; k++) blk[k] = 0;                  // own buffer only: no barrier needed
-  // Lanes with nothing to decode stay in the wave with an empty run: the write-out is
-  // wave-collective and counts on all 64 lanes being there.
-  const hj_image &im = s_im;
-  const uint32_t total = L.seg_nmcu*(uint32_t)im.nslots;
-  const uint32_t b0 = on ? A.B[L.g] : 0u;
-  const bool live = on && b0 < total;
-  const uint32_t sidx = L.g + im.seg0 + L.si;
-  const uint64_t start = live ? A.S[sidx] : 0ull;
-  const uint64_t stop = !live ? 0ull
-   : L.i + 1 < L.seg_nsub ? hj_pos(A.S[sidx + 1]) : (uint64_t)L.seg_end*8;
-  hj_block_out out;
-  out.im = &im;
-  out.coef = A.coef + (long long)blockIdx.y*A.coef_stride;
-  out.blk = blk;
-  out.wave_blk = lds_blk + (threadIdx.x & ~63u)*HJ_BLK_STRIDE;
-  out.rank_lane = s_rank + (threadIdx.x & ~63u);
-  out.init(L.seg_mcu0 + b0/(uint32_t)im.nslots);
-  out.flush_lanes = A.flush_lanes;
-  const uint32_t nblk = live ? total - b0 : 0u;
-  const int p0 = live ? A.D[3*L.g + 0] : 0, p1 = live ? A.D[3*L.g + 1] : 0, p2 = live ? A.D[3*L.g + 2] : 0;
-  const int err = GMEM ? hj_write_decode(gsrc, im, &lds_tabs, s_dezz, start, stop, nblk, p0, p1, p2, out)
-   : hj_write_decode(src, im, &lds_tabs, s_dezz, start, stop, nblk, p0, p1, p2, out);
-  if (err) atomicOr(&A.errors[blockIdx.y], 2u);
-}
-
-// ---- the write pass, second edition (round 3) --------------------------------------------------
-// Same job, same block buffers and the same wave-collective write-out as hj_write<true>, with the
-// per-symbol path rebuilt around what the counters said about the first one (54 scalar + 16
-// branch instructions per 100 vector ones: exec-mask bookkeeping of a loop in which every "rare"
-// case is taken by some lane of the wave on nearly every trip):
+// ---- the write pass -------------------------------------------------------------------------------
+// One lane per subsequence, final decode from its true start state.  The scan is read from global
+// memory (hj_gmem_src), a workgroup is 512 lanes: 81 KB of LDS (block buffers + one copy of the
+// tables), 2 x 8 waves per CU.  The per-symbol path is built around what the counters said about
+// the first edition (54 scalar + 16 branch instructions per 100 vector ones: exec-mask bookkeeping
+// of a loop in which every "rare" case is taken by some lane of the wave on nearly every trip):
 //   * the tables are re-encoded while they are staged (hj_wtables): DC and AC entries are both
 //     32 bits wide, so a symbol's lookup is ONE ds_read_b32 from a table base selected by k == 0;
 //     an EOB advances 127, so that "k + adv has bit 7 set" means EOB and "64 < (k + adv) & 127"
 //     means an AC run past coefficient 63; bit 16 marks bit patterns that are no code.  The
 //     error tests become an OR and a MAX per symbol, looked at once after the run;
 //   * the magnitude is cut out with v_bfe_u32 / v_bfe_i32 (width 0 gives 0: no "s == 0" case);
-//   * only the CURRENT component's DC predictor is updated per symbol (a select), the three
-//     predictors are swapped when the slot changes, i.e. at a write-out;
+//   * no DC prediction: a block's DC coefficient is stored as the DIFFERENCE it was coded as, and
+//     the lane that decoded it also leaves it in A.dc_diff[block in scan order] when the block
+//     leaves its buffer; hj_dc_scan turns differences into values afterwards;
 //   * every symbol stores its value: the de-zigzag table is extended so that the positions an
 //     EOB / a bad run computes (>= 64) land in the spare half-dword behind the block buffer, and a
-//     ZRL stores a zero where a zero is — no "is there a value" branch;
+//     ZRL stores a zero where a zero is — no "is there a value" branch; the store happens one
+//     symbol LATE, so that a symbol costs the wave one LDS round trip, not two in a row;
 //   * pieces of blocks shared with a neighbouring lane ride the same collective write-out as
-//     whole blocks (8 lanes per block, 16 bytes each) with 2-byte stores of their non-zeros,
-//     instead of a 32-dword serial loop per lane that every lane of the wave sat through.
+//     whole blocks (8 lanes per block, 16 bytes each) with 2-byte stores of their non-zeros.
 // What is left under a branch: the level-2 lookup of codes longer than 9 bits and the scan
-// dword refill.
+// dword refill.  815 -> 670 us per 48 x 4K (round 3).
 struct hj_wtables {
   uint32_t dc[2][1 << HJ_FAST_BITS];
   uint32_t ac[2][1 << HJ_FAST_BITS];
@@ -762,12 +655,13 @@ static __device__ __forceinline__ uint32_t hj_wentry(uint32_t e) {      // e: a 
   if (HJ_E_LEN(e) > 16) e |= HJ_W_NOCODE;
   return e;
 }
-#ifndef HJ_WRITE2_UNROLL
-#define HJ_WRITE2_UNROLL 4
+#ifndef HJ_WRITE_UNROLL
+#define HJ_WRITE_UNROLL 4
 #endif
 #define HJ_DEZZ_EXT 192              /* k + adv - 1 <= 63 + 127 */
+#define HJ_WRITE_BLOCK 512
 
-__global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
+__global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
   constexpr int NB = HJ_WRITE_BLOCK;
   __shared__ __attribute__((aligned(16))) hj_wtables lds_tabs;
   __shared__ uint32_t lds_blk[NB*HJ_BLK_STRIDE];
@@ -822,13 +716,11 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
   out.init(seg_mcu0 + b0/(uint32_t)im.nslots);
   out.flush_lanes = A.flush_lanes;
   const uint32_t max_blocks = live ? total - b0 : 0u;
-  int p0 = live ? A.D[3*g + 0] : 0, p1 = live ? A.D[3*g + 1] : 0, p2 = live ? A.D[3*g + 2] : 0;
+  // this lane's blocks in scan order: DC differences go to dcd[n]
+  int16_t *dcd = A.dc_diff + (long long)blockIdx.y*A.dc_stride + (size_t)seg_mcu0*(uint32_t)im.nslots + b0;
 
-  uint32_t slot_comp_bits = 0, slot_tbl_bits = 0;
-  for (int q = 0; q < im.nslots; q++) {
-    slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
-    slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
-  }
+  uint32_t slot_tbl_bits = 0;
+  for (int q = 0; q < im.nslots; q++) slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
   const int nslots = im.nslots;
   hj_gmem_src gsrc;
   gsrc.scan32 = reinterpret_cast<const uint32_t *>(A.scan + im0.scan_off);
@@ -839,11 +731,35 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
   int k = hj_k(start), c = hj_slot(start);
   bool head = k == 0, waiting = false;
   uint32_t n = 0, errbits = 0;
-  int errm = 0;
-  int comp = (int)((slot_comp_bits >> (2*c)) & 3u);
+  int errm = 0, dcv = 0;
   int tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
-  int predc = comp == 0 ? p0 : comp == 1 ? p1 : p2;
   const uint32_t *tb_dc = lds_tabs.dc[tbl & 1], *tb_ac = lds_tabs.ac[tbl >> 1];
+  // The DC differences this lane decodes belong to consecutive blocks (all its blocks but, when
+  // it starts inside one, the first): they leave four at a time, as one 8-byte store — a 2-byte
+  // store per block into lines that eight lanes share cost the pass 75 us per 48 x 4K.
+  struct {
+    int16_t *at;                     // where the next store goes
+    uint64_t acc;
+    uint32_t cnt;
+    __device__ __forceinline__ void push(int v) {
+      acc |= (uint64_t)(uint16_t)v << (16u*(cnt & 3u));
+      cnt++;
+      if ((cnt & 3u) == 0u) {
+        typedef uint64_t __attribute__((aligned(2), may_alias)) u64_a2;
+        *reinterpret_cast<u64_a2 *>(at) = acc;
+        at += 4;
+        acc = 0;
+      }
+    }
+    __device__ __forceinline__ void finish() {
+      typedef uint32_t __attribute__((aligned(2), may_alias)) u32_a2;
+      if (cnt & 2u) { *reinterpret_cast<u32_a2 *>(at) = (uint32_t)acc; at += 2; acc >>= 32; }
+      if (cnt & 1u) *at = (int16_t)acc;
+    }
+  } dcq;
+  dcq.at = dcd + (head ? 0 : 1);
+  dcq.acc = 0;
+  dcq.cnt = 0;
   uint8_t *blk8 = reinterpret_cast<uint8_t *>(blk);
   uint32_t pz = 128;
   int pv = 0;
@@ -851,7 +767,7 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
     bool running = !waiting && br.before_stop() && n < max_blocks;
     if (!out.any(running || waiting)) break;
 #pragma unroll
-    for (int u = 0; u < HJ_WRITE2_UNROLL; u++) {
+    for (int u = 0; u < HJ_WRITE_UNROLL; u++) {
       if (u) running = !waiting && br.before_stop() && n < max_blocks;
       if (!running) continue;
       const uint32_t w = br.window();
@@ -866,15 +782,10 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
       const uint32_t off = 32u - tot;
       const int vu = (int)__builtin_amdgcn_ubfe(w, off, s);
       const int vs = __builtin_amdgcn_sbfe((int)w, off, s);  // < 0 iff the top magnitude bit is set (value >= 0)
-      int v = vu - (vs < 0 ? 0 : (int)((1u << s) - 1u));     // T.81 F.2.2.1 EXTEND; s = 0 gives 0
-      const int pn = predc + v;
-      predc = isdc ? pn : predc;
-      v = isdc ? (int)(int16_t)pn : v;                       // wraps like xjpeg.c:480
+      const int v = vu - (vs < 0 ? 0 : (int)((1u << s) - 1u));   // T.81 F.2.2.1 EXTEND; s = 0 gives 0
+      dcv = isdc ? v : dcv;                                  // the block's DC difference, kept for dcd[]
       const int kn = k + (int)((e >> 5) & 127u);             // one past this coefficient's zig-zag index
-      // The value is stored one symbol LATE: its de-zigzagged position is asked for here and
-      // used after the next symbol's table entry has been asked for, so that a symbol costs the
-      // wave one LDS round trip, not two in a row.
-      *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;
+      *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;   // (the previous symbol's value)
       pz = s_dezz[kn - 1];                                   // (>= 64: the spare half-dword)
       pv = v;
       errbits |= e;
@@ -886,14 +797,12 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
     *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;     // the store still owed
     pz = 128;
     if (out.flush_due(waiting, running && !waiting)) {
+      if (waiting && head) dcq.push(dcv);                    // (the lane that decoded the DC symbol reports it)
       out.flush_blocks(waiting, !head, true, c);
       if (waiting) {
         n++;
-        p0 = comp == 0 ? predc : p0; p1 = comp == 1 ? predc : p1; p2 = comp == 2 ? predc : p2;
         c = c + 1 == nslots ? 0 : c + 1;
-        comp = (int)((slot_comp_bits >> (2*c)) & 3u);
         tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
-        predc = comp == 0 ? p0 : comp == 1 ? p1 : p2;
         tb_dc = lds_tabs.dc[tbl & 1]; tb_ac = lds_tabs.ac[tbl >> 1];
         head = true;
         waiting = false;
@@ -901,8 +810,130 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write2(const hj_args A) {
     }
   }
   // blocks left unfinished (a later lane holds the rest): their coefficients so far
-  out.flush_blocks(k != 0 && n < max_blocks, true, false, c);
+  const bool rest = k != 0 && n < max_blocks;
+  if (rest && head) dcq.push(dcv);
+  dcq.finish();
+  out.flush_blocks(rest, true, false, c);
   if ((errbits & HJ_W_NOCODE) || errm > 64) atomicOr(&A.errors[blockIdx.y], 2u);
+}
+
+// ---- DC prediction (xjpeg.c:480), after the fact ------------------------------------------------------
+// dc_diff[b] = the DC difference of block b of the image in scan order (MCU by MCU, slot by slot),
+// left there by the write pass.  DC value of a block = sum of the differences of its component's
+// blocks from the start of its restart interval up to and including itself (mod 2^16).  One thread
+// takes one MCU (its per-component sums), a workgroup a chunk of 1024 MCUs of one segment; as in
+// hj_scan, FINAL = false stores chunk totals, FINAL = true adds the chunks before and writes the
+// values — to dc_val[slot of the block in the coefficient buffer] (offset/64: the order the
+// block-decode kernels and hj_dc_apply find them in).
+#define HJ_DC_BLOCK 256
+#define HJ_DC_ITEMS 4
+#define HJ_DC_CHUNK (HJ_DC_BLOCK*HJ_DC_ITEMS)
+template <bool FINAL>
+__global__ __launch_bounds__(HJ_DC_BLOCK) void hj_dc_scan(const hj_args A, uint32_t *part_base) {
+  __shared__ uint32_t wtot[HJ_DC_BLOCK/64][3];
+  __shared__ hj_image s_im;
+  const uint32_t gs = blockIdx.x, c = blockIdx.y;
+  int img = 0;
+  {
+    int lo = 0, hi = A.nimages - 1;                         // image of this (batch-global) segment
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (A.images[mid].seg0 <= gs) lo = mid; else hi = mid - 1;
+    }
+    img = lo;
+  }
+  const hj_segment sg = A.segs[gs];
+  const uint32_t m0 = c*HJ_DC_CHUNK;
+  if (m0 >= sg.nmcu) return;
+  hj_stage_image(&s_im, A.images + img);
+  __syncthreads();
+  const hj_image &im = s_im;
+  const uint32_t nslots = (uint32_t)im.nslots;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // chunk totals live at part[3*(first MCU chunk slot of the segment + c)]: segments are laid
+  // out one after the other by their first MCU, so (image's chunk base + mcu0/CHUNK + si + c) is distinct
+  const uint32_t si = gs - im.seg0;
+  uint32_t *part = part_base + 3*((size_t)img*A.dc_chunks_per_image + (sg.mcu0/HJ_DC_CHUNK) + si + c);
+  const int16_t *dcd = A.dc_diff + (long long)img*A.dc_stride;
+  uint32_t slot_comp_bits = 0;
+  for (uint32_t q = 0; q < nslots; q++) slot_comp_bits |= (uint32_t)im.slot_comp[q] << (2*q);
+  const uint32_t i0 = m0 + threadIdx.x*HJ_DC_ITEMS;
+  uint32_t sum[HJ_DC_ITEMS][3];
+  uint32_t mine[3] = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < HJ_DC_ITEMS; j++) {
+    sum[j][0] = sum[j][1] = sum[j][2] = 0;
+    if (i0 + j < sg.nmcu) {
+      const int16_t *d = dcd + (size_t)(sg.mcu0 + i0 + j)*nslots;
+      for (uint32_t q = 0; q < nslots; q++) {
+        const uint32_t comp = (slot_comp_bits >> (2*q)) & 3u, v = (uint32_t)(int)d[q];
+        sum[j][0] += comp == 0 ? v : 0; sum[j][1] += comp == 1 ? v : 0; sum[j][2] += comp == 2 ? v : 0;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 3; f++) mine[f] += sum[j][f];
+  }
+  uint32_t run[3] = {0, 0, 0};
+  if (FINAL) {
+    for (uint32_t k = 1; k <= c; k++) {
+#pragma unroll
+      for (int f = 0; f < 3; f++) run[f] += part[f - 3*(int)k];
+    }
+  }
+  uint32_t inc[3] = {mine[0], mine[1], mine[2]};
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+      const uint32_t x = (uint32_t)__shfl_up((int)inc[f], d);
+      if ((int)lane >= d) inc[f] += x;
+    }
+  }
+  if (lane == 63u) {
+#pragma unroll
+    for (int f = 0; f < 3; f++) wtot[wave][f] = inc[f];
+  }
+  __syncthreads();
+  uint32_t tot[3] = {0, 0, 0};
+#pragma unroll
+  for (int f = 0; f < 3; f++) run[f] += inc[f] - mine[f];
+  for (uint32_t w = 0; w < HJ_DC_BLOCK/64; w++) {
+#pragma unroll
+    for (int f = 0; f < 3; f++) {
+      const uint32_t x = wtot[w][f];
+      tot[f] += x;
+      if (w < wave) run[f] += x;
+    }
+  }
+  if (!FINAL) {
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int f = 0; f < 3; f++) part[f] = tot[f];
+    }
+    return;
+  }
+  int16_t *dcv = A.dc_val + (long long)img*A.dc_stride;
+#pragma unroll
+  for (int j = 0; j < HJ_DC_ITEMS; j++) {
+    if (i0 + j >= sg.nmcu) break;
+    const uint32_t mcu = sg.mcu0 + i0 + j;
+    const int16_t *d = dcd + (size_t)mcu*nslots;
+    for (uint32_t q = 0; q < nslots; q++) {
+      const uint32_t comp = (slot_comp_bits >> (2*q)) & 3u;
+      const uint32_t v = (comp == 0 ? run[0] : comp == 1 ? run[1] : run[2]) + (uint32_t)(int)d[q];
+      run[0] = comp == 0 ? v : run[0]; run[1] = comp == 1 ? v : run[1]; run[2] = comp == 2 ? v : run[2];
+      dcv[hj_block_offset(im, mcu, (int)q) >> 6] = (int16_t)v;
+    }
+  }
+}
+
+// dc_val -> the DC position of every block of the planes (callers that want finished QUANT planes).
+// One thread per block slot of the coefficient buffer; slots that hold no block (the layout's holes)
+// carry a zero, which is what the cleared planes hold there anyway.
+__global__ __launch_bounds__(256) void hj_dc_apply(const hj_args A, int slots_per_image) {
+  const int s = blockIdx.x*256 + threadIdx.x;
+  if (s >= slots_per_image) return;
+  A.coef[(long long)blockIdx.y*A.coef_stride + (long long)s*64] = A.dc_val[(long long)blockIdx.y*A.dc_stride + s];
 }
 
 // Start states, segment numbers and "never ran" marks of every subsequence, written on the device instead of
@@ -959,18 +990,24 @@ extern "C" int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, vo
   return (int)hipGetLastError();
 }
 extern "C" size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs) {
-  return 16*(total_segs + (total_subs >> HJ_SCAN_CHUNK_LOG2) + 2);
+  return 4*(total_segs + (total_subs >> HJ_SCAN_CHUNK_LOG2) + 2);
 }
-extern "C" int hj_launch_write(const hj_args *A, int max_nsub, int gmem, void *stream) {
-  static const bool first_edition = getenv("JGA_HUFF_WRITE2") && atoi(getenv("JGA_HUFF_WRITE2")) == 0;   // (A/B knob)
-  if (gmem) {
-    dim3 grid((max_nsub + HJ_WRITE_BLOCK - 1)/HJ_WRITE_BLOCK, A->nimages);
-    if (first_edition) hipLaunchKernelGGL(hj_write<true>, grid, dim3(HJ_WRITE_BLOCK), 0, (hipStream_t)stream, *A);
-    else hipLaunchKernelGGL(hj_write2, grid, dim3(HJ_WRITE_BLOCK), 0, (hipStream_t)stream, *A);
-  }
-  else {
-    dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
-    hipLaunchKernelGGL(hj_write<false>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A);
+extern "C" int hj_launch_write(const hj_args *A, int max_nsub, void *stream) {
+  dim3 grid((max_nsub + HJ_WRITE_BLOCK - 1)/HJ_WRITE_BLOCK, A->nimages);
+  hipLaunchKernelGGL(hj_write, grid, dim3(HJ_WRITE_BLOCK), 0, (hipStream_t)stream, *A);
+  return (int)hipGetLastError();
+}
+// chunks of HJ_DC_CHUNK MCUs an image's segments can take: every segment at most one partial chunk more
+extern "C" int hj_dc_chunks_per_image(int total_mcus, int max_segs_per_image) {
+  return total_mcus/HJ_DC_CHUNK + max_segs_per_image + 1;
+}
+extern "C" int hj_launch_dc(const hj_args *A, int total_segs, int max_seg_mcus, uint32_t *part, int apply_slots,
+ void *stream) {
+  const dim3 grid(total_segs, (max_seg_mcus + HJ_DC_CHUNK - 1)/HJ_DC_CHUNK);
+  if (grid.y > 1) hipLaunchKernelGGL(hj_dc_scan<false>, grid, dim3(HJ_DC_BLOCK), 0, (hipStream_t)stream, *A, part);
+  hipLaunchKernelGGL(hj_dc_scan<true>, grid, dim3(HJ_DC_BLOCK), 0, (hipStream_t)stream, *A, part);
+  if (apply_slots > 0) {
+    hipLaunchKernelGGL(hj_dc_apply, dim3((apply_slots + 255)/256, A->nimages), dim3(256), 0, (hipStream_t)stream, *A, apply_slots);
   }
   return (int)hipGetLastError();
 }

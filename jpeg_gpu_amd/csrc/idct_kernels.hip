@@ -326,6 +326,16 @@ DEV void load_block_direct(const int16_t *__restrict__ src, uint4 (&rows)[8]) {
   for (int r = 0; r < 8; r++) rows[r] = p[r];   // plain loads: the 8 rows share L1 lines
 }
 
+// DC values handed in beside the planes (the GPU entropy stage leaves DC prediction out of its
+// write pass: jga_huff_decode_split): coefficient 0 of the block in buffer slot `slot` comes from
+// P.dc instead of from the planes.  One 2-byte load per block; wave-uniform test.
+DEV void take_dc(const jga_kparams &P, int img, long long slot, uint4 (&rows)[8]) {
+  if (P.dc) {
+    const uint32_t v = (uint16_t)P.dc[(long long)img*P.dc_stride + slot];
+    rows[0].x = (rows[0].x & 0xffff0000u) | v;
+  }
+}
+
 // Coalesced fetch of a wave's 64 consecutive blocks (8 KB) through LDS: each
 // instruction moves 1 KB contiguous (8 blocks); the LDS image of region k is
 // [row ^ ((k>>1)&1)][block&7] in 16-byte slots so that the per-lane
@@ -386,6 +396,7 @@ __global__ __launch_bounds__(256) void jga_idct_yuv_kernel(const jga_kparams P) 
      rows);
   }
   else load_block_direct(cbase + (long long)s*64, rows);
+  take_dc(P, img, s, rows);
   const uint32_t *q = reinterpret_cast<const uint32_t *>(P.qtab)
    + ((long long)img*3 + pl)*32;
   uint32_t qv[32];
@@ -526,6 +537,7 @@ void jga_idct_rgb_kernel(const jga_kparams P) {
 
   uint4 rows[8];
   load_block_direct(src, rows);                // in flight across the barrier below
+  take_dc(P, img, (src - (P.coef + (long long)img*P.coef_stride)) >> 6, rows);
   if (DEQUANT) {
     if (threadIdx.x < 24) {
       qlds[threadIdx.x] = reinterpret_cast<const uint4 *>(P.qtab + (long long)img*192)[threadIdx.x];
@@ -719,6 +731,7 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
    + rs*(by >> xdec) + (rs >> xdec)*(by & ((1 << xdec) - 1)) + (long long)bxl*64;
   uint4 rows[8];
   load_block_direct(src, rows);                      // in flight across the barrier below
+  take_dc(P, img, (src - (P.coef + (long long)img*P.coef_stride)) >> 6, rows);
   if (DEQUANT) {
     if (threadIdx.x < 24) {
       qlds[threadIdx.x] = reinterpret_cast<const uint4 *>(P.qtab + (long long)img*192)[threadIdx.x];
@@ -845,6 +858,7 @@ __global__ __launch_bounds__(256) void jga_idct_grey_kernel(const jga_kparams P)
      rows);
   }
   else load_block_direct(cbase + (long long)s*64, rows);
+  take_dc(P, img, s, rows);
   const uint32_t *q = reinterpret_cast<const uint32_t *>(P.qtab) + (long long)img*3*32;
   uint32_t qv[32];
   if (DEQUANT) {

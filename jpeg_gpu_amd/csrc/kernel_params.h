@@ -34,6 +34,8 @@ typedef struct jga_kparams {
   int plane_slot0[3];         /* first slot of each plane */
   long long plane_coef_off[3];
   long long plane_data_off[3];
+  const int16_t *dc;          /* NULL, or DC values beside the planes: image i slot s at dc[i*dc_stride + s] */
+  long long dc_stride;
 } jga_kparams;
 
 #ifdef __cplusplus

@@ -65,10 +65,11 @@ struct hlane {
   int hb_images = 0;
   long long hb_scan = 0;
   short *d_coef = nullptr;
+  short *d_dc = nullptr;            // DC values beside the planes (jga_huff_decode_split)
   unsigned short *d_q = nullptr;
   unsigned char *d_out = nullptr, *h_out = nullptr;
   short *h_coef = nullptr;          // pinned, host-entropy fallback only
-  long long cap_coef = 0, cap_q = 0, cap_out = 0, cap_hout = 0, cap_hcoef = 0;
+  long long cap_coef = 0, cap_dc = 0, cap_q = 0, cap_out = 0, cap_hout = 0, cap_hcoef = 0;
 };
 
 }  // namespace
@@ -270,6 +271,7 @@ void run_worker(jga_pipeline *pl, worker *w, jga_job *jobs, int n,
 void free_lane(hlane &l) {
   if (l.hb) jga_huff_destroy(l.hb);
   if (l.d_coef) (void)hipFree(l.d_coef);
+  if (l.d_dc) (void)hipFree(l.d_dc);
   if (l.d_q) (void)hipFree(l.d_q);
   if (l.d_out) (void)hipFree(l.d_out);
   if (l.h_out) (void)hipHostFree(l.h_out);
@@ -397,7 +399,9 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     strided = pitch >= out_bytes && pitch % 16 == 0 && ((uintptr_t)jobv[0]->dev_out) % 16 == 0;
     for (int i = 1; i < m && strided; i++) strided = jobv[i]->dev_out == jobv[0]->dev_out + pitch*i;
   }
+  const long long dcstride = (g.coef_shorts/64 + 127) & ~127ll;
   if (!grow((void **)&l.d_coef, &l.cap_coef, cstride*2*m, false)
+   || !grow((void **)&l.d_dc, &l.cap_dc, dcstride*2*m, false)
    || !grow((void **)&l.d_q, &l.cap_q, 384ll*m, false)) {
     return EXIT_FAILURE;
   }
@@ -423,26 +427,28 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     if (!HOK(hipMemcpyAsync(l.d_q, jga_huff_qtabs(l.hb), 384*(size_t)m, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
     // damaged data in some members does not spoil the others' planes: go on, and report the
     // damaged ones alone (anything else — a launch failure — fails the group)
-    if (jga_huff_decode(l.hb, l.d_coef, cstride, l.stream) != EXIT_SUCCESS) {
+    // (DC values in their own array: the block-decode kernel takes them from there)
+    if (jga_huff_decode_split(l.hb, l.d_coef, cstride, l.d_dc, dcstride, l.stream) != EXIT_SUCCESS) {
       if (jga_huff_image_errors(l.hb) <= 0) return EXIT_FAILURE;
       damaged = true;
     }
   }
   const auto t_c = std::chrono::steady_clock::now();
   const double c_c = trace ? thread_cpu_ms() : 0.0;
+  const short *dcv = host_entropy ? nullptr : l.d_dc;       // (the host entropy stage makes finished planes)
   if (!scattered || strided) {
     unsigned char *base = strided ? jobv[0]->dev_out : l.d_out;
     const long long step = strided ? pitch : ostride;
-    if ((rgb ? jga_idct_rgb_batch(&g, m, l.d_coef, cstride, l.d_q, 1, base, step, l.stream)
-     : jga_idct_yuv_batch(&g, m, l.d_coef, cstride, l.d_q, 1, base, step, l.stream)) != EXIT_SUCCESS) {
+    if ((rgb ? jga_idct_rgb_batch_dc(&g, m, l.d_coef, cstride, dcv, dcstride, l.d_q, 1, base, step, l.stream)
+     : jga_idct_yuv_batch_dc(&g, m, l.d_coef, cstride, dcv, dcstride, l.d_q, 1, base, step, l.stream)) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
     }
   }
   else {
     for (int i = 0; i < m; i++) {
       unsigned char *dst = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
-      if ((rgb ? jga_idct_rgb_batch(&g, 1, l.d_coef + cstride*i, cstride, l.d_q + 192*i, 1, dst, ostride, l.stream)
-       : jga_idct_yuv_batch(&g, 1, l.d_coef + cstride*i, cstride, l.d_q + 192*i, 1, dst, ostride, l.stream)) != EXIT_SUCCESS) {
+      if ((rgb ? jga_idct_rgb_batch_dc(&g, 1, l.d_coef + cstride*i, cstride, dcv ? dcv + dcstride*i : nullptr, dcstride, l.d_q + 192*i, 1, dst, ostride, l.stream)
+       : jga_idct_yuv_batch_dc(&g, 1, l.d_coef + cstride*i, cstride, dcv ? dcv + dcstride*i : nullptr, dcstride, l.d_q + 192*i, 1, dst, ostride, l.stream)) != EXIT_SUCCESS) {
         return EXIT_FAILURE;
       }
     }

@@ -15,7 +15,7 @@ EXPORTED = [
     "HIPJPEG_DECODE_CTX_VTBL", "LIBJPEG_DECODE_CTX_VTBL", "jga_libjpeg_available", "jga_version", "jga_last_error", "jga_image_init",
     "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",
     "jga_parse_header", "jga_entropy_decode", "jga_entropy_decode_pack",
-    "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_kernel_name",
+    "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_idct_rgb_batch_dc", "jga_idct_yuv_batch_dc", "jga_huff_decode_split", "jga_kernel_name",
     "jga_index_count", "jga_unpack_batch", "jga_yuv_rgb_batch",
     "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
     "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
@@ -67,6 +67,8 @@ L.jga_entropy_decode_pack.argtypes = [C.c_char_p, _i, _G, _vp, _ll, _vp,
                                       C.POINTER(_ll), C.POINTER(_ll)]
 L.jga_idct_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
 L.jga_idct_yuv_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+L.jga_idct_rgb_batch_dc.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+L.jga_idct_yuv_batch_dc.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp, _i, _vp, _ll, _vp]
 L.jga_yuv_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp]
 L.jga_index_count.argtypes = [_G]
 L.jga_index_count.restype = _ll
@@ -102,6 +104,7 @@ L.jga_huff_destroy.argtypes = [_vp]
 L.jga_huff_destroy.restype = None
 L.jga_huff_prepare.argtypes = [_vp, C.POINTER(C.c_char_p), C.POINTER(_i), _i, _G, _vp]
 L.jga_huff_decode.argtypes = [_vp, _vp, _ll, _vp]
+L.jga_huff_decode_split.argtypes = [_vp, _vp, _ll, _vp, _ll, _vp]
 L.jga_huff_prepare_verdict.argtypes = [_vp, _i]
 L.jga_huff_upload_bytes.argtypes = [_vp]
 L.jga_huff_upload_bytes.restype = _ll
@@ -464,6 +467,11 @@ class HuffBatch:
 
     def decode(self, d_coef_ptr, coef_stride, stream=None):
         check(L.jga_huff_decode(self.ptr, d_coef_ptr, coef_stride, stream))
+        return L.jga_huff_last_rounds(self.ptr)
+
+    def decode_split(self, d_coef_ptr, coef_stride, d_dc_ptr, dc_stride, stream=None):
+        """Planes with DC differences + the DC values by buffer slot in d_dc (for *_batch_dc)."""
+        check(L.jga_huff_decode_split(self.ptr, d_coef_ptr, coef_stride, d_dc_ptr, dc_stride, stream))
         return L.jga_huff_last_rounds(self.ptr)
 
     def assisted(self):

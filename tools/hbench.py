@@ -40,13 +40,16 @@ d_coef = lib.DeviceBuffer(stride * 2 * n)
 d_q = lib.DeviceBuffer(3 * 64 * 2 * n)
 d_rgb = lib.DeviceBuffer(ostride * n)
 d_q.upload(hb.qtabs())
+split = os.environ.get("SPLIT", "1") == "1"        # DC values beside the planes (what the pipeline does)
+dcs = (g.coef_shorts // 64 + 127) // 128 * 128
+d_dc = lib.DeviceBuffer(dcs * 2 * n)
 for rep in range(3):
     t0 = time.perf_counter()
-    rounds = hb.decode(d_coef.ptr, stride)
+    rounds = hb.decode_split(d_coef.ptr, stride, d_dc.ptr, dcs) if split else hb.decode(d_coef.ptr, stride)
     t_h = time.perf_counter() - t0
     t0 = time.perf_counter()
-    lib.check(lib.L.jga_idct_rgb_batch(C.byref(g), n, d_coef.ptr, stride, d_q.ptr, 1, d_rgb.ptr,
-                                       ostride, None))
+    lib.check(lib.L.jga_idct_rgb_batch_dc(C.byref(g), n, d_coef.ptr, stride, d_dc.ptr if split else None, dcs,
+                                          d_q.ptr, 1, d_rgb.ptr, ostride, None))
     lib.check(lib.L.jga_stream_sync(None))
     t_i = time.perf_counter() - t0
     mp = n * w * h / 1e6
@@ -55,6 +58,10 @@ for rep in range(3):
               w, h, samp, n, ri, hb.upload_bytes() / 1e6, t_prep * 1e3, t_h * 1e3, rounds,
               mp / t_h, t_i * 1e3, mp / (t_h + t_i)))
 want = lib.entropy_decode(jpegs[0], g)
+hb.decode(d_coef.ptr, stride)                      # finished planes for the comparison
 got = d_coef.download(g.coef_shorts * 2, dtype=np.int16)
 m = lib.real_coef_mask(g)
 print("coefficients equal host stage:", bool(np.array_equal(got[m], want[m])))
+import oracle  # noqa: E402
+print("rgb of image 0 equals oracle (split=%s):" % split,
+      bool(np.array_equal(d_rgb.download(g.rgb_bytes), oracle.Oracle().decode_rgb(jpegs[0])[1].reshape(-1))))
