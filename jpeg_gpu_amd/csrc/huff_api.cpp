@@ -715,7 +715,9 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
     // DC differences (scan order) and, unless the caller brings its own array, DC values (by
     // buffer slot); one stride for both: the caller's, or the slot count rounded up
     const size_t stride = d_dc ? (size_t)dc_stride : (size_t)((b->geom.coef_shorts/64 + 127) & ~127ll);
-    const size_t need = stride*(size_t)b->nimages;
+    // (sized for the batch object's capacity, not for this batch: no re-allocation — it
+    // synchronises the device — when a bigger batch of the same frames follows)
+    const size_t need = stride*(size_t)(b->max_images > b->nimages ? b->max_images : b->nimages);
     if (need > b->dc_cap) {
       if (b->d_dc) (void)hipFree(b->d_dc);
       b->d_dc = NULL; b->dc_cap = 0;
@@ -723,7 +725,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
       b->dc_cap = need;
     }
     A.dc_chunks_per_image = hj_dc_chunks_per_image(b->geom.nhmb*b->geom.nvmb, (int)b->max_segs_image);
-    const size_t pneed = 3*(size_t)b->nimages*(size_t)A.dc_chunks_per_image;
+    const size_t pneed = 3*(size_t)(b->max_images > b->nimages ? b->max_images : b->nimages)*(size_t)A.dc_chunks_per_image;
     if (pneed > b->dcpart_cap) {
       if (b->d_dcpart) (void)hipFree(b->d_dcpart);
       b->d_dcpart = NULL; b->dcpart_cap = 0;

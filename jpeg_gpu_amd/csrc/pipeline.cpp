@@ -320,6 +320,7 @@ struct device_turn {
 // geometry, an unparsable member, ...): GROUP_REJECTED when prepare() turned the group down
 // (its per-member verdicts then say who is to blame), EXIT_FAILURE for anything else.
 enum { GROUP_REJECTED = 2 };
+uint64_t geometry_key(const unsigned char *p, int size);
 int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads) {
   const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
   const bool copy_back = pl->cfg.copy_back != 0;
@@ -332,10 +333,23 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     sizes[i] = jobv[i]->size;
     total += jobv[i]->size + 4096;
   }
+  // Buffers are sized for a FULL group of this geometry (cfg.batch frame equivalents) the first
+  // time, whatever this group holds: a short first job (cut into small groups) must not leave the
+  // lanes re-allocating — pinned host memory at that — in the middle of the next, longer one.
+  int full = m;
+  {
+    const uint64_t key = geometry_key(jobv[0]->jpeg, jobv[0]->size);
+    const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
+    const long long batch = pl->cfg.batch > 0 ? pl->cfg.batch : 48;
+    long long cap = px > 0 ? (batch*3840ll*2160 + px/2)/px : batch;
+    cap = cap < 1 ? 1 : cap > 16*batch ? 16*batch : cap;
+    if (cap > full) full = (int)cap;
+  }
+  const long long total_full = total/m*full + total/4;
   if (!l.hb || m > l.hb_images || total > l.hb_scan) {
     if (l.hb) jga_huff_destroy(l.hb);
-    l.hb_images = m > l.hb_images ? m : l.hb_images;
-    l.hb_scan = total + total/4 > l.hb_scan ? total + total/4 : l.hb_scan;
+    l.hb_images = full > l.hb_images ? full : l.hb_images;
+    l.hb_scan = total_full > l.hb_scan ? total_full : l.hb_scan;
     l.hb = jga_huff_create(l.hb_images, l.hb_scan);
     if (!l.hb) { l.hb_images = 0; l.hb_scan = 0; return EXIT_FAILURE; }
 
@@ -400,13 +414,13 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     for (int i = 1; i < m && strided; i++) strided = jobv[i]->dev_out == jobv[0]->dev_out + pitch*i;
   }
   const long long dcstride = (g.coef_shorts/64 + 127) & ~127ll;
-  if (!grow((void **)&l.d_coef, &l.cap_coef, cstride*2*m, false)
-   || !grow((void **)&l.d_dc, &l.cap_dc, dcstride*2*m, false)
-   || !grow((void **)&l.d_q, &l.cap_q, 384ll*m, false)) {
+  if (!grow((void **)&l.d_coef, &l.cap_coef, cstride*2*full, false)
+   || !grow((void **)&l.d_dc, &l.cap_dc, dcstride*2*full, false)
+   || !grow((void **)&l.d_q, &l.cap_q, 384ll*full, false)) {
     return EXIT_FAILURE;
   }
-  if ((!all_given && !grow((void **)&l.d_out, &l.cap_out, ostride*m, false))
-   || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*m, true))) {
+  if ((!all_given && !grow((void **)&l.d_out, &l.cap_out, ostride*full, false))
+   || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*full, true))) {
     return EXIT_FAILURE;
   }
   device_turn turn(pl);

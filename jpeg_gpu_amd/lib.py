@@ -67,8 +67,9 @@ L.jga_entropy_decode_pack.argtypes = [C.c_char_p, _i, _G, _vp, _ll, _vp,
                                       C.POINTER(_ll), C.POINTER(_ll)]
 L.jga_idct_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
 L.jga_idct_yuv_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
-L.jga_idct_rgb_batch_dc.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp, _i, _vp, _ll, _vp]
-L.jga_idct_yuv_batch_dc.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+if hasattr(L, "jga_idct_rgb_batch_dc"):          # (absent from older A/B builds given through JGA_LIB_PATH)
+    L.jga_idct_rgb_batch_dc.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp, _i, _vp, _ll, _vp]
+    L.jga_idct_yuv_batch_dc.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp, _i, _vp, _ll, _vp]
 L.jga_yuv_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _ll, _vp]
 L.jga_index_count.argtypes = [_G]
 L.jga_index_count.restype = _ll
@@ -104,7 +105,8 @@ L.jga_huff_destroy.argtypes = [_vp]
 L.jga_huff_destroy.restype = None
 L.jga_huff_prepare.argtypes = [_vp, C.POINTER(C.c_char_p), C.POINTER(_i), _i, _G, _vp]
 L.jga_huff_decode.argtypes = [_vp, _vp, _ll, _vp]
-L.jga_huff_decode_split.argtypes = [_vp, _vp, _ll, _vp, _ll, _vp]
+if hasattr(L, "jga_huff_decode_split"):
+    L.jga_huff_decode_split.argtypes = [_vp, _vp, _ll, _vp, _ll, _vp]
 L.jga_huff_prepare_verdict.argtypes = [_vp, _i]
 L.jga_huff_upload_bytes.argtypes = [_vp]
 L.jga_huff_upload_bytes.restype = _ll
@@ -120,8 +122,9 @@ L.jga_huff_set_inputs_pinned.argtypes = [_vp, _i]
 L.jga_huff_set_inputs_pinned.restype = None
 L.jga_huff_set_blocking_waits.argtypes = [_vp, _i]
 L.jga_huff_set_blocking_waits.restype = None
-L.jga_huff_set_copy_stream.argtypes = [_vp, _vp]
-L.jga_huff_set_copy_stream.restype = None
+if hasattr(L, "jga_huff_set_copy_stream"):
+    L.jga_huff_set_copy_stream.argtypes = [_vp, _vp]
+    L.jga_huff_set_copy_stream.restype = None
 L.jga_host_register.argtypes = [_vp, C.c_size_t]
 L.jga_host_unregister.argtypes = [_vp]
 L.jga_huff_qtabs.argtypes = [_vp]
