@@ -345,7 +345,10 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     cap = cap < 1 ? 1 : cap > 16*batch ? 16*batch : cap;
     if (cap > full) full = (int)cap;
   }
-  const long long total_full = total/m*full + total/4;
+  // (with the clean-up on the device the batch holds the raw scans AND the clean streams)
+  const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pl->offload_cleanup);
+  const long long total_full = (total/m*full + total/4)*(on_device ? 2 : 1);
+  if (on_device) total *= 2;
   if (!l.hb || m > l.hb_images || total > l.hb_scan) {
     if (l.hb) jga_huff_destroy(l.hb);
     l.hb_images = full > l.hb_images ? full : l.hb_images;
@@ -366,7 +369,6 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   {
     bool pinned = true;
     for (int i = 0; i < m; i++) pinned = pinned && (jobv[i]->pinned & 1) != 0;
-    const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pl->offload_cleanup);
     jga_huff_set_device_unstuff(l.hb, on_device);
     jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
