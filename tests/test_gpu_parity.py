@@ -677,6 +677,61 @@ def test_irregular_huffman_tables_take_the_host_entropy_stage(gpu, orc, synth):
         pl.close()
 
 
+@pytest.mark.parametrize("sampling", SAMPLINGS)
+@pytest.mark.parametrize("ri", [0, -1, 3])
+def test_split_decode_dc_values_beside_the_planes(gpu, orc, synth, sampling, ri):
+    """jga_huff_decode_split: the planes keep the DC DIFFERENCES, the DC values (src/xjpeg.c:480)
+    come in an array of their own, one per 128-byte slot of the coefficient buffer, and
+    jga_idct_rgb_batch_dc / jga_idct_yuv_batch_dc take them from there: same pixels and planes
+    as the oracle, the DC array equal to the oracle's QUANT planes' DC positions, for every
+    sampling, with and without restart intervals (every interval starts its predictors at 0),
+    several images per batch."""
+    import oracle
+    files = [synth.synthetic_jpeg(200 + 16 * i, 120, sampling, quality=60 + 10 * i, restart_interval=ri, seed=70 + i)
+             for i in range(1)] * 1 + [synth.synthetic_jpeg(200, 120, sampling, quality=q, restart_interval=ri, seed=80 + q)
+                                       for q in (35, 95)]
+    files = files[1:]                                       # (one geometry per batch)
+    n = len(files)
+    hb = gpu.HuffBatch(n, sum(map(len, files)) + 4096 * n)
+    g = hb.prepare(files)
+    cs = gpu._align(g.coef_shorts * 2) // 2
+    dcs = (g.coef_shorts // 64 + 127) // 128 * 128
+    d_coef, d_dc, d_q = gpu.DeviceBuffer(cs * 2 * n), gpu.DeviceBuffer(dcs * 2 * n), gpu.DeviceBuffer(384 * n)
+    ob, yb = gpu._align(g.rgb_bytes), gpu._align(g.yuv_bytes, 256)
+    d_rgb, d_yuv = gpu.DeviceBuffer(ob * n), gpu.DeviceBuffer(yb * n)
+    try:
+        d_coef.upload(np.full(cs * n, 0x5A5A, np.int16))
+        d_dc.upload(np.full(dcs * n, 0x7B7B, np.int16))
+        hb.decode_split(d_coef.ptr, cs, d_dc.ptr, dcs)
+        d_q.upload(hb.qtabs())
+        gpu.check(gpu.L.jga_idct_rgb_batch_dc(C.byref(g), n, d_coef.ptr, cs, d_dc.ptr, dcs, d_q.ptr, 1, d_rgb.ptr, ob, None))
+        gpu.check(gpu.L.jga_idct_yuv_batch_dc(C.byref(g), n, d_coef.ptr, cs, d_dc.ptr, dcs, d_q.ptr, 1, d_yuv.ptr, yb, None))
+        gpu.check(gpu.L.jga_stream_sync(None))
+        dc = d_dc.download(dtype=np.int16).reshape(n, dcs)
+        planes_dev = d_coef.download(dtype=np.int16).reshape(n, cs)
+        m = gpu.real_coef_mask(g)
+        slots = np.flatnonzero(m[::64])                      # buffer slots that hold a block
+        for i, f in enumerate(files):
+            quant = orc.decode(f, oracle.QUANT)[1]
+            assert np.array_equal(dc[i][slots], quant[::64][slots]), (sampling, ri, i)
+            ac = np.ones(g.coef_shorts, bool)
+            ac[::64] = False                                 # everything but the DC positions is final
+            assert np.array_equal(planes_dev[i][:g.coef_shorts][m & ac], quant[m & ac])
+            assert np.array_equal(d_rgb.download(g.rgb_bytes, offset=i * ob), orc.decode_rgb(f)[1].reshape(-1))
+            _, planes = orc.decode(f, oracle.YUV)
+            want = np.concatenate([p.reshape(-1) for p in planes])
+            assert np.array_equal(d_yuv.download(g.yuv_bytes, offset=i * yb), want)
+        # ... and the plain call puts them in place
+        hb.decode(d_coef.ptr, cs)
+        full = d_coef.download(dtype=np.int16).reshape(n, cs)
+        for i, f in enumerate(files):
+            assert np.array_equal(full[i][:g.coef_shorts][m], orc.decode(f, oracle.QUANT)[1][m])
+    finally:
+        hb.close()
+        for b in (d_coef, d_dc, d_q, d_rgb, d_yuv):
+            b.free()
+
+
 def test_tables_repeated_under_a_third_id_stay_on_the_gpu_entropy_stage(gpu, orc, synth):
     """An encoder that writes one DHT per component gives Cr tables byte-identical to Cb's under
     an id of their own: the device format tells tables apart by content, so the frame keeps
