@@ -48,6 +48,7 @@ struct jga_huff_batch {
   int last_assisted;           // subsequences the host walked in the last decode
   int image_errors;            // images of the last decode whose data was damaged
   int assist_hint;             // the previous decode needed the host walk
+  int spec_rounds;             // rounds queued before the speculative tail (0: not yet decided)
   hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
   hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
@@ -788,17 +789,52 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   A.flush_lanes = flush_lanes;
   A.sub_log2 = b->sub_log2;
   const int GROUP = group;
+  // The tail of a decode: prefix sums, write pass, DC values, the images' verdicts.
+  auto queue_tail = [&]() -> int {
+    if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+    HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
+    if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+    // DC differences -> DC values; into the planes too unless the caller takes the array itself
+    if (hj_launch_dc(&A, (int)b->total_seg, (int)b->max_seg_mcus, b->d_dcpart, d_dc ? 0 : (int)(b->geom.coef_shorts/64), st)) {
+      return jga_fail("huff: launch failed");
+    }
+    HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
+    return EXIT_SUCCESS;
+  };
+  // A photograph settles in 4-6 rounds, so the tail is queued SPECULATIVELY behind the first
+  // group of rounds: one host round trip per decode instead of two (a lone 1080p frame: ~60 us of
+  // its ~700).  If the last of those rounds still moved something, the tail ran on unsettled
+  // states — bounded like a corrupt stream's, but wrong: outputs and verdicts are reset, the
+  // rounds go on, the tail runs again, and the next decode of this batch object queues more
+  // rounds first (JGA_HUFF_SPECULATE=0: never).
+  static const bool speculate_ok = !(getenv("JGA_HUFF_SPECULATE") && atoi(getenv("JGA_HUFF_SPECULATE")) == 0);
+  bool speculated = speculate_ok && !b->assist_hint, tail_done = false;
+  if (b->spec_rounds < GROUP) b->spec_rounds = GROUP;
   for (;;) {
-    for (int k = 0; k < GROUP && round < HJ_MAX_ROUNDS; k++, round++) {
+    const int burst = speculated && round == 0 ? b->spec_rounds : GROUP;
+    for (int k = 0; k < burst && round < HJ_MAX_ROUNDS; k++, round++) {
       if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, round >= sparse_from, st)) {
         return jga_fail("huff: launch failed");
       }
     }
+    const bool with_tail = speculated && round == burst;
     HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
+    if (with_tail && queue_tail() != EXIT_SUCCESS) return EXIT_FAILURE;
     lap(c_launch);
     HOK(wait_stream(b, st));
     lap(c_wait);
-    if (b->h_ran[round - 1] == 0) break;                   // a round in which nothing moved
+    if (b->h_ran[round - 1] == 0) { tail_done = with_tail; break; }   // a round in which nothing moved
+    if (with_tail) {
+      // not settled: undo what the speculative tail wrote (planes, DC arrays, verdicts)
+      b->spec_rounds = round + 4 < 24 ? round + 4 : 24;
+      if (b->unstuffed_on_device) {
+        HOK(hipMemcpyAsync(b->d_errors, b->d_blob + b->off_perr, 4*(size_t)b->nimages, hipMemcpyDeviceToDevice, st));
+      }
+      else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
+      HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, st));
+      HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, st));
+      HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, st));
+    }
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
     // (a batch object whose previous decode needed the walk — the same camera, the same
     // letterbox — gets it at the first check instead of waiting out twelve rounds)
@@ -807,17 +843,13 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   b->last_rounds = 0;
   while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;
   b->assist_hint = b->last_assisted > 0;
-  if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
-  HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
-  if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
-  // DC differences -> DC values; into the planes too unless the caller takes the array itself
-  if (hj_launch_dc(&A, (int)b->total_seg, (int)b->max_seg_mcus, b->d_dcpart, d_dc ? 0 : (int)(b->geom.coef_shorts/64), st)) {
-    return jga_fail("huff: launch failed");
+  if (tail_done && b->last_rounds + 2 < b->spec_rounds && b->spec_rounds > GROUP) b->spec_rounds--;   // (drifts back)
+  if (!tail_done) {
+    if (queue_tail() != EXIT_SUCCESS) return EXIT_FAILURE;
+    lap(c_launch);
+    HOK(wait_stream(b, st));
+    lap(c_wait);
   }
-  HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
-  lap(c_launch);
-  HOK(wait_stream(b, st));
-  lap(c_wait);
   if (trace) fprintf(stderr, "  huff decode: this thread's CPU in launches + copies %.2f ms, in waits %.2f ms\n", c_launch, c_wait);
   // per-image verdicts stay readable (jga_huff_image_error): the other images of the batch
   // are decoded correctly whatever one damaged member did
