@@ -745,13 +745,11 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   A.nimages = b->nimages;
   // reset: states back to the guesses, "never ran", planes zero (only non-zeros are written)
   A.sub_log2 = b->sub_log2;
-  if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
-  HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));
   // (on-device unstuffing has already had its say about every image: early end, RSTn counters)
-  if (b->unstuffed_on_device) {
-    HOK(hipMemcpyAsync(b->d_errors, b->d_blob + b->off_perr, 4*(size_t)b->nimages, hipMemcpyDeviceToDevice, st));
+  if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub,
+   b->unstuffed_on_device ? (const uint32_t *)(b->d_blob + b->off_perr) : NULL, st)) {
+    return jga_fail("huff: launch failed");
   }
-  else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
   // the planes are only touched by the write pass: zero them on the side stream, behind
   // whatever the caller's stream has queued so far, while the rounds run
   HOK(hipEventRecord(b->ev_begin, st));

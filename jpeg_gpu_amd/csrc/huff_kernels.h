@@ -35,7 +35,8 @@ extern "C" {
 #endif
 /* sparse != 0: the one-wave-per-group variant for rounds in which few lanes still move */
 /* fills sub_seg and the start states S (guesses) on the device */
-int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, void *stream);
+/* ... and clears ran[] and sets errors[] (to verdicts0[], device memory, or to 0) */
+int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream);
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);

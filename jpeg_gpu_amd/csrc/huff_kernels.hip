@@ -562,15 +562,21 @@ struct hj_block_out {
     return w != 0ull && ((int)__popcll(w) >= flush_lanes || __ballot(running) == 0ull);
   }
   // offset (shorts) of the current MCU's block `slot` in the image's planes
-  // (inverse of the MCU loop nest + block placement of src/xjpeg.c:461-472, 556-561)
+  // (inverse of the MCU loop nest + block placement of src/xjpeg.c:461-472, 556-561), from the
+  // slot's descriptor: one 8-byte LDS read instead of seven byte reads per block
+  const uint2 *slotd;                // [nslots] {plane base + sbx*64, hs | vs << 8 | sby << 16 | xdec << 24}
+  uint32_t rs;                       // shorts per row of luma blocks
+  static __device__ __forceinline__ uint2 describe(const hj_image &m, int slot) {
+    const int comp = m.slot_comp[slot];
+    return make_uint2((uint32_t)m.comp_coef_off[comp] + ((uint32_t)m.slot_sbx[slot] << 6),
+     (uint32_t)m.comp_hs[comp] | (uint32_t)m.comp_vs[comp] << 8 | (uint32_t)m.slot_sby[slot] << 16
+     | (uint32_t)m.comp_xdec[comp] << 24);
+  }
   __device__ __forceinline__ uint32_t offset(int slot) const {
-    const int comp = im->slot_comp[slot];
-    const uint32_t bx = mbx*im->comp_hs[comp] + im->slot_sbx[slot];
-    const uint32_t by = mby*im->comp_vs[comp] + im->slot_sby[slot];
-    const uint32_t xd = im->comp_xdec[comp];
-    const uint32_t rs = (uint32_t)im->w0_blocks*64u;
-    return (uint32_t)im->comp_coef_off[comp] + rs*(by >> xd) + (rs >> xd)*(by & ((1u << xd) - 1u))
-     + (bx << 6);
+    const uint2 d = slotd[slot];
+    const uint32_t hs = d.y & 255u, vs = (d.y >> 8) & 255u, sby = (d.y >> 16) & 255u, xd = d.y >> 24;
+    const uint32_t by = mby*vs + sby;
+    return d.x + ((mbx*hs) << 6) + rs*(by >> xd) + (rs >> xd)*(by & ((1u << xd) - 1u));
   }
   __device__ __forceinline__ void next_block(int slot) {
     if (slot + 1 == im->nslots) {
@@ -669,9 +675,11 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
   __shared__ uint32_t s_dezz[HJ_DEZZ_EXT];           // BYTE offset of zig-zag position i in a block buffer (dwords: the
                                                      // loaded value is used as it comes, a symbol later)
   __shared__ uint8_t s_rank[NB];
+  __shared__ uint2 s_slotd[HJ_MAX_SLOTS];
   const hj_image im0 = A.images[blockIdx.y];
   if (blockIdx.x*NB >= im0.nsub) return;              // grid.x covers the largest image
   hj_stage_image(&s_im, A.images + blockIdx.y);
+  if (threadIdx.x < (uint32_t)im0.nslots) s_slotd[threadIdx.x] = hj_block_out::describe(A.images[blockIdx.y], (int)threadIdx.x);
   if (threadIdx.x < HJ_DEZZ_EXT) s_dezz[threadIdx.x] = threadIdx.x < 64 ? 2u*HJ_DEZZ[threadIdx.x] : 128u;
   {
     const hj_tables *T = A.tables + blockIdx.y;
@@ -713,6 +721,8 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
   out.blk = blk;
   out.wave_blk = lds_blk + (threadIdx.x & ~63u)*HJ_BLK_STRIDE;
   out.rank_lane = s_rank + (threadIdx.x & ~63u);
+  out.slotd = s_slotd;
+  out.rs = (uint32_t)im0.w0_blocks*64u;
   out.init(seg_mcu0 + b0/(uint32_t)im.nslots);
   out.flush_lanes = A.flush_lanes;
   const uint32_t max_blocks = live ? total - b0 : 0u;
@@ -940,8 +950,15 @@ __global__ __launch_bounds__(256) void hj_dc_apply(const hj_args A, int slots_pe
 // uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
 // (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
 // their first byte.  A workgroup takes 4096 subsequences of one segment.
-__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg) {
+__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg, const uint32_t *verdicts0) {
   const uint32_t gs = blockIdx.x;
+  // (also the decode's bookkeeping words, instead of two memsets in front of it: "did anything
+  // run in round r", and every image's verdict — what the on-device scan clean-up already
+  // found, or nothing)
+  if (gs == 0 && blockIdx.y == 0) {
+    for (int i = threadIdx.x; i < HJ_MAX_ROUNDS; i += 256) A.ran[i] = 0;
+    for (int i = threadIdx.x; i < A.nimages; i += 256) A.errors[i] = verdicts0 ? verdicts0[i] : 0u;
+  }
   int lo = 0, hi = A.nimages - 1;                           // image of this (batch-global) segment
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -963,9 +980,9 @@ __global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t 
   }
   if (k1 == sg.nsub && threadIdx.x == 0) S[sg.nsub] = 0;
 }
-extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, void *stream) {
+extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream) {
   hipLaunchKernelGGL(hj_init_states, dim3(total_segs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
-   const_cast<uint32_t *>(A->sub_seg));
+   const_cast<uint32_t *>(A->sub_seg), verdicts0);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,
