@@ -141,11 +141,11 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
     }
 #pragma unroll
     for (int u = 0; u < PK_INFLIGHT; u++) {
-      // words up to the first zero after the DC word belong to the block
-      const unsigned long long zero = __ballot(w[u] == 0u && lane > 0u);
-      const uint32_t nwords = zero ? (uint32_t)__builtin_ctzll(zero) : 64u;
-      const int pos = pk_wave_scan(lane ? (int)(w[u] >> 12) + 1 : 0);
-      if (start[u] < limit && lane < nwords && pos < 64) {
+      // words up to the first zero after the DC word belong to the block.  The terminator needs
+      // no vote: a zero word adds 64 to the prefix sum, so its own position and every later one
+      // fail the "position < 64" test that ends a block anyway
+      const int pos = pk_wave_scan(lane == 0u ? 0 : w[u] == 0u ? 64 : (int)(w[u] >> 12) + 1);
+      if (start[u] < limit && pos < 64) {
         lds_line[wv][u][s_dezz[pos]] = (uint16_t)pk_sext12(w[u]);
       }
     }
