@@ -1,5 +1,7 @@
-"""gpurun_out/<tag>/ (tools/r2_check.sh) -> profiles/<tag>_rocprof_summary.md, profiles/<tag>_bench.json,
-profiles/pmc_latest.json.  Usage: python tools/summarise_check.py r2c [r2]"""
+"""gpurun_out/<tag>/ (tools/r2_check.sh, tools/r3_check.sh) -> profiles/<name>_rocprof_summary.md,
+profiles/<name>_bench.json, profiles/pmc_latest.json (+ round 3: <name>_configs_bench.txt,
+<name>_huffman_kernels.txt, <name>_huffman_pmc.md, <name>_harness_fps.txt).
+Usage: python tools/summarise_check.py r3c r3"""
 import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 name = sys.argv[2] if len(sys.argv) > 2 else tag
@@ -7,9 +9,11 @@ src = os.path.join("gpurun_out", tag)
 bench = json.load(open(os.path.join(src, "bench.json")))
 out = ["# rocprofv3 summary, %s" % name, "",
        "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 12 --warmup 3 --no-cpu --no-e2e "
-       "--no-pack --no-other --no-gpu-entropy` (tools/r2_check.sh): the end-to-end pipeline leg (12 steps of "
-       "32 files through 8 lanes, plus set-up and warm-up batches) followed by the roofline leg (launches of "
-       "the fused kernel on 48 resident images).", "",
+       "--no-pack --no-other --no-gpu-entropy` (tools/r2_check.sh / r3_check.sh; round 3 adds `--no-configs "
+       "--no-measure-traffic`): the end-to-end pipeline legs (12 steps of 128 files through 8 lanes in groups "
+       "of 32, pageable then pinned files, plus set-up and warm-up batches) followed by the roofline leg "
+       "(launches of the fused kernel on 48 resident images).  Under the pipeline several groups' kernels "
+       "share the device, so their averages are longer than alone (hj_* alone: <name>_huffman_kernels.txt).", "",
        "## kernel stats", "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
 avg = None
 for fn in glob.glob(os.path.join(src, "**", "stats_kernel_stats.csv"), recursive=True):
@@ -46,3 +50,14 @@ out += ["", "## bench line of the same build (un-profiled run)", "```", json.dum
 open(os.path.join("profiles", "%s_rocprof_summary.md" % name), "w").write("\n".join(out) + "\n")
 json.dump(bench, open(os.path.join("profiles", "%s_bench.json" % name), "w"), indent=1)
 print("\n".join(out))
+
+# round 3 extras
+if "configs" in bench:
+    with open(os.path.join("profiles", "%s_configs_bench.txt" % name), "w") as f:
+        f.write("# bench.py `configs` object of the same run: every BASELINE.json config on one MI355X beside its CPU path\n")
+        for k, v in bench["configs"].items():
+            f.write("%s %s\n" % (k, json.dumps(v)))
+for fn, to in (("huffman_kernels.txt", "%s_huffman_kernels.txt"), ("huffman_pmc.txt", "%s_huffman_pmc.md"),
+               ("harness_fps.txt", "%s_harness_fps.txt")):
+    if os.path.exists(os.path.join(src, fn)):
+        shutil.copy(os.path.join(src, fn), os.path.join("profiles", to % name))
