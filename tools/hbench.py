@@ -12,8 +12,18 @@ from jpeg_gpu_amd import lib, synth  # noqa: E402
 
 w, h, samp, n, ri = (sys.argv[1:] + [None] * 5)[:5]
 w, h, samp, n, ri = int(w or 3840), int(h or 2160), samp or "420", int(n or 48), int(ri or 0)
-distinct = [synth.synthetic_jpeg(w, h, samp, quality=90, restart_interval=ri, seed=1234 + i)
-            for i in range(min(n, 6))]
+if os.environ.get("CONTENT") == "light":       # bench.py's lighter content: smooth image + fine grain, 0.6 bits per pixel
+    def photo_like(i):
+        r = np.random.default_rng(900 + i)
+        xx = np.linspace(0, 1, w, dtype=np.float32)[None, :, None]
+        yy = np.linspace(0, 1, h, dtype=np.float32)[:, None, None]
+        cc = np.arange(3, dtype=np.float32)[None, None, :]
+        img = 128 + 60 * np.sin((6 + i) * xx * (cc + 1)) * np.cos(4 * yy) + r.normal(0, 2, (h, w, 3)).astype(np.float32)
+        return synth.encode_pixels(np.clip(img, 0, 255).astype(np.uint8), samp, 90, restart_interval=ri)
+    distinct = [photo_like(i) for i in range(min(n, 6))]
+else:
+    distinct = [synth.synthetic_jpeg(w, h, samp, quality=90, restart_interval=ri, seed=1234 + i)
+                for i in range(min(n, 6))]
 jpegs = [distinct[i % len(distinct)] for i in range(n)]
 hb = lib.HuffBatch(n, sum(map(len, jpegs)) + 4096 * n)
 if os.environ.get("PINNED") == "1":        # files in pinned memory, scans DMA'd in place + cleaned up on the GPU
