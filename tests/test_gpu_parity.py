@@ -1,9 +1,12 @@
 """Parity tests proper: the HIP path, called through the C-ABI, against the oracle
 on the same seeded inputs — bit-exact (integer/byte outputs)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
+
+from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -730,6 +733,51 @@ def test_split_decode_dc_values_beside_the_planes(gpu, orc, synth, sampling, ri)
         hb.close()
         for b in (d_coef, d_dc, d_q, d_rgb, d_yuv):
             b.free()
+
+
+def test_speculative_tail_that_ran_too_early_is_undone(gpu):
+    """The tail of a decode (prefix sums, write pass, DC pass) is queued behind the first group of
+    rounds without waiting for them to settle.  With ONE round per group and one in-group iteration
+    (JGA_HUFF_ITERS=1,1,1: read once per process, hence the child) the first tail always runs on
+    unsettled states: outputs and verdicts must be reset and the decode must still end equal to
+    the oracle — planes, DC array, pixels — on the second decode of the same batch object too
+    (which queues more rounds first), for clean and for damaged members."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, ctypes as C
+sys.path.insert(0, %r)
+import oracle
+from jpeg_gpu_amd import lib, synth
+orc = oracle.Oracle()
+files = [synth.synthetic_jpeg(640, 360, "420", quality=q, restart_interval=ri, seed=s) for q, ri, s in ((90, 0, 1), (50, 7, 2), (95, -1, 3))]
+bad = bytearray(files[0]); sos = bad.find(b"\xff\xda"); del bad[sos + 200:sos + 1200]; bad = bytes(bad)   # a kilobyte of entropy-coded data missing
+for batch, damaged in ((files, None), (files[:2] + [bad], 2)):
+    hb = lib.HuffBatch(len(batch), sum(map(len, batch)) + 4096 * len(batch))
+    g = hb.prepare(batch)
+    cs = lib._align(g.coef_shorts * 2) // 2
+    d = lib.DeviceBuffer(cs * 2 * len(batch))
+    m = lib.real_coef_mask(g)
+    for rep in range(3):
+        d.upload(np.full(cs * len(batch), 0x5A5A, np.int16))
+        try:
+            rounds = hb.decode(d.ptr, cs)
+            assert damaged is None, "a damaged member must be reported"
+        except lib.JgaError:
+            assert damaged is not None and lib.L.jga_huff_image_error(hb.ptr, damaged) != 0
+            assert all(lib.L.jga_huff_image_error(hb.ptr, i) == 0 for i in range(len(batch)) if i != damaged)
+        got = d.download(dtype=np.int16).reshape(len(batch), cs)
+        for i, f in enumerate(batch):
+            if i == damaged: continue
+            want = orc.decode(f, oracle.QUANT)[1]
+            assert np.array_equal(got[i][:g.coef_shorts][m], want[m]), (rep, i)
+    hb.close(); d.free()
+print("OK", lib.L.jga_huff_last_rounds.__name__)
+""" % ROOT
+    env = dict(os.environ, JGA_HUFF_ITERS="1,1,1")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
 def test_tables_repeated_under_a_third_id_stay_on_the_gpu_entropy_stage(gpu, orc, synth):
