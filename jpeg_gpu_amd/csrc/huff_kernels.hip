@@ -1,9 +1,11 @@
 // huff_kernels.hip — GPU-parallel baseline-JPEG entropy decode (gfx950).
-// Algorithm and state definitions: huff_common.h.  Three kernels:
+// Algorithm and state definitions: huff_common.h.  The kernels:
+//   hj_init_states start states (guesses), segment numbers, "never ran" marks, bookkeeping words
 //   hj_sync_round  one lane per subsequence; re-decodes when its start state moved.
 //                  A workgroup iterates internally (states handed lane-to-lane
 //                  through LDS) until none of its lanes moves, so most of the
 //                  propagation needs no extra launch.
+//   hj_sync_sparse the same round for the later launches: one wave per 256 subsequences
 //   hj_scan        per restart segment: exclusive prefix sums of the block counts over the
 //                  segment's lanes
 //   hj_write       one lane per subsequence: final decode.  Blocks are assembled in LDS;
@@ -18,8 +20,9 @@
 // Integer/byte work.  Every subsequence of a workgroup gets its own LDS copy — 35
 // big-endian dwords (alignment + 128 bytes + look-ahead) at an odd stride, so lanes
 // walking their own copies hit different banks — next to the image's two-level Huffman
-// lookup (12 KB with the DC entries widened: hj_ltables).  LDS is what bounds occupancy: 54.2 KB
-// per sync workgroup (3 per CU), 81 KB per write workgroup (2 per CU).
+// lookup (12 KB with the DC entries widened: hj_ltables).  LDS is what bounds occupancy: 53 440 B
+// per sync workgroup (3 per CU — 54 208 B did not fit three times), 81 344 B per write workgroup
+// (2 per CU).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
     }
     __syncthreads();
     // The first run of all starts every lane from a guess: only its end state means anything,
-    // so it is a LITE run (no block count, no DC sums: a third fewer instructions per symbol)
+    // so it is a LITE run (no block count, started part-way into the subsequence)
     // and every lane is marked for a counted run from whatever state it is handed next.
     const bool lite = lite_first && round == 0 && it == 0;
     if (t < total) {
