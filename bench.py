@@ -119,13 +119,31 @@ def launch_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+class quiet_stdout:
+    """Send file descriptor 1 to stderr for the duration: libraries that chat on stdout while the
+    process group comes up (gloo prints "[Gloo] Rank 0 is connected to ..." from C++) must not
+    put lines next to the ONE JSON line rank 0 owes its caller."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def dry_launch(args, rank, local_rank, world):
     """Who am I, which CPUs are mine — the launch path without the GPU work (CPU test)."""
     import torch.distributed as dist
     from jpeg_gpu_amd import shard
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with quiet_stdout():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
     pin = {} if args.no_pin else shard.pin_rank_to_gpu_node(local_rank, world)
     quota = shard.cpu_quota()
     me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
@@ -158,7 +176,9 @@ class Comm:
             return
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with quiet_stdout():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()                                           # (connects the pairs now, while stdout is away)
         self.backend = "gloo"
         if share or os.environ.get("JGA_BENCH_NO_RCCL") == "1":
             self.note = ("ranks share devices (JGA_BENCH_SHARE_GPUS): RCCL refuses two ranks per GPU" if share
@@ -166,11 +186,12 @@ class Comm:
             return
         ok, why, grp = 1, "", None
         try:
-            grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120),
-                                 device_id=torch.device("cuda", gpu))
-            t = torch.ones(1, device="cuda")
-            dist.all_reduce(t, group=grp)
-            torch.cuda.synchronize()
+            with quiet_stdout():
+                grp = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120),
+                                     device_id=torch.device("cuda", gpu))
+                t = torch.ones(1, device="cuda")
+                dist.all_reduce(t, group=grp)
+                torch.cuda.synchronize()
             ok = int(t.item() == world)
             why = "" if ok else "first all-reduce returned %r" % t.item()
         except Exception as e:                      # RCCL / IPC not usable on this box

@@ -17,8 +17,8 @@ def run_bench(*flags, timeout=900):
                        env={k: v for k, v in os.environ.items()
                             if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout      # ONE line on stdout, and it is the JSON
     return json.loads(lines[0])
 
 
