@@ -754,7 +754,23 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   // whatever the caller's stream has queued so far, while the rounds run
   HOK(hipEventRecord(b->ev_begin, st));
   HOK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
-  HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
+  // (the planes themselves need no clear: the write pass stores whole 128-byte lines, and the lines
+  // of blocks that two lanes share are zeroed by hj_scan<true> — only the slots at the end of a
+  // decimated plane that hold no block are cleared here, so that the buffer reads like the host
+  // stage's)
+  for (int p = 0; p < b->geom.nplanes; p++) {
+    const jga_plane_geom &pg = b->geom.plane[p];
+    const long long rs = (long long)b->geom.w0*8, used = (long long)pg.hblocks*pg.vblocks*64;
+    const long long end = p + 1 < b->geom.nplanes ? b->geom.plane[p + 1].coef_off : b->geom.coef_shorts;
+    if ((long long)pg.hblocks*64 != (rs >> pg.xdec)) {          // rows with gaps (rare samplings): clear it all
+      HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
+      break;
+    }
+    if (end > pg.coef_off + used) {
+      HOK(hipMemset2DAsync(d_coef + pg.coef_off + used, (size_t)coef_stride*2, 0, (size_t)(end - pg.coef_off - used)*2,
+       (size_t)b->nimages, b->side));
+    }
+  }
   // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
   HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
   HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
@@ -829,7 +845,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
         HOK(hipMemcpyAsync(b->d_errors, b->d_blob + b->off_perr, 4*(size_t)b->nimages, hipMemcpyDeviceToDevice, st));
       }
       else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
-      HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, st));
+      // (the planes: every line the final write pass touches is rewritten or zeroed first)
       HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, st));
       HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, st));
     }

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
   if (__ballot(ran_any) != 0ull && lane == 0) atomicOr(&A.ran[round], 1u);
 }
 
+typedef uint32_t hj_v4u __attribute__((ext_vector_type(4)));
 #define HJ_SCAN_BLOCK 1024          /* threads per chunk */
 #define HJ_SCAN_ITEMS 4             /* consecutive lanes summed by one thread */
 #define HJ_SCAN_CHUNK_LOG2 12       /* HJ_SCAN_BLOCK*HJ_SCAN_ITEMS lanes per workgroup */
@@ -471,9 +472,17 @@ static_assert(HJ_SCAN_BLOCK*HJ_SCAN_ITEMS == 1 << HJ_SCAN_CHUNK_LOG2, "chunk siz
 //   FINAL = true   adds the totals of the chunks before it in the segment and writes B.
 // Chunk c of segment gs keeps its total at scan_part[gs + (first lane of the segment >> 12)
 // + c]: distinct and increasing over the batch, below total_seg + total_sub/4096 + 1.
+// FINAL also prepares the planes for the write pass, which stores a block that two lanes share as
+// 2-byte pieces onto a ZERO background and every other block as a whole 128-byte line: each lane
+// whose start state lies inside a block zeroes that block's line here (now that B says which
+// block it is) — 128 bytes per subsequence instead of a memset of every plane of the batch
+// (1.2 GB per 48 x 4K, on the side stream: a quarter of the HBM traffic of a decode of lighter
+// content, whose pipeline ran 285-300 Gpixel/s with it and 337-346 without).
 template <bool FINAL>
 __global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
   __shared__ uint32_t wtot[HJ_SCAN_BLOCK/64];
+  __shared__ uint32_t zline[FINAL ? HJ_SCAN_BLOCK*HJ_SCAN_ITEMS : 1];   // 128-byte lines to zero (~0: none)
+  __shared__ hj_image s_im;
   // blockIdx.x = batch-global segment; find its image (few images: linear search)
   const uint32_t gs = blockIdx.x, c = blockIdx.y;
   int img = 0;
@@ -490,14 +499,21 @@ __global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
   const uint32_t i0 = c0 + threadIdx.x*HJ_SCAN_ITEMS;
   const uint32_t g0 = first + i0;
   uint32_t v[HJ_SCAN_ITEMS], slot[HJ_SCAN_ITEMS];
+  bool inside[HJ_SCAN_ITEMS];                                 // the lane starts inside a block
   uint32_t mine = 0;
+  if (FINAL) hj_stage_image(&s_im, A.images + img);           // (read after the barrier below)
 #pragma unroll
   for (int j = 0; j < HJ_SCAN_ITEMS; j++) {
     v[j] = 0;
     slot[j] = 0;
+    inside[j] = false;
     if (i0 + j < sg.nsub) {
       v[j] = A.R[g0 + j];
-      if (FINAL) slot[j] = (uint32_t)hj_slot(A.S[g0 + j + im.seg0 + si]);
+      if (FINAL) {
+        const uint64_t st = A.S[g0 + j + im.seg0 + si];
+        slot[j] = (uint32_t)hj_slot(st);
+        inside[j] = hj_k(st) != 0;
+      }
     }
     mine += v[j];
   }
@@ -529,14 +545,28 @@ __global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
   if (c0 + (1u << HJ_SCAN_CHUNK_LOG2) >= sg.nsub && threadIdx.x == 0 && run + tot < total) bad = true;
 #pragma unroll
   for (int j = 0; j < HJ_SCAN_ITEMS; j++) {
+    uint32_t z = ~0u;
     if (i0 + j < sg.nsub) {
       A.B[g0 + j] = run;
       // the slot a lane starts in must agree with the number of blocks before it
       if (run < total && slot[j] != run % (uint32_t)im.nslots) bad = true;
+      else if (run < total && inside[j]) {
+        z = (uint32_t)(hj_block_offset(s_im, sg.mcu0 + run/(uint32_t)im.nslots, (int)slot[j]) >> 6);
+      }
     }
+    zline[threadIdx.x*HJ_SCAN_ITEMS + j] = z;
     run += v[j];
   }
   if (bad) atomicOr(&A.errors[img], 1u);
+  __syncthreads();
+  // eight threads per line, 16 bytes each: whole-line stores
+  typedef __attribute__((address_space(1))) hj_v4u global_v4u;
+  int16_t *planes = A.coef + (long long)img*A.coef_stride;
+  const hj_v4u zero = {0u, 0u, 0u, 0u};
+  for (uint32_t e = threadIdx.x >> 3; e < HJ_SCAN_BLOCK*HJ_SCAN_ITEMS; e += HJ_SCAN_BLOCK/8) {
+    const uint32_t l = zline[e];
+    if (l != ~0u) *((global_v4u *)((uintptr_t)planes + (size_t)l*128u) + (threadIdx.x & 7u)) = zero;
+  }
 }
 
 // Output side of the write pass.  Every coefficient lands in the lane's LDS block buffer first.
@@ -545,7 +575,6 @@ __global__ __launch_bounds__(HJ_SCAN_BLOCK) void hj_scan(const hj_args A) {
 // instruction writes whole 128-byte lines (16-byte pieces at a 128-byte stride per lane cost
 // 2-4x more in the memory pipeline).
 typedef int16_t __attribute__((may_alias)) hj_i16_alias;    // 16-bit view of the dword buffer
-typedef uint32_t hj_v4u __attribute__((ext_vector_type(4)));
 struct hj_block_out {
   const hj_image *im;
   int16_t *coef;                     // this image's planes
