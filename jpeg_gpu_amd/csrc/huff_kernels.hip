@@ -625,33 +625,38 @@ struct hj_block_out {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long mask = __ballot(have);
     if (mask == 0ull) return;
+    // whole blocks first, shared ones after them: each kind gets its own passes, so the 2-byte
+    // stores of the shared ones are only issued by passes that hold nothing else (one or two per
+    // write-out instead of most of them)
+    const unsigned long long pmask = __ballot(have && partial), fmask = mask & ~pmask;
+    const uint32_t nfull = (uint32_t)__popcll(fmask), cnt = (uint32_t)__popcll(mask);
     if (have) {
-      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      rank_lane[r] = (uint8_t)lane;
-      blk[32] = offset(slot)*2u | (partial ? 1u : 0u);       // (byte offsets of blocks are multiples of 128)
+      const unsigned long long m = partial ? pmask : fmask;
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      rank_lane[(partial ? nfull : 0u) + r] = (uint8_t)lane;
+      blk[32] = offset(slot)*2u;                             // byte offset of the block (a multiple of 128)
     }
-    const bool pieces = __ballot(have && partial) != 0ull;
-    const uint32_t cnt = (uint32_t)__popcll(mask), part = lane & 7u;
+    const uint32_t part = lane & 7u;
     typedef __attribute__((address_space(1))) hj_v4u global_v4u;
-    for (uint32_t k = lane >> 3; k < cnt; k += 8) {
+    for (uint32_t k = lane >> 3; k < nfull; k += 8) {
       uint32_t *src = wave_blk + (uint32_t)rank_lane[k]*HJ_BLK_STRIDE;
       const uint32_t off = src[32];
       hj_v4u v;
       v.x = src[4*part]; v.y = src[4*part + 1]; v.z = src[4*part + 2]; v.w = src[4*part + 3];
       src[4*part] = 0; src[4*part + 1] = 0; src[4*part + 2] = 0; src[4*part + 3] = 0;
-      if (!pieces || !(off & 1u)) {
-        __builtin_nontemporal_store(v, (global_v4u *)((uintptr_t)coef + (off & ~1u)) + part);
-      }
-      else {
-        typedef __attribute__((address_space(1))) int16_t global_i16;
-        global_i16 *dst = (global_i16 *)((uintptr_t)coef + (off & ~1u)) + 8*part;
-        const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(v, (global_v4u *)((uintptr_t)coef + off) + part);
+    }
+    for (uint32_t k = nfull + (lane >> 3); k < cnt; k += 8) {
+      uint32_t *src = wave_blk + (uint32_t)rank_lane[k]*HJ_BLK_STRIDE;
+      const uint32_t off = src[32];
+      const uint32_t d4[4] = {src[4*part], src[4*part + 1], src[4*part + 2], src[4*part + 3]};
+      src[4*part] = 0; src[4*part + 1] = 0; src[4*part + 2] = 0; src[4*part + 3] = 0;
+      typedef __attribute__((address_space(1))) int16_t global_i16;
+      global_i16 *dst = (global_i16 *)((uintptr_t)coef + off) + 8*part;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          if (d4[q] & 0xffffu) dst[2*q] = (int16_t)(d4[q] & 0xffffu);
-          if (d4[q] >> 16) dst[2*q + 1] = (int16_t)(d4[q] >> 16);
-        }
+      for (int q = 0; q < 4; q++) {
+        if (d4[q] & 0xffffu) dst[2*q] = (int16_t)(d4[q] & 0xffffu);
+        if (d4[q] >> 16) dst[2*q + 1] = (int16_t)(d4[q] >> 16);
       }
     }
     if (have && complete) next_block(slot);                 // on to the next block's place
