@@ -780,14 +780,14 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   b->image_errors = 0;
   // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
   struct knobs {
-    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = 1, assist_after = 12;
+    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = -1, assist_after = 12;
     knobs() {
       const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group": in-group iterations, rounds per host check
       if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
       if (it0 < 1) it0 = 1;
       if (it1 < 1) it1 = 1;
       if (group < 1) group = 1;
-      e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel
+      e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (default: by batch size)
       if (e) sparse_from = atoi(e);
       e = getenv("JGA_HUFF_ASSIST_AFTER");             // rounds before the host walks the unsettled stretches
       if (e) assist_after = atoi(e) > 0 ? atoi(e) : 1;
@@ -799,7 +799,15 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   static const knobs K;
   const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;     // no LDS rows that long: global-memory readers only
   const int it0 = K.it0, it1 = K.it1, group = K.group, flush_lanes = K.flush_lanes,
-            sparse_from = long_subs ? 0 : K.sparse_from, assist_after = K.assist_after;
+            assist_after = K.assist_after;
+  // Which kernel runs the later rounds.  The sparse one (a wave per 256 subsequences, rows read from
+  // global memory) is for batches that fill the device: there a dense launch pays staging for
+  // every group that still has one moving lane.  Up to ~200k subsequences (8 x 4K, 32 x 1080p) the
+  // dense kernel's LDS rows make each step of the chain shorter and nothing else wants the CUs:
+  // one 1080p frame 0.55 -> 0.48 ms, one 4K 0.62 -> 0.52, 8 x 4K 0.71 -> 0.68, but 16 x 4K 0.96 -> 1.05
+  // (profiles/r3_entropy_stage_steps.md).
+  const int sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from
+   : b->total_sub <= 200u*1024u ? HJ_MAX_ROUNDS : 1;
   A.flush_lanes = flush_lanes;
   A.sub_log2 = b->sub_log2;
   const int GROUP = group;

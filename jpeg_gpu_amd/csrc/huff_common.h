@@ -231,11 +231,16 @@ HJ_HD int hj_value(uint32_t w, int len, int s) {
 // LITE: only the end state is wanted (r.nblocks is left 0) — the very first run of a
 // subsequence starts from a GUESS (bit 0 of the subsequence, slot 0), so everything but where it
 // ends is meaningless.
+// The table choice of every MCU slot, two bits each (a kernel works it out once, not per run: the
+// loop is a chain of dependent LDS reads).
+HJ_HD uint32_t hj_slot_tables(const hj_image &im) {
+  uint32_t bits = 0;
+  for (int q = 0; q < im.nslots; q++) bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
+  return bits;
+}
 template <class Src, bool LITE = false, class Tab = hj_tables>
 HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
- uint64_t start, uint64_t stop_bit, bool last = false) {
-  uint32_t slot_tbl_bits = 0;
-  for (int q = 0; q < im.nslots; q++) slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
+ uint64_t start, uint64_t stop_bit, bool last, uint32_t slot_tbl_bits) {
   const int nslots = im.nslots;
   typename hj_reader_of<Src>::type br;
   hj_run r;
@@ -265,6 +270,12 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
   r.nblocks = nblocks;
   r.end_state = hj_pack(br.tell(), c, k);
   return r;
+}
+
+template <class Src, bool LITE = false, class Tab = hj_tables>
+HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
+ uint64_t start, uint64_t stop_bit, bool last = false) {
+  return hj_sync_decode<Src, LITE, Tab>(src, im, T, start, stop_bit, last, hj_slot_tables(im));
 }
 
 // The final pass as the HOST states it (tools/huff_emul.cpp, tests/test_huff_emul.py): every

@@ -247,6 +247,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
   // moved into dense waves (any lane can decode any subsequence of the staged window),
   // so the work follows the number of runs, not iterations x 256.
   const uint32_t lane = t & 63, wave = t >> 6;
+  const uint32_t slot_tables = hj_slot_tables(s_im);
   // (only a few iterations: the long, thin tail of the propagation is left to later
   // launches, which cost one short run each instead of keeping this group resident)
   for (int it = 0; it < max_iters; it++) {
@@ -284,13 +285,13 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
         uint64_t skip = (uint64_t)(lite_first - 1)*8;
         if (from + 2*skip > stop_bit) skip = from < stop_bit ? (stop_bit - from)/2 : 0;
         r = hj_sync_decode<hj_lds_src, true, hj_ltables>(hj_source(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
-         hj_pack(from + skip, hj_slot(start), hj_k(start)), stop_bit, (sb >> 31) == 0u);
+         hj_pack(from + skip, hj_slot(start), hj_k(start)), stop_bit, (sb >> 31) == 0u, slot_tables);
         lds_ran[sub] = 2;                                    // ran, but nothing to publish
         lds_dirty[sub] = 1;                                  // (its own flag: no other lane writes it now)
       }
       else {
         r = hj_sync_decode<hj_lds_src, false, hj_ltables>(hj_source(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
-         (uint64_t)(sb & 0x7fffffffu)*8, (sb >> 31) == 0u);
+         (uint64_t)(sb & 0x7fffffffu)*8, (sb >> 31) == 0u, slot_tables);
         lds_R[sub] = (uint16_t)r.nblocks;
         lds_ran[sub] = 1;
       }
@@ -328,7 +329,9 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
 // after it is staged: 23 KB of LDS per 4 groups instead of 54 KB per group, 28 groups in
 // flight per CU instead of three.  Same indexing, same hand-over protocol and same results as
 // hj_sync_round.
+#ifndef HJ_SPARSE_GROUPS
 #define HJ_SPARSE_GROUPS 4
+#endif
 static __device__ __forceinline__ void hj_wave_sync() {      // LDS hand-over inside one wavefront
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -394,6 +397,7 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
   if (__ballot(any) == 0ull) return;
   const uint8_t *scan = A.scan + im.scan_off;
   const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;
+  const uint32_t slot_tables = hj_slot_tables(s_im);
   for (int it = 0; it < max_iters; it++) {
     // the lanes that moved, in order
     uint32_t total = 0;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
           src.dw0 = first >> 2;
           src.ndw = padded >> 2;
         }
-        const hj_run r = hj_sync_decode<hj_gmem_src, false, sparse_tables>(src, s_im, &lds_tabs, start, (uint64_t)stop*8, i + 1 >= sg.nsub);
+        const hj_run r = hj_sync_decode<hj_gmem_src, false, sparse_tables>(src, s_im, &lds_tabs, start, (uint64_t)stop*8, i + 1 >= sg.nsub, slot_tables);
         const uint64_t end_state = r.end_state;
         A.R[gg] = r.nblocks;                     // (a later run of the same subsequence overwrites it)
         lds_ran[sub] = 1;
@@ -766,8 +770,7 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
   // this lane's blocks in scan order: DC differences go to dcd[n]
   int16_t *dcd = A.dc_diff + (long long)blockIdx.y*A.dc_stride + (size_t)seg_mcu0*(uint32_t)im.nslots + b0;
 
-  uint32_t slot_tbl_bits = 0;
-  for (int q = 0; q < im.nslots; q++) slot_tbl_bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
+  const uint32_t slot_tbl_bits = hj_slot_tables(im);
   const int nslots = im.nslots;
   hj_gmem_src gsrc;
   gsrc.scan32 = reinterpret_cast<const uint32_t *>(A.scan + im0.scan_off);
