@@ -750,37 +750,12 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
    b->unstuffed_on_device ? (const uint32_t *)(b->d_blob + b->off_perr) : NULL, st)) {
     return jga_fail("huff: launch failed");
   }
-  // the planes are only touched by the write pass: zero them on the side stream, behind
-  // whatever the caller's stream has queued so far, while the rounds run
-  HOK(hipEventRecord(b->ev_begin, st));
-  HOK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
-  // (the planes themselves need no clear: the write pass stores whole 128-byte lines, and the lines
-  // of blocks that two lanes share are zeroed by hj_scan<true> — only the slots at the end of a
-  // decimated plane that hold no block are cleared here, so that the buffer reads like the host
-  // stage's)
-  for (int p = 0; p < b->geom.nplanes; p++) {
-    const jga_plane_geom &pg = b->geom.plane[p];
-    const long long rs = (long long)b->geom.w0*8, used = (long long)pg.hblocks*pg.vblocks*64;
-    const long long end = p + 1 < b->geom.nplanes ? b->geom.plane[p + 1].coef_off : b->geom.coef_shorts;
-    if ((long long)pg.hblocks*64 != (rs >> pg.xdec)) {          // rows with gaps (rare samplings): clear it all
-      HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
-      break;
-    }
-    if (end > pg.coef_off + used) {
-      HOK(hipMemset2DAsync(d_coef + pg.coef_off + used, (size_t)coef_stride*2, 0, (size_t)(end - pg.coef_off - used)*2,
-       (size_t)b->nimages, b->side));
-    }
-  }
-  // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
-  HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
-  HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
-  HOK(hipEventRecord(b->ev_zeroed, b->side));
   int round = 0;
   b->last_assisted = 0;
   b->image_errors = 0;
   // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
   struct knobs {
-    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = -1, assist_after = 12;
+    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = -1, assist_after = 12, lean = 1;
     knobs() {
       const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group": in-group iterations, rounds per host check
       if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
@@ -789,6 +764,8 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
       if (group < 1) group = 1;
       e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (default: by batch size)
       if (e) sparse_from = atoi(e);
+      e = getenv("JGA_HUFF_LEAN");                     // 0: the dense kernel's stateless row reader (A/B knob)
+      if (e) lean = atoi(e) != 0;
       e = getenv("JGA_HUFF_ASSIST_AFTER");             // rounds before the host walks the unsettled stretches
       if (e) assist_after = atoi(e) > 0 ? atoi(e) : 1;
       e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching
@@ -806,11 +783,43 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   // dense kernel's LDS rows make each step of the chain shorter and nothing else wants the CUs:
   // one 1080p frame 0.55 -> 0.48 ms, one 4K 0.62 -> 0.52, 8 x 4K 0.71 -> 0.68, but 16 x 4K 0.96 -> 1.05
   // (profiles/r3_entropy_stage_steps.md).
-  const int sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from
-   : b->total_sub <= 200u*1024u ? HJ_MAX_ROUNDS : 1;
+  const bool small_batch = b->total_sub <= 200u*1024u;
+  const int sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from : small_batch ? HJ_MAX_ROUNDS : 1;
   A.flush_lanes = flush_lanes;
   A.sub_log2 = b->sub_log2;
   const int GROUP = group;
+  // What the write pass needs cleared (DC arrays, padding slots) is queued on the side stream AFTER
+  // the first burst of rounds has been handed to the device: the seven API calls take the host
+  // ~40 us, which a lone frame's first round used to spend waiting to be launched.
+  bool side_queued = false;
+  auto queue_side = [&]() -> int {
+    if (side_queued) return EXIT_SUCCESS;
+    side_queued = true;
+    HOK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
+    // (the planes themselves need no clear: the write pass stores whole 128-byte lines, and the lines
+    // of blocks that two lanes share are zeroed by hj_scan<true> — only the slots at the end of a
+    // decimated plane that hold no block are cleared here, so that the buffer reads like the host
+    // stage's)
+    for (int p = 0; p < b->geom.nplanes; p++) {
+      const jga_plane_geom &pg = b->geom.plane[p];
+      const long long rs = (long long)b->geom.w0*8, used = (long long)pg.hblocks*pg.vblocks*64;
+      const long long end = p + 1 < b->geom.nplanes ? b->geom.plane[p + 1].coef_off : b->geom.coef_shorts;
+      if ((long long)pg.hblocks*64 != (rs >> pg.xdec)) {          // rows with gaps (rare samplings): clear it all
+        HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
+        break;
+      }
+      if (end > pg.coef_off + used) {
+        HOK(hipMemset2DAsync(d_coef + pg.coef_off + used, (size_t)coef_stride*2, 0, (size_t)(end - pg.coef_off - used)*2,
+         (size_t)b->nimages, b->side));
+      }
+    }
+    // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
+    HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
+    HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
+    HOK(hipEventRecord(b->ev_zeroed, b->side));
+    return EXIT_SUCCESS;
+  };
+  HOK(hipEventRecord(b->ev_begin, st));          // (the side stream starts behind whatever the caller queued before us)
   // The tail of a decode: prefix sums, write pass, DC values, the images' verdicts.
   auto queue_tail = [&]() -> int {
     if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
@@ -835,10 +844,11 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   for (;;) {
     const int burst = speculated && round == 0 ? b->spec_rounds : GROUP;
     for (int k = 0; k < burst && round < HJ_MAX_ROUNDS; k++, round++) {
-      if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, round >= sparse_from, st)) {
+      if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, round >= sparse_from ? 1 : K.lean ? -1 : 0, st)) {
         return jga_fail("huff: launch failed");
       }
     }
+    if (queue_side() != EXIT_SUCCESS) return EXIT_FAILURE;
     const bool with_tail = speculated && round == burst;
     HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
     if (with_tail && queue_tail() != EXIT_SUCCESS) return EXIT_FAILURE;

@@ -75,6 +75,45 @@ struct hj_lds_src {
   };
 };
 
+// The same LDS row read with the two dwords under the position in registers and the one after
+// them already on its way, so a symbol's chain of dependent operations holds one LDS round trip
+// (the table lookup), not two: a few more instructions per symbol, no branch.  What the dense
+// kernel runs with (a lone frame's ~9 runs one after the other: 94 -> 83 us per launch; 48 x 4K:
+// 2.00 -> 1.95 ms in an interleaved A/B); the stateless reader above stays for comparison
+// (JGA_HUFF_LEAN=0).
+struct hj_lds_reg_src {
+  const uint32_t *base;
+  uint32_t bit0;
+  typedef void has_reader;
+  struct reader {
+    const uint32_t *base;
+    uint32_t bit0;
+    int32_t r1, stop1, d;
+    uint32_t w0, w1, w2;
+    __device__ __forceinline__ void init(const hj_lds_reg_src &src, uint64_t pos, uint64_t stop_bit) {
+      base = src.base; bit0 = src.bit0;
+      r1 = (int32_t)((uint32_t)pos - bit0) - 1;
+      stop1 = (int32_t)((uint32_t)stop_bit - bit0) - 1;
+      d = r1 >> 5;                                           // -1: the dword before the row (its bits are never used)
+      w0 = base[d]; w1 = base[d + 1]; w2 = base[d + 2];
+    }
+    __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
+    __device__ __forceinline__ bool room9() const { return r1 + 9 <= stop1; }
+    __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w0, w1, ~(uint32_t)r1); }
+    __device__ __forceinline__ void skip(int n) {
+      r1 += n;
+      const int32_t nd = r1 >> 5;                            // a symbol is at most 31 bits: one dword further at most
+      const bool cross = nd != d;
+      const uint32_t nx = base[nd + 2];                      // (read every time, used two crossings later; the rows
+      w0 = cross ? w1 : w0;                                  //  are followed by spare dwords)
+      w1 = cross ? w2 : w1;
+      w2 = nx;
+      d = nd;
+    }
+    __device__ __forceinline__ uint64_t tell() const { return (uint64_t)((uint32_t)(r1 + 1) + bit0); }
+  };
+};
+
 // Bit source straight from the clean scan in global memory, for the write pass: the lane
 // keeps the two dwords under its position in registers and a third one in flight, and only
 // issues a (lane-divergent, L1-resident) dword load when its position crosses into the next
@@ -194,15 +233,17 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
 }
 
 // Bit source of subsequence `sub` of the group.
-static __device__ __forceinline__ hj_lds_src hj_source(const uint32_t *lds_win,
+template <class RowSrc>
+static __device__ __forceinline__ RowSrc hj_source(const uint32_t *lds_win,
  const uint16_t *lds_start, uint32_t start0, uint32_t sub, uint32_t sdw) {
-  hj_lds_src s;
+  RowSrc s;
   s.base = lds_win + sub*sdw;
   s.bit0 = ((start0 + lds_start[sub]) & ~3u) << 3;
   return s;
 }
 
 
+template <class RowSrc>
 __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int round, int max_iters, int lite_first) {
   __shared__ __attribute__((aligned(16))) hj_ltables lds_tabs;
   __shared__ uint32_t lds_win_mem[1 + HJ_WIN_DWORDS];      // [0]: the dword "before" row 0 (hj_lds_src::reader)
@@ -284,13 +325,13 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
         uint64_t from = hj_pos(start);
         uint64_t skip = (uint64_t)(lite_first - 1)*8;
         if (from + 2*skip > stop_bit) skip = from < stop_bit ? (stop_bit - from)/2 : 0;
-        r = hj_sync_decode<hj_lds_src, true, hj_ltables>(hj_source(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
+        r = hj_sync_decode<RowSrc, true, hj_ltables>(hj_source<RowSrc>(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
          hj_pack(from + skip, hj_slot(start), hj_k(start)), stop_bit, (sb >> 31) == 0u, slot_tables);
         lds_ran[sub] = 2;                                    // ran, but nothing to publish
         lds_dirty[sub] = 1;                                  // (its own flag: no other lane writes it now)
       }
       else {
-        r = hj_sync_decode<hj_lds_src, false, hj_ltables>(hj_source(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
+        r = hj_sync_decode<RowSrc, false, hj_ltables>(hj_source<RowSrc>(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
          (uint64_t)(sb & 0x7fffffffu)*8, (sb >> 31) == 0u, slot_tables);
         lds_R[sub] = (uint16_t)r.nblocks;
         lds_ran[sub] = 1;
@@ -1033,11 +1074,14 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
   // a lone 1080p frame 0.77 -> 0.70 ms: profiles/r2_lite_first_run_ab.txt)
   static const int lite_first = getenv("JGA_HUFF_LITE") ? atoi(getenv("JGA_HUFF_LITE")) : 49;
   dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
-  if (sparse) {
+  if (sparse > 0) {
     const dim3 sgrid((grid.x + HJ_SPARSE_GROUPS - 1)/HJ_SPARSE_GROUPS, grid.y);
     hipLaunchKernelGGL(hj_sync_sparse, sgrid, dim3(64*HJ_SPARSE_GROUPS), 0, (hipStream_t)stream, *A, round, max_iters);
   }
-  else hipLaunchKernelGGL(hj_sync_round, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
+  else if (sparse < 0) {                         // dense, rows read through registers
+    hipLaunchKernelGGL(hj_sync_round<hj_lds_reg_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
+  }
+  else hipLaunchKernelGGL(hj_sync_round<hj_lds_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream) {
