@@ -35,6 +35,12 @@
 
 namespace {
 
+// JGA_PIPE_TRACE: offsets from the start of the current jga_pipeline_run (one run at a time when tracing)
+std::chrono::steady_clock::time_point g_run_t0;
+double since_run_start_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_run_t0).count();
+}
+
 struct slot {
   short *h_coef = nullptr;          // pinned
   short *d_coef = nullptr;
@@ -487,9 +493,9 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
       return std::chrono::duration<double, std::milli>(b - a).count(); };
     const double c_d = thread_cpu_ms();
-    fprintf(stderr, "lane group of %d: prepare + wait for a device slot %.2f ms (%.2f of this thread's CPU), "
-     "entropy decode %.2f ms (%.2f), idct+out+sync %.2f ms (%.2f)\n",
-     m, ms(t_a, t_b), c_b - c_a, ms(t_b, t_c), c_c - c_b, ms(t_c, t_d), c_d - c_c);
+    fprintf(stderr, "lane group of %d: began at %.2f ms; prepare + wait for a device slot %.2f ms (%.2f of this thread's CPU), "
+     "entropy decode %.2f ms (%.2f), idct+out+sync %.2f ms (%.2f); done at %.2f ms\n",
+     m, ms(g_run_t0, t_a), ms(t_a, t_b), c_b - c_a, ms(t_b, t_c), c_c - c_b, ms(t_c, t_d), c_d - c_c, since_run_start_ms());
   }
   const long long up = host_entropy ? g.coef_shorts*2 : jga_huff_upload_bytes(l.hb)/m;
   if (copy_back) {
@@ -658,6 +664,8 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
   int failed = 0;
   for (int i = 0; i < n; i++) jobs[i].status = EXIT_FAILURE;
   if (pl->cfg.transport == 2) {
+    const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+    if (trace) g_run_t0 = std::chrono::steady_clock::now();
     const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 48;
     const int nl = (int)pl->lanes.size();
     int per = pl->cfg.nthreads/nl;
@@ -699,10 +707,13 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
         if ((long long)groups[it->second].size() >= cap) open.erase(it);
       }
     }
+    if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), since_run_start_ms());
     for (int t = 0; t < nl; t++) {
       threads.emplace_back(run_lane, pl, &pl->lanes[t], &groups, &next, per);
     }
+    if (trace) fprintf(stderr, "run: %d lane threads started at %.2f ms\n", nl, since_run_start_ms());
     for (auto &th : threads) th.join();
+    if (trace) fprintf(stderr, "run: lanes joined at %.2f ms\n", since_run_start_ms());
     for (int i = 0; i < n; i++) failed += jobs[i].status != EXIT_SUCCESS;
     return failed ? EXIT_FAILURE : EXIT_SUCCESS;
   }
