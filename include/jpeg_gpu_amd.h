@@ -444,6 +444,10 @@ void jga_huff_set_blocking_waits(jga_huff_batch *b, int on);
 /* prepare() queues its uploads on `copy_stream` (NULL = its own stream) and makes its own stream wait
  * for them: batches sharing a copy stream upload in the order they were prepared. */
 void jga_huff_set_copy_stream(jga_huff_batch *b, void *copy_stream);
+/* 1: other decodes run on the device at the same time (a pipeline's lanes).  A batch that would
+ * leave most of an idle device empty takes the kernels with the shortest chain of steps; told
+ * that the device is shared, it takes the ones that leave the most of it to the others. */
+void jga_huff_set_device_shared(jga_huff_batch *b, int on);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);
 

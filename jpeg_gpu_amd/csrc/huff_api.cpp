@@ -53,6 +53,7 @@ struct jga_huff_batch {
   hipEvent_t ev_begin, ev_zeroed;
   hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
   int blocking_waits;
+  int device_shared;                    // other decodes run beside this one (jga_huff_set_device_shared)
   hipStream_t copy_stream;     // uploads go here (in the order they are queued), the caller's stream waits for them
   hipEvent_t ev_up;
   size_t sub_cap;
@@ -561,6 +562,7 @@ JGA_EXPORT void jga_huff_set_device_unstuff(jga_huff_batch *b, int on) { b->devi
 JGA_EXPORT void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on) { b->inputs_pinned = on != 0; }
 // 1: jga_huff_decode's host waits sleep (blocking event) instead of spinning on a core.
 JGA_EXPORT void jga_huff_set_blocking_waits(jga_huff_batch *b, int on) { b->blocking_waits = on != 0; }
+JGA_EXPORT void jga_huff_set_device_shared(jga_huff_batch *b, int on) { b->device_shared = on != 0; }
 // prepare() queues its uploads on `copy_stream` (a hipStream_t; NULL = on prepare()'s own stream)
 // and makes its own stream wait for them.  Several batches that share one copy stream upload
 // one after the other, in the order they were prepared — the first one's decode starts when ITS
@@ -783,7 +785,9 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   // dense kernel's LDS rows make each step of the chain shorter and nothing else wants the CUs:
   // one 1080p frame 0.55 -> 0.48 ms, one 4K 0.62 -> 0.52, 8 x 4K 0.71 -> 0.68, but 16 x 4K 0.96 -> 1.05
   // (profiles/r3_entropy_stage_steps.md).
-  const bool small_batch = b->total_sub <= 200u*1024u;
+  // (with other decodes beside it — a pipeline's lanes — the groups fill the device together: 1024 x 1080p
+  // in groups of 32 ran 22.5 ms with the sparse kernel and 24.2 with the dense one)
+  const bool small_batch = !b->device_shared && b->total_sub <= 200u*1024u;
   const int sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from : small_batch ? HJ_MAX_ROUNDS : 1;
   A.flush_lanes = flush_lanes;
   A.sub_log2 = b->sub_log2;

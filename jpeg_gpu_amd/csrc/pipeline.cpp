@@ -327,7 +327,7 @@ struct device_turn {
 // (its per-member verdicts then say who is to blame), EXIT_FAILURE for anything else.
 enum { GROUP_REJECTED = 2 };
 uint64_t geometry_key(const unsigned char *p, int size);
-int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads) {
+int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads, bool shared = true) {
   const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
   const bool copy_back = pl->cfg.copy_back != 0;
   std::vector<const unsigned char *> ptrs((size_t)m);
@@ -378,6 +378,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     jga_huff_set_device_unstuff(l.hb, on_device);
     jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
+    jga_huff_set_device_shared(l.hb, shared);
     jga_huff_set_copy_stream(l.hb, pl->copy_streams.empty() ? nullptr
      : pl->copy_streams[pl->copy_next.fetch_add(1)%pl->copy_streams.size()]);
   }
@@ -557,7 +558,7 @@ void run_lane(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *g
     if (gi >= (int)groups->size()) break;
     std::vector<jga_job *> &grp = (*groups)[gi];
     const int m = (int)grp.size();
-    const int rc = lane_group(pl, *l, grp.data(), m, threads);
+    const int rc = lane_group(pl, *l, grp.data(), m, threads, groups->size() > 1);
     if (rc == EXIT_SUCCESS || m == 1) continue;
     // One member with an unparsable header, or with Huffman tables outside the device lookup
     // format, must not cost the other 47 their batch: the members prepare() found usable go
