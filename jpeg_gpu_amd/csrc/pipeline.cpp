@@ -112,6 +112,18 @@ struct jga_pipeline {
   std::vector<hipStream_t> copy_streams;
   std::atomic<unsigned> copy_next{0};
   int groups_per_lane = 4, min_group_eq = 4;      // group sizing for jobs too short to reach a steady state
+  // transport 2: the lane threads live as long as the pipeline (a run used to create its eight
+  // threads: 0.3 ms, the first thing a lone image's latency held); a run hands them its groups and
+  // waits for all of them to report back
+  std::vector<std::thread> lane_threads;
+  std::mutex run_mutex;
+  std::condition_variable run_cv, done_cv;
+  unsigned long long run_gen = 0;
+  int run_done = 0;
+  bool quit = false;
+  std::vector<std::vector<jga_job *>> *run_groups = nullptr;
+  std::atomic<int> *run_next = nullptr;
+  int run_threads = 1;
 };
 
 namespace {
@@ -547,12 +559,8 @@ uint64_t geometry_key(const unsigned char *p, int size) {
   return 0;
 }
 
-void run_lane(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *groups,
+void lane_groups(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *groups,
  std::atomic<int> *next, int threads) {
-  if (!HOK(hipSetDevice(pl->cfg.device))) return;
-  // the naps of host_wait.h are tens of microseconds: the default 50 us of timer slack would
-  // more than double them
-  if (!getenv("JGA_PIPE_KEEP_TIMERSLACK")) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL);
   for (;;) {
     const int gi = next->fetch_add(1);
     if (gi >= (int)groups->size()) break;
@@ -574,6 +582,33 @@ void run_lane(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *g
     }
     for (jga_job *j : good) (void)lane_group(pl, *l, &j, 1, 1);
     for (jga_job *j : rest) (void)lane_group(pl, *l, &j, 1, 1);
+  }
+}
+
+// A lane's thread: sleeps until jga_pipeline_run() posts a run, works through its groups with the
+// other lanes, reports back.
+void run_lane(jga_pipeline *pl, hlane *l) {
+  const bool dev_ok = HOK(hipSetDevice(pl->cfg.device));
+  // the naps of host_wait.h are tens of microseconds: the default 50 us of timer slack would
+  // more than double them
+  if (!getenv("JGA_PIPE_KEEP_TIMERSLACK")) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL);
+  unsigned long long seen = 0;
+  for (;;) {
+    std::vector<std::vector<jga_job *>> *groups;
+    std::atomic<int> *next;
+    int threads;
+    {
+      std::unique_lock<std::mutex> lk(pl->run_mutex);
+      pl->run_cv.wait(lk, [&] { return pl->quit || pl->run_gen != seen; });
+      if (pl->quit) return;
+      seen = pl->run_gen;
+      groups = pl->run_groups; next = pl->run_next; threads = pl->run_threads;
+    }
+    if (dev_ok) lane_groups(pl, l, groups, next, threads);      // (jobs keep their EXIT_FAILURE otherwise)
+    {
+      std::lock_guard<std::mutex> lk(pl->run_mutex);
+      if (++pl->run_done == (int)pl->lanes.size()) pl->done_cv.notify_one();
+    }
   }
 }
 
@@ -647,6 +682,7 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
         return nullptr;
       }
     }
+    for (auto &l : pl->lanes) pl->lane_threads.emplace_back(run_lane, pl, &l);
     return pl;
   }
   pl->workers.resize(pl->cfg.nthreads);
@@ -709,12 +745,19 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
       }
     }
     if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), since_run_start_ms());
-    for (int t = 0; t < nl; t++) {
-      threads.emplace_back(run_lane, pl, &pl->lanes[t], &groups, &next, per);
+    {
+      std::lock_guard<std::mutex> lk(pl->run_mutex);
+      pl->run_groups = &groups; pl->run_next = &next; pl->run_threads = per;
+      pl->run_done = 0;
+      pl->run_gen++;
     }
-    if (trace) fprintf(stderr, "run: %d lane threads started at %.2f ms\n", nl, since_run_start_ms());
-    for (auto &th : threads) th.join();
-    if (trace) fprintf(stderr, "run: lanes joined at %.2f ms\n", since_run_start_ms());
+    pl->run_cv.notify_all();
+    if (trace) fprintf(stderr, "run: posted to %d lanes at %.2f ms\n", nl, since_run_start_ms());
+    {
+      std::unique_lock<std::mutex> lk(pl->run_mutex);
+      pl->done_cv.wait(lk, [&] { return pl->run_done == nl; });
+    }
+    if (trace) fprintf(stderr, "run: lanes reported back at %.2f ms\n", since_run_start_ms());
     for (int i = 0; i < n; i++) failed += jobs[i].status != EXIT_SUCCESS;
     return failed ? EXIT_FAILURE : EXIT_SUCCESS;
   }
@@ -730,6 +773,12 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
 JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {
   if (!pl) return;
   (void)hipSetDevice(pl->cfg.device);
+  {
+    std::lock_guard<std::mutex> lk(pl->run_mutex);
+    pl->quit = true;
+  }
+  pl->run_cv.notify_all();
+  for (auto &th : pl->lane_threads) th.join();
   for (auto &l : pl->lanes) free_lane(l);
   for (auto cs : pl->copy_streams) (void)hipStreamDestroy(cs);
   for (auto &w : pl->workers) {
