@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the templated build of hj_sync_sparse that was measured and not kept: profiles/r3_entropy_stage_steps.md)
 # subsequences per wave of the sparse launches
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 JGA_HUFF_SPARSE_SUBS=512,1024,1024 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "huff or split or corrupt or periodic or irregular" 2>&1 | tail -2
