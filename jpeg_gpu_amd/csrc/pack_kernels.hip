@@ -14,22 +14,21 @@
 // writes the QUANT-stage planes (Appendix-B layout) the IDCT kernels read, so only
 // the compact form crosses PCIe.
 //
-// One WAVEFRONT expands one block at a time, one word per lane — a block is at most
-// 1 + 63 words, exactly a wave64:
-//   * where the wave's 64 blocks start and where they go is worked out up front, lane l
-//     for block l (one gather of the 64 start indices), and handed to the per-block loop
-//     as wave-uniform scalars with v_readlane;
-//   * lane l loads word start+l — a coalesced 128-byte read;
-//   * the first zero word (ballot + count-trailing-zeros) ends the block;
-//   * zig-zag position of word l = inclusive prefix sum of (run+1) over the lanes: six
-//     DPP adds (row_shr 1/2/4/8, row_bcast 15/31), no LDS;
-//   * each valid lane drops its sign-extended level at its natural position in a
-//     128-byte LDS line of the wave; the lines of the blocks in flight then leave 16 bytes
-//     per lane, eight whole blocks per store instruction (and are zeroed for the next ones).
-// Sixteen blocks are in flight per wave so that the vector load -> LDS -> store
-// chain of one overlaps the others (0.68 ms with 4 in flight, 0.54 ms with 16).  Blocks
-// are taken in scan order (the order the producer emits the words), so consecutive reads
-// walk the word stream sequentially.
+// One LANE expands one block (round 3; until then a wavefront expanded one block at a time, one
+// word per lane, with the zig-zag positions from a DPP prefix sum — 25 of 64 lanes busy and ~23
+// wave instructions per block: the kernel was bound by instruction issue at 0.46-0.49 of the HBM
+// peak):
+//   * lane l of a workgroup takes block (256 x group + l) of the scan (the order the producer
+//     emits the words in, so neighbouring lanes read neighbouring stretches of the stream), works
+//     out where it starts and where it goes, and walks its words itself: sixteen words per trip
+//     (four 8-byte loads, 2-byte aligned), `position += run + 1`, level sign-extended into the lane's own
+//     128-byte LDS buffer at the natural position (33-dword stride: lanes hit different banks);
+//   * a wave's loop runs as long as its longest block (<= 64 words);
+//   * then the wave's 64 buffers leave as whole 128-byte lines, eight lanes per block, 16 bytes
+//     each: eight blocks per store instruction.
+// A third fewer instructions per block than the wave-per-block form (the lanes of short blocks
+// still sit out the trips of the longest one): [MI355X] 0.449 -> 0.349 ms per 48 x 4K = 0.61 of the
+// HBM peak (tools/ubench.py).
 // Integer/byte work, HBM-bound: per block it reads 2 B x words + 4 B and writes 128 B.
 //
 // Out-of-range input is made safe, not meaningful: word reads stop at the end of the
@@ -39,9 +38,16 @@
 #include <stdint.h>
 #include "pack_params.h"
 
-#define PK_BLOCK 256                 /* 4 waves */
-#define PK_INFLIGHT 16                /* blocks a wave works on at once */
-#define PK_PER_WAVE 64               /* consecutive blocks (scan order) per wave: one per lane */
+#define PK_BLOCK 256                 /* 4 waves, one block per lane */
+#define PK_BLK_STRIDE 33             /* dwords per lane's block buffer: 32 + its destination */
+#ifndef PK_CHUNK
+#define PK_CHUNK 16                  /* words per trip: 8 or 16 */
+#endif
+#ifndef PK_PREFETCH
+#define PK_PREFETCH 0                /* 1: the next trip's words are loaded before this trip's are placed */
+#endif
+// [MI355X] 48 x 4K, 25.4 words per block: 8 / 16 / 32 / 64 words per trip = 0.365 / 0.349 / 0.400 / 0.521 ms;
+// with the prefetch 0.395 / 0.414 (the registers it holds cost more than the latency it hides)
 
 __device__ const uint8_t PK_DEZZ[64] = {     // T.81 Figure A.6: zig-zag index -> natural index
   0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20,
@@ -50,53 +56,34 @@ __device__ const uint8_t PK_DEZZ[64] = {     // T.81 Figure A.6: zig-zag index -
 
 typedef int16_t __attribute__((may_alias)) pk_i16_alias;
 typedef uint32_t __attribute__((may_alias)) pk_v4u __attribute__((ext_vector_type(4)));
+typedef uint64_t __attribute__((aligned(2), may_alias)) pk_u64_a2;
 
 static __device__ __forceinline__ int pk_sext12(uint32_t w) {
   return (int)(w << 20) >> 20;       // horz_pack_yuv.fs.glsl:112, 123
 }
 
-// x + (x of the lane `ctrl` positions away), DPP; lanes without a source add 0
-#define PK_DPP_ADD(x, ctrl, rows) \
-  ((x) + __builtin_amdgcn_update_dpp(0, (x), (ctrl), (rows), 0xf, false))
-
-// Inclusive prefix sum over the 64 lanes of a wave.
-static __device__ __forceinline__ int pk_wave_scan(int x) {
-  x = PK_DPP_ADD(x, 0x111, 0xf);     // row_shr:1
-  x = PK_DPP_ADD(x, 0x112, 0xf);     // row_shr:2
-  x = PK_DPP_ADD(x, 0x114, 0xf);     // row_shr:4
-  x = PK_DPP_ADD(x, 0x118, 0xf);     // row_shr:8   -> scan inside each row of 16
-  x = PK_DPP_ADD(x, 0x142, 0xa);     // row_bcast:15 into rows 1 and 3
-  x = PK_DPP_ADD(x, 0x143, 0xc);     // row_bcast:31 into rows 2 and 3
-  return x;
-}
-
 __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_params P) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds_line[PK_BLOCK/64][PK_INFLIGHT][64];   // one 128-byte line per block in flight
-  __shared__ uint8_t s_dezz[64];
+  __shared__ __attribute__((aligned(16))) uint32_t lds_blk[PK_BLOCK*PK_BLK_STRIDE];
+  __shared__ uint8_t s_dezz2[64];                          // BYTE offset of zig-zag position p in a block buffer
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int img = blockIdx.y;
-  if (threadIdx.x < 64) s_dezz[threadIdx.x] = PK_DEZZ[threadIdx.x];
+  if (threadIdx.x < 64) s_dezz2[threadIdx.x] = (uint8_t)(2u*PK_DEZZ[threadIdx.x]);
+  uint32_t *blk = lds_blk + threadIdx.x*PK_BLK_STRIDE;
 #pragma unroll
-  for (int u = 0; u < PK_INFLIGHT; u++) lds_line[wv][u][lane] = 0;
-  __syncthreads();
+  for (int q = 0; q < 32; q++) blk[q] = 0;                  // own buffer only
+  __syncthreads();                                           // s_dezz2
 
   const uint32_t nslots = (uint32_t)P.nslots, nhmb = (uint32_t)P.nhmb;
   const uint32_t total = nhmb*(uint32_t)P.nvmb*nslots;            // blocks of the scan
-  const uint32_t first = (blockIdx.x*(PK_BLOCK/64) + wv)*PK_PER_WAVE;
   const int32_t *index = P.index + (long long)img*P.index_stride;
   const uint16_t *pack = P.pack + (long long)img*P.pack_stride;
-  int16_t *coef = P.coef + (long long)img*P.coef_stride;
   const uint32_t limit = (uint32_t)P.pack_words;
   const long long rs = (long long)P.w0_blocks*64;
 
-  // Lane l works out, once, where block first+l starts in the stream and where it goes in
-  // the planes (all 64 descriptions in parallel, the 64 start indices in one gather); the
-  // loop below picks them up with v_readlane.
-  uint32_t my_start = limit;
-  unsigned long long my_dst = 0;
+  // where this lane's block starts in the stream and where it goes in the planes
+  uint32_t k = limit, dst = ~0u;                             // dst: 128-byte slot of the image's planes; ~0: no block
   {
-    const uint32_t b = first + lane;
+    const uint32_t b = blockIdx.x*PK_BLOCK + threadIdx.x;
     if (b < total) {
       const uint32_t mcu = (uint32_t)(((uint64_t)b*P.div_nslots.mul) >> P.div_nslots.shift);
       const uint32_t slot = b - mcu*nslots;
@@ -112,73 +99,91 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
       const int xdec = PK_SEL(P.plane_xdec);
       const uint32_t hblocks = (uint32_t)PK_SEL(P.plane_hblocks);
       const uint32_t index0 = (uint32_t)PK_SEL(P.plane_index0);
-      my_dst = (unsigned long long)(uintptr_t)(coef + PK_SEL(P.plane_coef_off) + rs*(by >> xdec)
-       + (rs >> xdec)*(by & ((1u << xdec) - 1u)) + (long long)bx*64);
+      dst = (uint32_t)((PK_SEL(P.plane_coef_off) + rs*(by >> xdec)
+       + (rs >> xdec)*(by & ((1u << xdec) - 1u)) + (long long)bx*64) >> 6);     // (block offsets are multiples of 64 shorts)
 #undef PK_SEL
-      my_start = (uint32_t)index[index0 + by*hblocks + bx];
+      k = (uint32_t)index[index0 + by*hblocks + bx];
     }
   }
-  const uint32_t dst_lo = (uint32_t)my_dst, dst_hi = (uint32_t)(my_dst >> 32);
+  blk[32] = dst;
 
-#pragma unroll 1
-  for (uint32_t b0 = 0; b0 < PK_PER_WAVE && first + b0 < total; b0 += PK_INFLIGHT) {
-    uint32_t start[PK_INFLIGHT];
-    int16_t *dst[PK_INFLIGHT];
-    uint32_t w[PK_INFLIGHT];
+  // Walk the block's words: word 0 is the DC level (position 0), every later one moves the
+  // position by run + 1 — a zero word (end of block) by 64, which ends the walk like a run past
+  // coefficient 63 does.
+  uint8_t *blk8 = reinterpret_cast<uint8_t *>(blk);
+  bool active = k < limit;                                   // (a start outside the stream: the block stays zero)
+  bool dcword = true;
+  int pos = 0;
+  // PK_CHUNK words per trip (with PK_PREFETCH the next trip's are loaded before these are placed)
+  struct chunk { uint32_t q[PK_CHUNK/2]; };
+  auto fetch = [&](uint32_t at, bool want) {
+    chunk c;
 #pragma unroll
-    for (int u = 0; u < PK_INFLIGHT; u++) {
-      const int src = (int)b0 + u;                       // wave-uniform lane number
-      start[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_start, src);
-      const unsigned long long a = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dst_hi, src) << 32)
-       | (uint32_t)__builtin_amdgcn_readlane((int)dst_lo, src);
-      dst[u] = reinterpret_cast<int16_t *>((uintptr_t)a);
-    }
-    // one word per lane
+    for (int j = 0; j < PK_CHUNK/2; j++) c.q[j] = 0u;
+    if (want) {
+      if (at + (uint32_t)PK_CHUNK <= limit) {
 #pragma unroll
-    for (int u = 0; u < PK_INFLIGHT; u++) {
-      const uint32_t k = start[u] + lane;
-      w[u] = (start[u] < limit && k < limit) ? pack[k] : 0u;
-    }
+        for (int j = 0; j < PK_CHUNK/4; j++) {
+          const uint64_t v = *reinterpret_cast<const pk_u64_a2 *>(pack + at + 4*j);
+          c.q[2*j] = (uint32_t)v; c.q[2*j + 1] = (uint32_t)(v >> 32);
+        }
+      }
+      else if (at < limit) {                                 // the stream's last words
 #pragma unroll
-    for (int u = 0; u < PK_INFLIGHT; u++) {
-      // words up to the first zero after the DC word belong to the block.  The terminator needs
-      // no vote: a zero word adds 64 to the prefix sum, so its own position and every later one
-      // fail the "position < 64" test that ends a block anyway
-      const int pos = pk_wave_scan(lane == 0u ? 0 : w[u] == 0u ? 64 : (int)(w[u] >> 12) + 1);
-      if (start[u] < limit && pos < 64) {
-        lds_line[wv][u][s_dezz[pos]] = (uint16_t)pk_sext12(w[u]);
+        for (int j = 0; j < PK_CHUNK; j++) {
+          const uint32_t w = at + (uint32_t)j < limit ? pack[at + (uint32_t)j] : 0u;
+          c.q[j >> 1] |= w << (16*(j & 1));
+        }
       }
     }
-    // (a wave's LDS accesses execute in order: the writes above are visible to the reads below)
-    // Write-out: the PK_INFLIGHT lines leave 16 bytes per lane — lanes 8j..8j+7 carry block j of
-    // a pass — so one store instruction moves eight whole blocks instead of one.
-    static_assert(PK_INFLIGHT % 8 == 0, "eight blocks per store pass");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return c;
+  };
+  chunk cur = fetch(k, active);
+  while (__ballot(active) != 0ull) {
+#if PK_PREFETCH
+    const chunk nxt = fetch(k + (uint32_t)PK_CHUNK, active);
+#endif
 #pragma unroll
-    for (int pass = 0; pass < PK_INFLIGHT/8; pass++) {
-      const int u = pass*8 + (int)(lane >> 3), part = (int)(lane & 7u);
-      pk_v4u *line = reinterpret_cast<pk_v4u *>(&lds_line[wv][u][0]) + part;
-      const pk_v4u v = *line;
-      const pk_v4u zero = {0u, 0u, 0u, 0u};
-      *line = zero;
-      const int owner = (int)b0 + u;                        // lane that described this block
-      const uint32_t lo = (uint32_t)__shfl((int)dst_lo, owner), hi = (uint32_t)__shfl((int)dst_hi, owner);
-      const unsigned long long a = ((unsigned long long)hi << 32) | lo;
-      if (a && owner < PK_PER_WAVE) {
-        typedef __attribute__((address_space(1))) pk_v4u global_v4u;     // global_store, not flat
-        __builtin_nontemporal_store(v, (global_v4u *)(uintptr_t)a + part);
-      }
+    for (int j = 0; j < PK_CHUNK; j++) {
+      const uint32_t w = (j & 1) ? cur.q[j >> 1] >> 16 : cur.q[j >> 1] & 0xffffu;
+      const int inc = (j == 0 && dcword) ? 0 : w == 0u ? 64 : (int)(w >> 12) + 1;
+      pos += inc;
+      active = active && pos < 64;
+      if (active) *reinterpret_cast<pk_i16_alias *>(blk8 + s_dezz2[pos]) = (int16_t)pk_sext12(w);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    dcword = false;
+    k += (uint32_t)PK_CHUNK;
+#if PK_PREFETCH
+    cur = nxt;
+#else
+    cur = fetch(k, active);
+#endif
+  }
+  // (a wave's LDS accesses execute in order: the writes above are visible to the reads below)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // Write-out: lanes 8j..8j+7 of a pass carry block j of it, 16 bytes each — one store instruction
+  // moves eight whole blocks.
+  const uint32_t *wave_blk = lds_blk + (threadIdx.x & ~63u)*PK_BLK_STRIDE;
+  uint8_t *planes = reinterpret_cast<uint8_t *>(P.coef + (long long)img*P.coef_stride);
+  const uint32_t part = lane & 7u;
+#pragma unroll
+  for (int pass = 0; pass < 8; pass++) {
+    const uint32_t *src = wave_blk + ((uint32_t)pass*8u + (lane >> 3))*PK_BLK_STRIDE;
+    const uint32_t off = src[32];
+    pk_v4u v;
+    v.x = src[4*part]; v.y = src[4*part + 1]; v.z = src[4*part + 2]; v.w = src[4*part + 3];
+    if (off != ~0u) {
+      typedef __attribute__((address_space(1))) pk_v4u global_v4u;     // global_store, not flat
+      __builtin_nontemporal_store(v, (global_v4u *)(uintptr_t)(planes + (size_t)off*128u) + part);
+    }
   }
 }
 
 extern "C" int jga_launch_unpack(const jga_pack_params *P, void *stream) {
-  const int blocks = P->nhmb*P->nvmb*P->nslots, per_group = (PK_BLOCK/64)*PK_PER_WAVE;
-  dim3 grid((blocks + per_group - 1)/per_group, P->nimages), block(PK_BLOCK);
+  const int blocks = P->nhmb*P->nvmb*P->nslots;
+  dim3 grid((blocks + PK_BLOCK - 1)/PK_BLOCK, P->nimages), block(PK_BLOCK);
   hipLaunchKernelGGL(jga_unpack_kernel, grid, block, 0, (hipStream_t)stream, *P);
   return (int)hipGetLastError();
 }
