@@ -876,8 +876,8 @@ def main():
         d_pack, d_idx = lib.DeviceBuffer(hp.nbytes), lib.DeviceBuffer(hi.nbytes)
         d_pack.upload(hp)
         d_idx.upload(hi)
-        reps = 10
-        for rep in range(2):
+        reps = 20
+        for rep in range(3):
             t0 = time.perf_counter()
             for _ in range(reps):
                 lib.check(lib.L.jga_unpack_batch(C.byref(g), B, d_pack.ptr, pstride, pstride,
