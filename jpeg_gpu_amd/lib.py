@@ -122,6 +122,9 @@ L.jga_huff_set_inputs_pinned.argtypes = [_vp, _i]
 L.jga_huff_set_inputs_pinned.restype = None
 L.jga_huff_set_blocking_waits.argtypes = [_vp, _i]
 L.jga_huff_set_blocking_waits.restype = None
+if hasattr(L, "jga_huff_set_device_shared"):
+    L.jga_huff_set_device_shared.argtypes = [_vp, _i]
+    L.jga_huff_set_device_shared.restype = None
 if hasattr(L, "jga_huff_set_copy_stream"):
     L.jga_huff_set_copy_stream.argtypes = [_vp, _vp]
     L.jga_huff_set_copy_stream.restype = None

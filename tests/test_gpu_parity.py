@@ -488,6 +488,34 @@ def test_gpu_huffman_equals_oracle_quant_stage(gpu, orc, synth, sampling, ri):
         assert np.array_equal(c, gpu.entropy_decode(d, g)), (sampling, ri)
 
 
+@pytest.mark.parametrize("sampling", ["420", "422", "444", "grey", "411"])
+def test_gpu_huffman_into_a_dirty_buffer(gpu, synth, sampling):
+    """The decode clears no plane (round 3): into a buffer full of garbage it must still leave the
+    host stage's buffer, byte for byte — real blocks written whole or zeroed before their pieces
+    land, the slots at the end of decimated planes that hold no block cleared — whether or not it
+    was told that other decodes share the device (which changes the kernels of the later rounds)."""
+    datas = [synth.synthetic_jpeg(349, 227, sampling, quality=q, restart_interval=ri, seed=q)
+             for q, ri in ((90, 0), (40, 0))]
+    for shared in (0, 1):
+        hb = gpu.HuffBatch(len(datas), sum(map(len, datas)) + 8192)
+        try:
+            g = hb.prepare(datas)
+            gpu.L.jga_huff_set_device_shared(hb.ptr, shared)
+            stride = (g.coef_shorts + 127) // 128 * 128
+            d = gpu.DeviceBuffer(stride * 2 * len(datas))
+            try:
+                for fill in (0x5A5A, -1):
+                    d.upload(np.full(stride * len(datas), fill, np.int16))
+                    hb.decode(d.ptr, stride)
+                    got = d.download(dtype=np.int16).reshape(len(datas), stride)[:, :g.coef_shorts]
+                    for i, data in enumerate(datas):
+                        assert np.array_equal(got[i], gpu.entropy_decode(data, g)), (sampling, shared, fill, i)
+            finally:
+                d.free()
+        finally:
+            hb.close()
+
+
 @pytest.mark.parametrize("sampling", SAMPLINGS)
 @pytest.mark.parametrize("ri", [0, -1, 1, 3])
 def test_gpu_unstuffing_then_huffman_equals_oracle_quant_stage(gpu, orc, synth, sampling, ri):
