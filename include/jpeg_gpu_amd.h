@@ -382,7 +382,9 @@ typedef struct jga_job {
 #define jga_pipeline_config_init(cfg) do { memset((cfg), 0, sizeof(jga_pipeline_config)); \
   (cfg)->struct_size = (int)sizeof(jga_pipeline_config); (cfg)->job_size = (int)sizeof(jga_job); } while (0)
 jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);
-/* Decode jobs[0..n) ; returns when all are complete (outputs valid). */
+/* Decode jobs[0..n) ; returns when all are complete (outputs valid).  One run at a time per
+ * pipeline (its lanes and their threads — which live from create to destroy, in the process that
+ * created them — belong to the run); several pipelines may run side by side. */
 int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);
 void jga_pipeline_destroy(jga_pipeline *pl);
 
