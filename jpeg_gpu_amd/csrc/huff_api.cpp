@@ -3,9 +3,10 @@
 // prepare(): host parses the marker segments of a batch of same-geometry JPEGs,
 //   builds device tables / restart segments / initial lane states and uploads them
 //   together with the entropy-coded bytes (compressed: ~0.4 B/px instead of 3 B/px).
-// decode(): everything on the GPU: zero the coefficient planes, synchronisation
-//   rounds until no lane moves, per-segment prefix sums, scatter pass.  The output is
-//   the same packed QUANT-stage buffer jga_entropy_decode() produces on the host.
+// decode(): everything on the GPU: synchronisation rounds until no lane moves, per-segment
+//   prefix sums (which also zero the lines of blocks two lanes share), write pass, DC pass.
+//   The output is the same packed QUANT-stage buffer jga_entropy_decode() produces on the
+//   host; no plane is cleared beforehand (every slot that holds a block is written).
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -49,7 +50,7 @@ struct jga_huff_batch {
   int image_errors;            // images of the last decode whose data was damaged
   int assist_hint;             // the previous decode needed the host walk
   int spec_rounds;             // rounds queued before the speculative tail (0: not yet decided)
-  hipStream_t side;            // zeroes the planes while the rounds run on the caller's stream
+  hipStream_t side;            // clears the DC arrays and the planes' padding slots while the rounds run on the caller's stream
   hipEvent_t ev_begin, ev_zeroed;
   hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
   int blocking_waits;
@@ -666,7 +667,7 @@ static int decode_checked(jga_huff_batch *b, short *d_coef, long long coef_strid
   if (d_dc && dc_stride < b->geom.coef_shorts/64) return jga_fail("huff: dc_stride too small");
   const int rc = decode_batch(b, d_coef, coef_stride, d_dc, dc_stride, st);
   if (rc != EXIT_SUCCESS && !b->image_errors) {
-    // a launch or copy failed part-way: the plane clear on the side stream (and whatever
+    // a launch or copy failed part-way: the clears on the side stream (and whatever
     // rounds were queued) may still be running — the caller is free to reuse or release
     // d_coef the moment this returns, so wait them out first
     (void)hipStreamSynchronize(b->side);
@@ -745,7 +746,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   A.coef = (int16_t *)d_coef;
   A.coef_stride = coef_stride;
   A.nimages = b->nimages;
-  // reset: states back to the guesses, "never ran", planes zero (only non-zeros are written)
+  // reset: states back to the guesses, "never ran"
   A.sub_log2 = b->sub_log2;
   // (on-device unstuffing has already had its say about every image: early end, RSTn counters)
   if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub,

@@ -663,7 +663,7 @@ struct hj_block_out {
   }
   // Every lane of the wave calls this together: the blocks of the lanes with `have` leave their
   // buffers.  A block that is `partial` (shared with a neighbouring lane: begun before this run,
-  // or unfinished at its end) leaves as 2-byte stores of its non-zeros onto the pre-zeroed planes
+  // or unfinished at its end) leaves as 2-byte stores of its non-zeros onto its line, which hj_scan<true> zeroed
   // (disjoint positions: the lanes need no ordering between them), a whole one as a 128-byte
   // line; either way 8 lanes handle one block, 16 bytes each, and the buffers are zero afterwards.
   __device__ __forceinline__ void flush_blocks(bool have, bool partial, bool complete, int slot) {
