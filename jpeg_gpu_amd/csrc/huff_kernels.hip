@@ -5,9 +5,11 @@
 //                  A workgroup iterates internally (states handed lane-to-lane
 //                  through LDS) until none of its lanes moves, so most of the
 //                  propagation needs no extra launch.
-//   hj_sync_sparse the same round for the later launches: one wave per 256 subsequences
+//   hj_sync_sparse the same round for the later launches of batches that fill the device: one
+//                  wave per 256 subsequences (smaller batches keep hj_sync_round: huff_api.cpp)
 //   hj_scan        per restart segment: exclusive prefix sums of the block counts over the
-//                  segment's lanes
+//                  segment's lanes; the final launch also zeroes the line of the block every
+//                  lane starts inside (the only lines the write pass stores piecewise)
 //   hj_write       one lane per subsequence: final decode.  Blocks are assembled in LDS;
 //                  a lane that finishes one waits until enough lanes of its wave have,
 //                  then the wave writes them out together as full 128-byte lines.  Only
