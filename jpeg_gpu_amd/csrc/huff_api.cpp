@@ -107,7 +107,7 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   b->max_scan = max_scan_bytes;
   // (grow_batch covers streams cut into very many restart intervals)
   // (sized for the shortest subsequences a batch of this capacity can be given)
-  b->sub_cap = (size_t)(max_scan_bytes >> hj_choose_sub_log2((uint64_t)max_scan_bytes, 1)) + (size_t)max_images*4096 + 1024;
+  b->sub_cap = (size_t)(max_scan_bytes >> hj_choose_sub_log2((uint64_t)max_scan_bytes, 1, 1)) + (size_t)max_images*4096 + 1024;
   if (const char *e = getenv("JGA_HUFF_SUB")) {               // tuning knob / tests: 32, 64 or 128
     const int v = atoi(e);
     b->force_sub_log2 = v == 32 ? 5 : v == 64 ? 6 : v == 128 ? 7 : v == 256 ? 8 : v == 512 ? 9 : 0;
@@ -259,7 +259,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   {
     uint64_t raw_total = 0;
     for (int i = 0; i < n; i++) raw_total += prep[i].avail;
-    b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(raw_total, prep[0].im.nslots);
+    b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(raw_total, prep[0].im.nslots, prep[0].geom.restart_interval);
   }
   std::vector<hj_unstuff_image> uimg((size_t)n);
   std::vector<uint32_t> sub0v((size_t)n), seg0v((size_t)n);
@@ -443,7 +443,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       }
       if ((long long)o > b->max_scan + 64ll*n || o >= ((size_t)1 << 32)) fatal.store(2);   // (hj_image::scan_off is 32 bits)
       // subsequence length of this batch (the stuffed length is close enough to the clean one)
-      b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o, prep[0].im.nslots);
+      b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o, prep[0].im.nslots, prep[0].geom.restart_interval);
       for (int i = 0; i < n; i++) prep[i].sub_log2 = b->sub_log2;
       b->off_scan = 0;
       b->scan_bytes = align_up(o, 256);
@@ -758,12 +758,12 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   b->image_errors = 0;
   // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
   struct knobs {
-    int it0 = 3, it1 = 3, group = 6, flush_lanes = 16, sparse_from = -1, assist_after = 12, lean = 1;
+    int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, assist_after = 12, lean = 1;
     knobs() {
       const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group": in-group iterations, rounds per host check
       if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
-      if (it0 < 1) it0 = 1;
-      if (it1 < 1) it1 = 1;
+      if (e && it0 < 1) it0 = 1;
+      if (e && it1 < 1) it1 = 1;
       if (group < 1) group = 1;
       e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (default: by batch size)
       if (e) sparse_from = atoi(e);
@@ -778,8 +778,16 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   };
   static const knobs K;
   const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;     // no LDS rows that long: global-memory readers only
-  const int it0 = K.it0, it1 = K.it1, group = K.group, flush_lanes = K.flush_lanes,
-            assist_after = K.assist_after;
+  // In-group iterations per launch: three — the long, thin tail of the propagation is cheaper as
+  // further launches than as resident groups — except for a small batch of frames cut into long
+  // restart intervals with 64-byte subsequences (hj_choose_sub_log2), whose chains are twice as
+  // many steps of half the length: six (one 1080p frame with an interval per MCU row 0.41 -> 0.39
+  // ms, the 8K frame of BASELINE config 5 0.64 -> 0.60; intervals of a few subsequences: worse).
+  const bool long_intervals = b->geom.restart_interval > 0 && b->sub_log2 == HJ_SUB_LOG2_MAX - 1
+   && b->total_seg > 0 && b->total_sub/b->total_seg >= 64u;
+  const int it_auto = long_intervals ? 6 : 3;
+  const int it0 = K.it0 > 0 ? K.it0 : it_auto, it1 = K.it1 > 0 ? K.it1 : it_auto, group = K.group,
+            flush_lanes = K.flush_lanes, assist_after = K.assist_after;
   // Which kernel runs the later rounds.  The sparse one (a wave per 256 subsequences, rows read from
   // global memory) is for batches that fill the device: there a dense launch pays staging for
   // every group that still has one moving lane.  Up to ~200k subsequences (8 x 4K, 32 x 1080p) the

@@ -120,9 +120,17 @@ struct hj_segment {                  // one restart interval (or the whole scan)
 // the GPU has lanes to spare: one 4K 4:4:4 frame 0.40 -> 0.33 ms, one grey 4K 0.44 -> 0.37, one
 // 1080p 4:4:4 0.40 -> 0.30; four 4K 4:4:4 frames are back at 0.50 vs 0.54
 // (profiles/r2_sub_size_lone_frames.txt).
+// Frames WITH restart intervals: a run falls into step at the next interval at the latest, so the
+// serial distance is bounded whatever the subsequence length and the shorter runs just put more
+// lanes on a small batch — one 1080p frame with an interval per MCU row 0.50 -> 0.41 ms, one 4K
+// 0.55 -> 0.48, the 8K frame of BASELINE config 5 0.70 -> 0.64, four 4K frames 0.60 -> 0.57
+// (profiles/r3_entropy_stage_steps.md).
 #define HJ_SMALL_BATCH_BYTES (8u << 20)
-HJ_HD int hj_choose_sub_log2(uint64_t scan_bytes, int nslots) {
-  return (nslots <= 3 && scan_bytes <= HJ_SMALL_BATCH_BYTES) ? HJ_SUB_LOG2_MAX - 1 : HJ_SUB_LOG2_MAX;
+#define HJ_SMALL_BATCH_BYTES_RESTARTS (16u << 20)
+HJ_HD int hj_choose_sub_log2(uint64_t scan_bytes, int nslots, int restart_interval = 0) {
+  if (nslots <= 3 && scan_bytes <= HJ_SMALL_BATCH_BYTES) return HJ_SUB_LOG2_MAX - 1;
+  if (restart_interval > 0 && scan_bytes <= HJ_SMALL_BATCH_BYTES_RESTARTS) return HJ_SUB_LOG2_MAX - 1;
+  return HJ_SUB_LOG2_MAX;
 }
 
 // state word: p (bit position inside the image's clean scan) << 16 | c << 8 | k
