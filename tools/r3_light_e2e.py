@@ -21,7 +21,7 @@ with ThreadPoolExecutor(8) as ex:
     light = list(ex.map(photo_like, range(8)))
     heavy = list(ex.map(lambda s: synth.synthetic_jpeg(W, H, "420", 90, seed=1234 + s), range(16)))
 for name, files, n in (("light", light, 1920), ("bench", heavy, 1536)):
-    pl = lib.Pipeline(device=0, nthreads=24, out=abi.JPEG_DECODE_RGB, transport=2, batch=32, depth=8)
+    pl = lib.Pipeline(device=0, nthreads=24, out=abi.JPEG_DECODE_RGB, transport=2, batch=int(os.environ.get("BATCH", "32")), depth=int(os.environ.get("LANES", "8")))
     jobs = lib.Pipeline.make_jobs([files[i % len(files)] for i in range(n)])
     pl.run_jobs(jobs)
     best = 1e9
