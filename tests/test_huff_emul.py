@@ -177,3 +177,19 @@ def test_three_tables_of_a_class_go_to_the_host_stage(emul, lib, orc, synth):
     want = lib.entropy_decode(base, g)
     assert np.array_equal(lib.entropy_decode(odd, g), want)
     assert np.array_equal(orc.decode(odd, oracle.QUANT)[1], want)
+
+
+def test_subsequence_length_by_batch(emul):
+    """hj_choose_sub_log2: 128 bytes, except for small batches of frames without subsampling
+    (they fall into step within a few dozen bytes) and of frames cut into restart intervals (the
+    next interval bounds the distance a run must walk): 64."""
+    E = emul
+    E.huff_emul_choose_sub.argtypes = [C.c_ulonglong, C.c_int, C.c_int]
+    MB = 1 << 20
+    assert E.huff_emul_choose_sub(3 * MB, 6, 0) == 128          # one 4K 4:2:0 frame
+    assert E.huff_emul_choose_sub(6 * MB, 3, 0) == 64           # one 4K 4:4:4 frame
+    assert E.huff_emul_choose_sub(9 * MB, 3, 0) == 128          # ... two of them
+    assert E.huff_emul_choose_sub(12 * MB, 6, 480) == 64        # BASELINE config 5: 8K, an interval per MCU row
+    assert E.huff_emul_choose_sub(3 * MB, 6, 8) == 64
+    assert E.huff_emul_choose_sub(148 * MB, 6, 480) == 128      # a batch that fills the device
+    assert E.huff_emul_choose_sub(1, 1, 0) == 64

@@ -49,6 +49,12 @@ int huff_emul_set_sub(int bytes) {
   return 0;
 }
 
+// The subsequence length a batch of the given size gets (huff_common.h: hj_choose_sub_log2), in bytes.
+extern "C" __attribute__((visibility("default")))
+int huff_emul_choose_sub(unsigned long long scan_bytes, int nslots, int restart_interval) {
+  return 1 << hj_choose_sub_log2(scan_bytes, nslots, restart_interval);
+}
+
 // hj_prepare_head's verdict on a file (0 usable, 1 not, 2 = HJ_PREPARE_IRREGULAR: valid, but
 // the device format cannot hold it — the host entropy stage takes it).
 extern "C" __attribute__((visibility("default")))
