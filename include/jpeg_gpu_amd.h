@@ -450,6 +450,12 @@ void jga_huff_set_copy_stream(jga_huff_batch *b, void *copy_stream);
  * leave most of an idle device empty takes the kernels with the shortest chain of steps; told
  * that the device is shared, it takes the ones that leave the most of it to the others. */
 void jga_huff_set_device_shared(jga_huff_batch *b, int on);
+/* `fn(arg, bytes, copies)` is called by prepare() right before it queues its upload of `bytes`
+ * bytes in `copies` copy calls (a caller that runs several batches may want their uploads to cross
+ * the link one after the other: the pipeline does).  NULL clears it. */
+void jga_huff_set_upload_gate(jga_huff_batch *b, void (*fn)(void *arg, long long bytes, int copies), void *arg);
+/* Returns when the last prepare()'s upload has arrived on the device. */
+int  jga_huff_wait_upload(jga_huff_batch *b);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);
 

@@ -55,6 +55,8 @@ struct jga_huff_batch {
   hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
   int blocking_waits;
   int device_shared;                    // other decodes run beside this one (jga_huff_set_device_shared)
+  void (*before_upload)(void *, long long, int);   // called right before prepare() queues its upload (jga_huff_set_upload_gate)
+  void *before_upload_arg;
   hipStream_t copy_stream;     // uploads go here (in the order they are queued), the caller's stream waits for them
   hipEvent_t ev_up;
   size_t sub_cap;
@@ -354,6 +356,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->shadow.clear();
   hipStream_t st = (hipStream_t)stream;
   hipStream_t up = b->copy_stream ? b->copy_stream : st;       // (see jga_huff_set_copy_stream)
+  if (b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, zero_copy ? n + 1 : 1);
   const auto t_1 = std::chrono::steady_clock::now();
   if (zero_copy) {
     // the files lie in pinned memory: the DMA engine reads the scans where they are (the host
@@ -366,10 +369,8 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
      hipMemcpyHostToDevice, up));
   }
   else HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, up));
-  if (up != st) {
-    HOK(hipEventRecord(b->ev_up, up));
-    HOK(hipStreamWaitEvent(st, b->ev_up, 0));
-  }
+  HOK(hipEventRecord(b->ev_up, up));                          // (jga_huff_wait_upload)
+  if (up != st) HOK(hipStreamWaitEvent(st, b->ev_up, 0));
   HOK(hipMemsetAsync(b->d_blob + b->off_info, 0xFF, sizeof(hj_unstuff_info)*(size_t)n, st));
   HOK(hipMemsetAsync(b->d_blob + b->off_perr, 0, 4*(size_t)n, st));
   hj_unstuff_args U;
@@ -532,13 +533,17 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   // the scan region is sized from the raw lengths; the bytes between an image's clean
   // stream (+16 pad) and the next image's start are never read
   const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  if (b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, 1);
   const auto t_h = std::chrono::steady_clock::now();
   if (b->copy_stream && b->copy_stream != (hipStream_t)stream) {
     HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, b->copy_stream));
     HOK(hipEventRecord(b->ev_up, b->copy_stream));
     HOK(hipStreamWaitEvent((hipStream_t)stream, b->ev_up, 0));
   }
-  else HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, (hipStream_t)stream));
+  else {
+    HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HOK(hipEventRecord(b->ev_up, (hipStream_t)stream));       // (jga_huff_wait_upload)
+  }
   if (trace) {
     fprintf(stderr, "  prepare: host %.2f ms, hipMemcpyAsync call %.2f ms (%zu MB)\n",
      std::chrono::duration<double, std::milli>(t_h - t_p0).count(),
@@ -564,6 +569,15 @@ JGA_EXPORT void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on) { b->input
 // 1: jga_huff_decode's host waits sleep (blocking event) instead of spinning on a core.
 JGA_EXPORT void jga_huff_set_blocking_waits(jga_huff_batch *b, int on) { b->blocking_waits = on != 0; }
 JGA_EXPORT void jga_huff_set_device_shared(jga_huff_batch *b, int on) { b->device_shared = on != 0; }
+// Wait until the last prepare()'s upload has arrived (its kernels, if it queued any, may still run).
+JGA_EXPORT int jga_huff_wait_upload(jga_huff_batch *b) {
+  HOK(b->blocking_waits ? jga_event_wait_sleeping(b->ev_up) : hipEventSynchronize(b->ev_up));
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT void jga_huff_set_upload_gate(jga_huff_batch *b, void (*fn)(void *, long long, int), void *arg) {
+  b->before_upload = fn;
+  b->before_upload_arg = arg;
+}
 // prepare() queues its uploads on `copy_stream` (a hipStream_t; NULL = on prepare()'s own stream)
 // and makes its own stream wait for them.  Several batches that share one copy stream upload
 // one after the other, in the order they were prepared — the first one's decode starts when ITS

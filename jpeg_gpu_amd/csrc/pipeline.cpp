@@ -112,6 +112,16 @@ struct jga_pipeline {
   std::vector<hipStream_t> copy_streams;
   std::atomic<unsigned> copy_next{0};
   int groups_per_lane = 4, min_group_eq = 4;      // group sizing for jobs too short to reach a steady state
+  // The groups' uploads take turns on the link, in the order their lanes got through prepare: with
+  // every lane free to upload, three or four blobs share the link, all of them arrive late (8 ms
+  // per 148 MB instead of 2.7) and the device waits for the first.  A turn is two units: one big
+  // blob takes both (a single copy fills the link), smaller uploads and those made of many copy
+  // calls (files DMA'd where they lie) one each, so that two of them hide each other's gaps.
+  // [MI355X] 1536 x 4K pageable 116 -> 131-134 Gpixel/s, lighter content 315-327 -> 373-387,
+  // 1024 x 1080p 83-89 -> 106-108 (profiles/r3_link_turns.txt; JGA_PIPE_LINK_SLOTS=0: off).
+  int link_slots = 2, link_free = 2;
+  std::mutex link_mutex;
+  std::condition_variable link_cv;
   // transport 2: the lane threads live as long as the pipeline (a run used to create its eight
   // threads: 0.3 ms, the first thing a lone image's latency held); a run hands them its groups and
   // waits for all of them to report back
@@ -334,6 +344,32 @@ struct device_turn {
   ~device_turn() { give(); }
 };
 
+// A turn on the link, held from the moment a group's upload is queued until it has arrived.
+struct link_turn {
+  jga_pipeline *pl;
+  int held = 0;
+  explicit link_turn(jga_pipeline *p) : pl(p) {}
+  static void take_hook(void *arg, long long bytes, int copies) {
+    link_turn *t = static_cast<link_turn *>(arg);
+    t->take(copies == 1 && bytes >= (64ll << 20) ? t->pl->link_slots : 1);
+  }
+  void take(int units) {
+    if (pl->link_slots <= 0) return;
+    if (units > pl->link_slots) units = pl->link_slots;
+    std::unique_lock<std::mutex> lk(pl->link_mutex);
+    pl->link_cv.wait(lk, [this, units] { return pl->link_free >= units; });
+    pl->link_free -= units;
+    held = units;
+  }
+  void give() {
+    if (!held) return;
+    { std::lock_guard<std::mutex> lk(pl->link_mutex); pl->link_free += held; }
+    pl->link_cv.notify_all();
+    held = 0;
+  }
+  ~link_turn() { give(); }
+};
+
 // Decode jobs[0..m) as ONE batch of the GPU entropy stage.  Fails as a whole (mixed
 // geometry, an unparsable member, ...): GROUP_REJECTED when prepare() turned the group down
 // (its per-member verdicts then say who is to blame), EXIT_FAILURE for anything else.
@@ -398,7 +434,15 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   // entropy stage (csrc/entropy.c) instead; everything after it is the same.
   bool host_entropy = false, damaged = false;
   jpeg_header hdr;
-  if (jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream) != EXIT_SUCCESS) {
+  link_turn link(pl);
+  jga_huff_set_upload_gate(l.hb, pl->link_slots > 0 ? &link_turn::take_hook : nullptr, &link);
+  const int prc = jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream);
+  jga_huff_set_upload_gate(l.hb, nullptr, nullptr);
+  if (link.held) {                                  // the upload is on its way: hold the turn until it is there
+    (void)jga_huff_wait_upload(l.hb);
+    link.give();
+  }
+  if (prc != EXIT_SUCCESS) {
     if (m != 1) return GROUP_REJECTED;              // run_lane looks at the per-member verdicts
     if (jga_huff_prepare_verdict(l.hb, 0) != 2) return EXIT_FAILURE;
     if (jga_parse_header(jobv[0]->jpeg, jobv[0]->size, &hdr) != EXIT_SUCCESS
@@ -674,6 +718,7 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
       }
       if (const char *e = getenv("JGA_PIPE_GROUPS_PER_LANE")) pl->groups_per_lane = atoi(e) > 0 ? atoi(e) : 1;
       if (const char *e = getenv("JGA_PIPE_MIN_GROUP")) pl->min_group_eq = atoi(e) > 0 ? atoi(e) : 1;
+      if (const char *e = getenv("JGA_PIPE_LINK_SLOTS")) pl->link_slots = pl->link_free = atoi(e) > 0 ? atoi(e) : 0;   // tuning knob
     }
     for (auto &l : pl->lanes) {
       if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")

@@ -23,7 +23,7 @@ EXPORTED = [
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
     "jga_huff_decode", "jga_huff_prepare_verdict", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
-    "jga_huff_set_threads", "jga_huff_set_device_unstuff", "jga_huff_set_inputs_pinned", "jga_huff_set_blocking_waits", "jga_huff_set_copy_stream", "jga_huff_set_device_shared",
+    "jga_huff_set_threads", "jga_huff_set_device_unstuff", "jga_huff_set_inputs_pinned", "jga_huff_set_blocking_waits", "jga_huff_set_copy_stream", "jga_huff_set_device_shared", "jga_huff_set_upload_gate", "jga_huff_wait_upload",
     "jga_host_register", "jga_host_unregister",
 ]
 
