@@ -386,6 +386,11 @@ jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg);
  * pipeline (its lanes and their threads — which live from create to destroy, in the process that
  * created them — belong to the run); several pipelines may run side by side. */
 int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);
+/* The groups a transport-2 pipeline of `lanes` lanes and `batch` 4K-frame equivalents per group (0: the
+ * defaults) would cut jobs[0..n) into: group_of[i] = the group of job i; returns the number of groups.
+ * Host logic only (no device is touched): same-geometry jobs in arrival order, groups sized by pixels,
+ * short jobs cut finer, a long job's first groups rising in size. */
+int  jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int n, int *group_of);
 void jga_pipeline_destroy(jga_pipeline *pl);
 
 /* --- GPU entropy stage (BASELINE config 5): the scan is

@@ -604,6 +604,57 @@ uint64_t geometry_key(const unsigned char *p, int size) {
   return 0;
 }
 
+// How a run cuts its jobs into groups (transport 2) — host logic only, no device involved:
+// bucket the jobs by geometry, in arrival order.  `batch` counts 4K frames; smaller frames fill
+// a group to about the same number of pixels (a launch takes at least one run's latency however
+// little it decodes).  A job too short to keep every lane busy for several groups (1024 1080p
+// files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
+// entropy stage and block decode of different groups overlap: about groups_per_lane groups
+// per lane, none below min_group_eq frame equivalents.
+struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; };
+void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups) {
+  const int nl = pp.lanes, batch = pp.batch;
+  std::unordered_map<uint64_t, long long> pixels;            // geometry -> pixels of all its jobs
+  std::vector<uint64_t> keys((size_t)n);
+  for (int i = 0; i < n; i++) {
+    keys[(size_t)i] = geometry_key(jobs[i].jpeg, jobs[i].size);
+    if (keys[(size_t)i]) {
+      pixels[keys[(size_t)i]] += (long long)((keys[(size_t)i] >> 48) & 0xffff)*(long long)((keys[(size_t)i] >> 32) & 0xffff);
+    }
+  }
+  const long long frame = 3840ll*2160;
+  std::unordered_map<uint64_t, size_t> open;      // geometry -> its group still filling up
+  std::unordered_map<uint64_t, int> made_groups;  // geometry -> groups closed so far
+  for (int i = 0; i < n; i++) {
+    const uint64_t key = keys[(size_t)i];
+    auto it = key ? open.find(key) : open.end();
+    if (it == open.end()) {
+      groups.emplace_back();
+      groups.back().reserve(key ? batch : 1);
+      if (key) it = open.emplace(key, groups.size() - 1).first;
+      else { groups.back().push_back(i); continue; }      // unparsable: fails on its own
+    }
+    groups[it->second].push_back(i);
+    const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
+    long long eq = (pixels[key]/frame + (long long)pp.groups_per_lane*nl - 1)/((long long)pp.groups_per_lane*nl);
+    if (eq < pp.min_group_eq) eq = pp.min_group_eq;
+    if (eq > batch) eq = batch;
+    long long cap = px > 0 ? (eq*frame + px/2)/px : eq;          // images of this size per group
+    cap = cap < 1 ? 1 : cap > 16ll*batch ? 16ll*batch : cap;
+    // The first group of every lane of a LONG job (three groups per lane and more): a fraction of
+    // a group, rising from lane to lane — all lanes start preparing at the same moment, and the
+    // link has nothing to do until the first of them is through (4 ms for 48 4K frames).
+    // [MI355X] 1536 x 4K 129-132 -> 134-136 Gpixel/s; a short job's few groups stay equal (the
+    // 128-file shard: 4.25 ms against 4.57 with its eight groups ramped).
+    int &made = made_groups[key];
+    if (pp.ramp_first && made < nl && nl > 1 && pixels[key] >= 3ll*nl*cap*px) {
+      cap = (cap*(made + 1) + nl - 1)/nl;
+      if (cap < 1) cap = 1;
+    }
+    if ((long long)groups[it->second].size() >= cap) { open.erase(it); made++; }
+  }
+}
+
 void lane_groups(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *groups,
  std::atomic<int> *next, int threads) {
   for (;;) {
@@ -754,52 +805,14 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     const int nl = (int)pl->lanes.size();
     int per = pl->cfg.nthreads/nl;
     if (per < 1) per = 1;
-    // bucket the jobs by geometry, in arrival order.  `batch` counts 4K frames; smaller frames fill
-    // a group to about the same number of pixels (a launch takes at least one run's latency however
-    // little it decodes).  A job too short to keep every lane busy for several groups (1024 1080p
-    // files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
-    // entropy stage and block decode of different groups overlap: about groups_per_lane groups
-    // per lane, none below min_group_eq frame equivalents.
     std::vector<std::vector<jga_job *>> groups;
     {
-      std::unordered_map<uint64_t, long long> pixels;            // geometry -> pixels of all its jobs
-      std::vector<uint64_t> keys((size_t)n);
-      for (int i = 0; i < n; i++) {
-        keys[(size_t)i] = geometry_key(jobs[i].jpeg, jobs[i].size);
-        if (keys[(size_t)i]) {
-          pixels[keys[(size_t)i]] += (long long)((keys[(size_t)i] >> 48) & 0xffff)*(long long)((keys[(size_t)i] >> 32) & 0xffff);
-        }
-      }
-      const long long frame = 3840ll*2160;
-      std::unordered_map<uint64_t, size_t> open;      // geometry -> its group still filling up
-      std::unordered_map<uint64_t, int> made_groups;  // geometry -> groups closed so far
-      for (int i = 0; i < n; i++) {
-        const uint64_t key = keys[(size_t)i];
-        auto it = key ? open.find(key) : open.end();
-        if (it == open.end()) {
-          groups.emplace_back();
-          groups.back().reserve(key ? batch : 1);
-          if (key) it = open.emplace(key, groups.size() - 1).first;
-          else { groups.back().push_back(&jobs[i]); continue; }      // unparsable: fails on its own
-        }
-        groups[it->second].push_back(&jobs[i]);
-        const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
-        long long eq = (pixels[key]/frame + (long long)pl->groups_per_lane*nl - 1)/((long long)pl->groups_per_lane*nl);
-        if (eq < pl->min_group_eq) eq = pl->min_group_eq;
-        if (eq > batch) eq = batch;
-        long long cap = px > 0 ? (eq*frame + px/2)/px : eq;          // images of this size per group
-        cap = cap < 1 ? 1 : cap > 16ll*batch ? 16ll*batch : cap;
-        // The first group of every lane of a LONG job (three groups per lane and more): a fraction of
-        // a group, rising from lane to lane — all lanes start preparing at the same moment, and the
-        // link has nothing to do until the first of them is through (4 ms for 48 4K frames).
-        // [MI355X] 1536 x 4K 129-132 -> 134-136 Gpixel/s; a short job's few groups stay equal (the
-        // 128-file shard: 4.25 ms against 4.57 with its eight groups ramped).
-        int &made = made_groups[key];
-        if (pl->ramp_first && made < nl && nl > 1 && pixels[key] >= 3ll*nl*cap*px) {
-          cap = (cap*(made + 1) + nl - 1)/nl;
-          if (cap < 1) cap = 1;
-        }
-        if ((long long)groups[it->second].size() >= cap) { open.erase(it); made++; }
+      std::vector<std::vector<int>> plan;
+      plan_groups({nl, batch, pl->groups_per_lane, pl->min_group_eq, pl->ramp_first != 0}, jobs, n, plan);
+      groups.resize(plan.size());
+      for (size_t k = 0; k < plan.size(); k++) {
+        groups[k].reserve(plan[k].size());
+        for (int i : plan[k]) groups[k].push_back(&jobs[i]);
       }
     }
     if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), since_run_start_ms());
@@ -826,6 +839,18 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
   for (auto &th : threads) th.join();
   for (int i = 0; i < n; i++) failed += jobs[i].status != EXIT_SUCCESS;
   return failed ? EXIT_FAILURE : EXIT_SUCCESS;
+}
+
+// The plan jga_pipeline_run() would make for these jobs on a transport-2 pipeline of `lanes` lanes and
+// `batch` 4K-frame equivalents per group (0: the defaults): group_of[i] = the group job i goes to.
+// Returns the number of groups.  Host logic only: no device is touched.
+JGA_EXPORT int jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int n, int *group_of) {
+  std::vector<std::vector<int>> plan;
+  jga_pipeline defaults_of;                      // (its knob defaults; nothing of it is started)
+  plan_groups({lanes > 0 ? lanes : 6, batch > 0 ? batch : 48, defaults_of.groups_per_lane, defaults_of.min_group_eq,
+   defaults_of.ramp_first != 0}, jobs, n, plan);
+  for (size_t k = 0; k < plan.size(); k++) for (int i : plan[k]) group_of[i] = (int)k;
+  return (int)plan.size();
 }
 
 JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {

@@ -20,7 +20,7 @@ EXPORTED = [
     "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
     "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
     "jga_stream_sync", "jga_set_device", "jga_device_pci_bus_id", "jga_stream_create", "jga_stream_destroy",
-    "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run",
+    "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run", "jga_pipeline_plan",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
     "jga_huff_decode", "jga_huff_prepare_verdict", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
     "jga_huff_set_threads", "jga_huff_set_device_unstuff", "jga_huff_set_inputs_pinned", "jga_huff_set_blocking_waits", "jga_huff_set_copy_stream", "jga_huff_set_device_shared", "jga_huff_set_upload_gate", "jga_huff_wait_upload",
