@@ -160,13 +160,15 @@ def test_plugin_entropy_stage_choice(gpu, orc, jpg, entropy):
                                  {"JGA_HUFF_FLUSH": "1"}, {"JGA_PLUGIN_REGISTER": "0"},
                                  {"JGA_HUFF_SUB": "32"}, {"JGA_HUFF_SUB": "64"},
                                  {"JGA_HUFF_LITE": "0"}, {"JGA_HUFF_LITE": "1", "JGA_HUFF_ITERS": "1,1,2"},
-                                 {"JGA_HUFF_LITE": "120"}, {"JGA_HUFF_PACKS": "0"}])
+                                 {"JGA_HUFF_LITE": "120"}, {"JGA_HUFF_PACKS": "0"},
+                                 {"JGA_HUFF_LEAN": "0"}, {"JGA_HUFF_SPARSE_FROM": "1"}])
 def test_alternate_code_paths_give_the_same_pixels(gpu, orc, jpg, env):
     """Every tuning knob selects a different route to the same result: per-lane loads in the
     YUV kernel, the write pass with LDS-staged rows, dense rounds only, one in-group iteration
     per launch, unbatched block write-out, staged D2H, 32- and 64-byte subsequences, a counted
     first run, a lite first run that is a launch's only iteration, one that starts from the
-    subsequence's first bit / from near its end, tables without multi-symbol packs."""
+    subsequence's first bit / from near its end, tables without multi-symbol packs, the dense
+    rounds' stateless row reader, the sparse kernel for the later rounds of a lone frame."""
     import oracle
     path, data = jpg(777, 431, "420", quality=88, restart_interval=0)
     _, rgb = orc.decode_rgb(data)
@@ -177,3 +179,21 @@ def test_alternate_code_paths_give_the_same_pixels(gpu, orc, jpg, env):
     _, planes = orc.decode(data, oracle.YUV)
     for a, b in zip(numbers(run("--dump", "-o", "yuv", path, env=env).stdout), planes):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ri", [0, -1])
+def test_registered_buffers_big_file(gpu, orc, jpg, ri):
+    """JGA_PLUGIN_REGISTER=1 with a file of 1.5 MB or more: the file itself is registered, DMA'd
+    where it lies and cleaned up on the device, the pixels come straight into the caller's
+    registered buffers — same checksum as the oracle's pixels, frame after frame."""
+    path, data = jpg(3840, 2160, "420", quality=90, restart_interval=ri)
+    assert len(data) >= 3 << 19
+    _, rgb = orc.decode_rgb(data)
+    want = "%08x" % zlib.adler32(rgb.tobytes())
+    for env in ({"JGA_PLUGIN_REGISTER": "1"}, {"JGA_PLUGIN_REGISTER": "0"}):
+        out = run("-o", "rgb", "--frames", "3", "--check", path, env=env).stdout.strip().split("\n")
+        assert out[-1].endswith(want), (env, ri)
+    out = run("-o", "yuv", "--frames", "2", "--check", path, env={"JGA_PLUGIN_REGISTER": "1"}).stdout.strip().split("\n")
+    assert out[-1].split()[-1] == run("-o", "yuv", "--frames", "2", "--check", path,
+                                      env={"JGA_PLUGIN_REGISTER": "0"}).stdout.strip().split("\n")[-1].split()[-1]
