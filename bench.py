@@ -68,7 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=448,
+                    help="images per GPU per step (20 steps = 8 960 images, 223 GB of kept outputs, a timed "
+                         "region of ~0.5 s: VERDICT r3 asked for >= 0.5 s; 128 until round 3)")
     ap.add_argument("--group", type=int, default=32,
                     help="images the pipeline hands to the GPU entropy stage at a time (one lane's batch)")
     ap.add_argument("--kernel-batch", type=int, default=48, help="images per launch in the roofline leg")
@@ -94,9 +96,18 @@ def parse_args(argv=None):
                          "at N = 1 when rocprofv3 is on the box)")
     ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false",
                     help="quote profiles/pmc_latest.json instead (with its provenance)")
-    ap.add_argument("--max-keep-GB", type=float, default=96.0,
+    ap.add_argument("--max-keep-GB", type=float, default=236.0,
                     help="HBM the timed region's retained outputs may take (every image is kept and "
-                         "verified when they fit: 64 GB at the defaults)")
+                         "verified when they fit: 223 GB at the defaults; beyond it slots are re-used by "
+                         "jobs that decode the same file and the last writer of each slot is checked)")
+    ap.add_argument("--scale-proxy", type=int, default=8,
+                    help="N = 1: repeat the headline in a child confined to the CPUs ONE rank of this many "
+                         "gets (cgroup grant / N, on the GPU's NUMA node) -> `scale_proxy` (0 = skip)")
+    ap.add_argument("--as-rank-of", type=int, default=0, help=argparse.SUPPRESS)   # the scale-proxy child
+    ap.add_argument("--input-cache-MB", type=int, default=1024,
+                    help="jga_pipeline_config.input_cache_mb of the headline pipelines (0 = none): pageable "
+                         "files are registered at first sight inside the timed region and DMA'd where they "
+                         "lie from then on - used by the library where the scan clean-up runs on the device")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, report who they are and which CPUs they own, exit "
                          "(gloo; needs no GPU)")
@@ -371,13 +382,19 @@ class KeptOutputs:
     evenly spaced, so the pipeline writes a group with one launch), and the check of all of
     them against the oracle's pixels after the clock has stopped."""
 
-    def __init__(self, torch, n_images, out_bytes, group, max_bytes):
+    def __init__(self, torch, n_images, out_bytes, group, max_bytes, nfiles=1):
         self.torch, self.out_bytes = torch, out_bytes
         self.pitch = (out_bytes + 255) // 256 * 256
         free, _ = torch.cuda.mem_get_info()
-        room = int(min(max_bytes, free - (12 << 30)))               # leave the lanes their buffers
-        slots = max(group, min(n_images, room // self.pitch))
-        self.slots = n_images if slots >= n_images else slots // group * group
+        room = int(min(max_bytes, free - (28 << 30)))               # leave the lanes their buffers (8 x ~2.5 GB)
+        # When not every output fits, jobs k and k + slots share a slot: slots is a multiple of the
+        # number of distinct files (job k decodes file (13 + k) % nfiles), so that both decode the SAME
+        # file and whichever lane writes last leaves the same pixels (lanes finish out of order: ADVICE
+        # r3) — and of the group size, so that no group straddles the wrap.
+        import math
+        unit = group * nfiles // math.gcd(group, nfiles)
+        slots = max(unit, min(n_images, room // self.pitch))
+        self.slots = n_images if slots >= n_images else slots // unit * unit
         self.n_images = n_images
         self.buf = torch.empty(self.slots * self.pitch, dtype=torch.uint8, device="cuda")
 
@@ -454,6 +471,20 @@ def main():
     budget = shard.rank_cpu_budget(my_cpus, world, quota)
     if world > 1:
         os.environ["JGA_CPU_BUDGET"] = str(budget)     # the library's defaults: this rank's share, not the box's
+    proxy_of = args.as_rank_of if world == 1 else 0
+    if proxy_of > 1:
+        # scale-proxy child: this process lives on what ONE rank of `proxy_of` gets — its share of the
+        # grant, as that many CPUs of the GPU's NUMA node (a harder limit than the real thing: a real rank
+        # may burst onto its neighbours' idle cores inside the cgroup's budget, this one cannot)
+        budget = shard.rank_cpu_budget(my_cpus, proxy_of, quota if quota else float(len(orig_cpus)))
+        mine = sorted(os.sched_getaffinity(0))
+        cores = shard.cpu_cores(mine) if hasattr(shard, "cpu_cores") else [[c] for c in mine]
+        take = [core[0] for core in cores[:budget]] or mine[:budget]
+        os.sched_setaffinity(0, take)
+        my_cpus = len(take)
+        os.environ["JGA_CPU_BUDGET"] = str(budget)
+        if pin:
+            pin = dict(pin, cpus=len(take), cpu_list=",".join(map(str, take)))
     torch.cuda.set_device(gpu)
     lib.check(lib.L.jga_set_device(gpu))
     comm = Comm(torch, dist, rank, world, gpu, share)
@@ -498,12 +529,16 @@ def main():
     pins = [lib.PinnedBytes(j) for j in jpegs]
     cyc = lambda n, o=0: [jpegs[(o + i) % len(jpegs)] for i in range(n)]
     pcyc = lambda n, o=0: [pins[(o + i) % len(pins)].array for i in range(n)]
-    kept = KeptOutputs(torch, K * B, g.rgb_bytes, G, int(args.max_keep_GB * 2**30))
+    kept = KeptOutputs(torch, K * B, g.rgb_bytes, G, int(args.max_keep_GB * 2**30), len(jpegs))
     file_of_job = [(13 + i) % len(jpegs) for i in range(K * B)]
+
+    import resource
 
     def headline_run(pinned, **kw):
         src = pcyc if pinned else cyc
         mk = lambda n, o, **k2: lib.Pipeline.make_jobs(src(n, o), pinned=pinned, **k2)
+        if not pinned and args.input_cache_MB > 0:
+            kw.setdefault("input_cache_mb", args.input_cache_MB)
         pl = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False,
                           transport=2, batch=G, depth=args.lanes, **kw)
         setup_jobs = mk(args.lanes * G, 0)                           # lanes allocate their buffers
@@ -517,11 +552,20 @@ def main():
         if warm_jobs is not None:
             pl.run_jobs(warm_jobs)                                   # W untimed steps
         kept.buf.zero_()
+        if not pinned and kw.get("input_cache_mb"):
+            # whatever the warm-up left registered is dropped: every file's FIRST sight — its
+            # hipHostRegister — happens inside the timed region
+            for v in timed_jobs._keep[0]:
+                lib.L.jga_pipeline_forget_input(pl.ptr, v.ctypes.data)
+        c0 = pl.counters()
         fence()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         rc = pl.run_jobs(timed_jobs)                                 # exactly K steps; returns when
         fence()                                                      # every output is complete
         dt_local = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        c1 = pl.counters()
         pl.close()
         if rc != 0 or any(j.status != 0 for j in timed_jobs):
             raise SystemExit("bench.py: a job of the timed region failed: " + lib.L.jga_last_error().decode())
@@ -530,11 +574,33 @@ def main():
             raise SystemExit("bench.py: rank %d: %d of %d images of the timed region differ from the oracle "
                              "(first: job %d, file %d)" % (rank, len(bad), nver, bad[0], file_of_job[bad[0]]))
         rate, dt = comm.throughput(K * B * W * H, dt_local)
+        nj = len(timed_jobs)
         return {"rate": rate, "dt": dt, "dt_local": dt_local, "verified": nver,
-                "h2d": sum(j.h2d_bytes for j in timed_jobs) // len(timed_jobs)}
+                "h2d": sum(j.h2d_bytes for j in timed_jobs) // nj,
+                # what the host side spent on the timed region: CPU seconds of the whole process (all
+                # threads, user + system) and file bytes a host core read, per image
+                "cpu_ms_per_image": round(((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / nj * 1e3, 4),
+                "host_bytes_per_image": sum(j.host_bytes for j in timed_jobs) // nj,
+                "scan_cleanup": "device" if c1["cleanup_on_device"] else "host",
+                "registered_in_timed_region": c1["registered"] - c0["registered"],
+                "register_ms_total": round((c1["register_us"] - c0["register_us"]) / 1e3, 2),
+                "jobs_dma_in_place": c1["jobs_in_place"] - c0["jobs_in_place"]}
 
     page = headline_run(False)
     pinn = headline_run(True)
+    if proxy_of > 1:
+        # the scale-proxy child's whole report
+        keys = ("cpu_ms_per_image", "host_bytes_per_image", "scan_cleanup", "registered_in_timed_region",
+                "register_ms_total", "jobs_dma_in_place")
+        print("SCALE_PROXY " + json.dumps({
+            "as_rank_of": proxy_of, "cpus": my_cpus, "cpu_list": sorted(os.sched_getaffinity(0)),
+            "cpu_budget": budget, "host_threads": nthreads, "images": K * B, "images_verified": page["verified"] + pinn["verified"],
+            "pageable": dict({"Mpixel_s": round(page["rate"] / 1e6, 1), "ms_per_step": round(page["dt"] / K * 1e3, 4)},
+                             **{k: page[k] for k in keys}),
+            "pinned": dict({"Mpixel_s": round(pinn["rate"] / 1e6, 1), "ms_per_step": round(pinn["dt"] / K * 1e3, 4)},
+                           **{k: pinn[k] for k in keys})}), flush=True)
+        comm.close()
+        return
     rate, dt = page["rate"], page["dt"]
     h2d_per_image = page["h2d"]
     ok = True
@@ -545,13 +611,48 @@ def main():
             r_ = headline_run(True, unstuff=mode)
             forced[name] = {"value": round(r_["rate"] / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * B,
                             "images_verified": r_["verified"], "ok": True,
-                            "ms_per_step": round(r_["dt"] / K * 1e3, 4)}
+                            "ms_per_step": round(r_["dt"] / K * 1e3, 4), "scan_cleanup": r_["scan_cleanup"],
+                            "cpu_ms_per_image": r_["cpu_ms_per_image"]}
+        # ... and the route a rank with few cores takes, on THIS box's full grant: pageable files through
+        # the input cache (registered at first sight inside the timed region, DMA'd in place afterwards),
+        # clean-up on the device
+        if args.input_cache_MB > 0:
+            r_ = headline_run(False, unstuff=2)
+            forced["pageable_files_input_cache_device_cleanup"] = {
+                "value": round(r_["rate"] / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": K * B,
+                "images_verified": r_["verified"], "ok": True, "ms_per_step": round(r_["dt"] / K * 1e3, 4),
+                **{k: r_[k] for k in ("scan_cleanup", "cpu_ms_per_image", "host_bytes_per_image",
+                                      "registered_in_timed_region", "register_ms_total", "jobs_dma_in_place")}}
     kept_slots = kept.slots
     kept.free()
     for p_ in pins:
         p_.free()
-    cleanup_route = "device" if min(nthreads, my_cpus, int(quota / world) if quota else my_cpus) \
-        <= int(os.environ.get("JGA_PIPE_OFFLOAD_AT", "8")) else "host"
+    # ---- scale proxy (N = 1): what ONE rank of `--scale-proxy` would reach on its share of the host — the
+    # headline repeated by a child process confined to grant / N CPUs of this GPU's NUMA node (a real
+    # 8-GPU node is not ours to launch; the driver measures the curve, this is its host-side predictor)
+    scale_proxy = None
+    if world == 1 and rank == 0 and args.scale_proxy > 1:
+        t_sp = time.perf_counter()
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(K), "--warmup", str(Wm),
+               "--batch", str(B), "--group", str(G), "--lanes", str(args.lanes), "--distinct", str(args.distinct),
+               "--as-rank-of", str(args.scale_proxy), "--input-cache-MB", str(args.input_cache_MB),
+               "--max-keep-GB", str(args.max_keep_GB), "--prewarm", str(args.prewarm)] + (["--no-pin"] if args.no_pin else [])
+        try:
+            os.sched_setaffinity(0, orig_cpus)                      # (the child pins itself, from the whole mask)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                               env={k: v for k, v in os.environ.items() if k != "JGA_CPU_BUDGET"})
+            line = [l for l in r.stdout.splitlines() if l.startswith("SCALE_PROXY ")]
+            if r.returncode == 0 and line:
+                scale_proxy = json.loads(line[0][len("SCALE_PROXY "):])
+                scale_proxy["seconds"] = round(time.perf_counter() - t_sp, 1)
+            else:
+                log("bench.py: scale-proxy child failed (rc %d):\n%s" % (r.returncode, r.stderr[-1500:]))
+        except Exception as e:
+            log("bench.py: scale-proxy child unavailable (%s)" % e)
+        finally:
+            if pin:
+                shard.pin_rank_to_gpu_node(local_rank, world, ids)
+    cleanup_route = page["scan_cleanup"]           # (what the library's `unstuff = 0` came to: jga_pipeline_counters)
     me = {"rank": rank, "gpu": gpu, "pci": (lib.device_pci_bus_id(gpu) if ndev else None),
           "numa_node": pin["numa_node"] if pin else None, "cpus": my_cpus,
           "cpu_list": pin["cpu_list"] if pin else None, "cpu_budget": budget, "host_threads": nthreads,
@@ -652,6 +753,11 @@ def main():
         "value_pageable": round(page["rate"] / 1e6, 1),
         "value_pinned_ingest": round(pinn["rate"] / 1e6, 1),
         "ms_per_step_pinned_ingest": round(pinn["dt"] / K * 1e3, 4),
+        # what the host spent per image of the two timed regions (process CPU time, all threads; file
+        # bytes read by host cores) and where the scan clean-up ran
+        "host_cost": {v: {k: r_[k] for k in ("cpu_ms_per_image", "host_bytes_per_image", "scan_cleanup",
+                                             "registered_in_timed_region", "jobs_dma_in_place")}
+                      for v, r_ in (("pageable", page), ("pinned_ingest", pinn))},
         "config": {
             "workload": "3840x2160 4:2:0 q90 baseline JPEG files in host RAM (ordinary pageable buffers) -> "
                         "RGB8 in HBM (end to end), every output kept and compared with the oracle; "
@@ -705,21 +811,42 @@ def main():
     }
     if e2e:
         out["e2e"] = e2e
+    if scale_proxy:
+        sp = scale_proxy
+        sp["vs_value"] = {"pageable": round(sp["pageable"]["Mpixel_s"] * 1e6 / rate, 3),
+                          "pinned": round(sp["pinned"]["Mpixel_s"] * 1e6 / rate, 3)}
+        sp["note"] = ("the headline's K steps repeated by a child process confined (sched_setaffinity + "
+                      "JGA_CPU_BUDGET) to the CPUs one rank of %d gets on this host: the per-GPU rate to expect "
+                      "at N = %d if the host is the limit; same images, every output verified; pageable files go "
+                      "through the input cache (hipHostRegister at first sight, inside the timed region)"
+                      % (sp["as_rank_of"], sp["as_rank_of"]))
+        out["scale_proxy"] = sp
 
     if rank == 0:
         # what a plain device-to-device copy of the same volume reaches on this box (SURVEY.md
         # 8d: "state the measured copy ceiling next to the spec"): bytes read + bytes written
+        # (warmed: clocks ramped for 0.3 s first; 50 repetitions between two events on the current stream;
+        # both directions are counted: a copy of n bytes reads n and writes n)
         src = torch.empty(alg_bytes // 2, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(src)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        dst.copy_(src)
-        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.3:
+            for _ in range(10):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+        reps_c = 50
         e0.record()
-        for _ in range(10):
+        for _ in range(reps_c):
             dst.copy_(src)
         e1.record()
         torch.cuda.synchronize()
-        out["roofline"]["device_copy_GBps"] = round(2 * src.numel() * 10 / e0.elapsed_time(e1) / 1e6, 1)
+        ms_c = e0.elapsed_time(e1) / reps_c
+        out["roofline"]["device_copy_GBps"] = round(2 * src.numel() / ms_c / 1e6, 1)
+        out["roofline"]["device_copy"] = {"bytes_each_way": int(src.numel()), "reps": reps_c, "ms": round(ms_c, 4),
+                                          "read_GBps": round(src.numel() / ms_c / 1e6, 1),
+                                          "write_GBps": round(src.numel() / ms_c / 1e6, 1),
+                                          "note": "device-to-device copy of the kernel's byte volume, warmed, HIP events"}
         del src, dst
 
     solo = rank == 0 and world == 1

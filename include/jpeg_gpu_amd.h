@@ -169,7 +169,15 @@ extern const jpeg_decode_ctx_vtbl HIPJPEG_DECODE_CTX_VTBL;
  * at run time; decode_alloc returns NULL when it is not installed
  * (jga_libjpeg_available() == 0).  Not on the hot path: bench.py times it beside the
  * MI355X path and the harness offers it as `-i libjpeg`. */
-extern const jpeg_decode_ctx_vtbl LIBJPEG_DECODE_CTX_VTBL;
+/* Exported under a name of its own: a maintainer who adds this library to the reference's build
+ * keeps linking jpeg_wrap.o, which DEFINES the data symbol LIBJPEG_DECODE_CTX_VTBL
+ * (src/jpeg_wrap.c:246-252) — two definitions of one symbol would be interposed silently by a
+ * shared library and refused by a static one.  Code that does not include the reference's
+ * jpeg_wrap.h may still use the reference's name: it is an alias then. */
+extern const jpeg_decode_ctx_vtbl JGA_LIBJPEG_DECODE_CTX_VTBL;
+#if !defined(_jpeg_wrap_H)
+# define LIBJPEG_DECODE_CTX_VTBL JGA_LIBJPEG_DECODE_CTX_VTBL
+#endif
 int jga_libjpeg_available(void);
 
 /* ------------------------------------------------------------------------ */
@@ -361,6 +369,42 @@ typedef struct jga_pipeline_config {
                                 * whose jobs are all `pinned` are uploaded by DMA straight from the
                                 * callers' buffers; else on the host: one core unstuffs ~12 GB/s, as
                                 * fast as it could copy), 1 = host, 2 = GPU (jga_huff_set_device_unstuff) */
+  /* --- scheduling of transport 2 (what rounds 1-3 read from JGA_PIPE_* environment variables; the
+   *     environment is only consulted by builds made with -DJGA_TUNING).  0 = the default named. */
+  int link_slots;              /* uploads that may cross the link side by side: 0 = 2 (a single blob of 64 MB or
+                                * more takes both), -1 = no turns (every lane uploads when it is ready) */
+  int device_slots;            /* full-size groups whose kernels may be queued at a time: 0 = 3 */
+  int groups_per_lane;         /* a job too short for a steady state is cut into about this many groups per
+                                * lane: 0 = 4 ... */
+  int min_group;               /* ... none under this many 4K-frame equivalents: 0 = 4 */
+  int ramp_first;              /* a long job's first groups rise in size from lane to lane: 0 = yes, -1 = all equal */
+  int spin_waits;              /* 0: lanes waiting for the device poll and sleep (csrc/host_wait.h), 1: they
+                                * spin in the runtime's waits (a core each; the lowest latency) */
+  int offload_at;              /* unstuff = 0: the clean-up runs on the device when the host side can count on this
+                                * many cores or fewer: 0 = 8 */
+  int copy_streams;            /* uploads of all lanes go through this many shared copy streams, round robin:
+                                * 0 = none (each lane's own stream; measured better with link_slots) */
+  int trace;                   /* 1: a timeline of every run on stderr */
+  /* --- ingest of caller-owned PAGEABLE buffers without a host copy (round 4).  input_cache_mb > 0: the
+   *     pipeline keeps up to that many MB of callers' JPEG buffers registered with the device
+   *     (hipHostRegister), keyed by (address, size), least recently used out first.  A buffer seen for the
+   *     input_cache_sight-th time (0 = 1: at first sight) is registered — inside the run that sees it —
+   *     and from then on its scan is DMA'd where it lies, exactly like a `pinned` job's; until then it
+   *     is copied as before.  Only used where the scan clean-up runs on the device (unstuff 2, or 0 with
+   *     few cores): a host that cleans up reads every byte anyway.  CONTRACT: a buffer handed in again
+   *     at the same address and size must still be the same live allocation, or have been dropped with
+   *     jga_pipeline_forget_input() before it was freed; jga_pipeline_destroy() unregisters everything. */
+  int input_cache_mb;
+  int input_cache_sight;
+  /* --- GPU entropy stage of the lanes' batches (jga_huff_set_option): 0 = default */
+  int huff_sub_bytes;          /* subsequence length 32/64/128/256/512; 0 = by batch (hj_choose_sub_log2) */
+  int huff_assist_after;       /* rounds before the host walks stretches that never fall into step: 0 = 12 */
+  int huff_speculate;          /* the decode's tail is queued behind the first burst of rounds: 0 = yes, -1 = no */
+  int short_job;               /* how a job of at most short_job_frames 4K-frame equivalents is run: 0 = auto,
+                                * 1 = cut into groups like any other, 2 = as few batches as possible whose
+                                * uploads arrive in pieces (the first synchronisation round of a piece starts
+                                * when its bytes have landed) */
+  int reserved_[6];            /* zero */
 } jga_pipeline_config;
 
 typedef struct jga_job {
@@ -375,6 +419,8 @@ typedef struct jga_job {
                                 * unstuffing then uploads the scan straight from it); bit 1: `host_out`
                                 * does (copy_back then writes the pixels straight into it: no staging
                                 * buffer, no host memcpy) — jga_host_malloc_pinned / jga_host_register */
+  long long host_bytes;        /* out: bytes of this file a host core read (copied or cleaned up) on the way to
+                                * the device; 0 when the scan was DMA'd where it lies */
 } jga_job;
 
 /* Zero the configuration (every 0 is a documented default) and stamp it with this header's
@@ -391,6 +437,20 @@ int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);
  * Host logic only (no device is touched): same-geometry jobs in arrival order, groups sized by pixels,
  * short jobs cut finer, a long job's first groups rising in size. */
 int  jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int n, int *group_of);
+/* The same for a whole configuration (depth, batch, groups_per_lane, min_group, ramp_first): exactly the
+ * plan jga_pipeline_run() of a pipeline created from `cfg` makes. */
+int  jga_pipeline_plan_cfg(const jga_pipeline_config *cfg, const jga_job *jobs, int n, int *group_of);
+/* input_cache_mb > 0: register [jpeg, jpeg + size) now (a reader that fills its ingest buffers before the
+ * first run) / drop it from the cache (before the caller frees or re-uses the memory).  Both return
+ * EXIT_SUCCESS or EXIT_FAILURE; forgetting a buffer the cache does not hold is not an error. */
+int  jga_pipeline_register_input(jga_pipeline *pl, const unsigned char *jpeg, int size);
+int  jga_pipeline_forget_input(jga_pipeline *pl, const unsigned char *jpeg);
+/* Counters of the pipeline since it was created: [0] buffers registered, [1] MB registered now, [2] jobs whose
+ * scan was DMA'd where it lay, [3] jobs whose scan a host core copied or cleaned up, [4] registrations
+ * evicted, [5] microseconds spent in hipHostRegister, [6] where the scan clean-up runs (0 host, 1 device: what
+ * unstuff = 0 came to), [7] bytes of callers' files read by host cores.  Fills at most n entries, returns how
+ * many exist. */
+int  jga_pipeline_counters(const jga_pipeline *pl, long long *out, int n);
 void jga_pipeline_destroy(jga_pipeline *pl);
 
 /* --- GPU entropy stage (BASELINE config 5): the scan is
@@ -463,6 +523,45 @@ void jga_huff_set_upload_gate(jga_huff_batch *b, void (*fn)(void *arg, long long
 int  jga_huff_wait_upload(jga_huff_batch *b);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);
+/* Per-image version of jga_huff_set_inputs_pinned for the NEXT prepare(): flags[i] != 0 says image i's
+ * buffer is pinned / registered (DMA'd where it lies when the clean-up runs on the device), 0 that it is
+ * ordinary memory (copied into the batch's pinned blob).  NULL: back to the all-or-nothing setting.  The
+ * array is read during prepare() only. */
+void jga_huff_set_input_flags(jga_huff_batch *b, const unsigned char *flags, int n);
+/* Bytes of the callers' files the last prepare() read on the host (0 = all DMA'd in place). */
+long long jga_huff_host_bytes(const jga_huff_batch *b);
+/* Tunables of a batch object that used to be JGA_HUFF_* environment variables (still read by builds made
+ * with -DJGA_TUNING).  value 0 = the default.  Returns EXIT_FAILURE for an unknown option or value. */
+enum {
+  JGA_HUFF_OPT_SUB_BYTES = 1,      /* subsequence length: 32, 64, 128, 256, 512; 0 = by batch */
+  JGA_HUFF_OPT_ASSIST_AFTER = 2,   /* rounds before the host walks unsettled stretches (default 12) */
+  JGA_HUFF_OPT_SPECULATE = 3,      /* 0 / 1 = the tail is queued behind the first rounds, -1 = never */
+  JGA_HUFF_OPT_PIECES = 4,         /* prepare() uploads the batch in this many pieces and decode() starts the
+                                    * first round of each as it lands (0 / 1 = one upload) */
+  JGA_HUFF_OPT_TRACE = 5           /* 1: what prepare() and decode() spent where, on stderr */
+};
+int jga_huff_set_option(jga_huff_batch *b, int option, int value);
+
+/* --- the plugin's settings (HIPJPEG_DECODE_CTX_VTBL has no room for options: decode_alloc takes a
+ *     jpeg_info and nothing else, src/jpeg_wrap.h:45).  Process-wide, read by decoder contexts when they
+ *     are allocated; what JGA_PLUGIN_* environment variables used to say. */
+typedef struct jga_plugin_config {
+  int struct_size;             /* sizeof(jga_plugin_config) of the caller's header */
+  int register_buffers;        /* 1: the caller keeps its image and file buffers alive and in place for as long
+                                * as a decoder context lives (the reference's main loop does,
+                                * src/jpeg_gpu.c:612-613, 1231-1237): they are registered with the device, pixels
+                                * are copied straight into them, big files DMA'd where they lie.  0 (default):
+                                * staged copies, safe for any caller */
+  int host_entropy;            /* 1: Huffman decoding on the host (csrc/entropy.c) for YUV / RGB too */
+  int copy_team;               /* staged copy back of frames of 12 MB and more: 0 = two helper threads move the
+                                * pieces (default), -1 = the calling thread alone */
+  int band_copy;               /* RGB frames of 24 MB and more with restart intervals: 0 = bands of MCU rows are
+                                * decoded and copied back one after the other (the copy of one hides the decode of
+                                * the next), -1 = whole frame at once */
+} jga_plugin_config;
+#define jga_plugin_config_init(cfg) do { memset((cfg), 0, sizeof(jga_plugin_config)); \
+  (cfg)->struct_size = (int)sizeof(jga_plugin_config); } while (0)
+int jga_plugin_configure(const jga_plugin_config *cfg);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -83,14 +83,30 @@ class jga_pipeline_config(C.Structure):
                 ("device", C.c_int), ("nthreads", C.c_int), ("depth", C.c_int),
                 ("out", C.c_int), ("copy_back", C.c_int),
                 ("max_coef_shorts", C.c_longlong), ("max_out_bytes", C.c_longlong),
-                ("transport", C.c_int), ("batch", C.c_int), ("unstuff", C.c_int)]
+                ("transport", C.c_int), ("batch", C.c_int), ("unstuff", C.c_int),
+                # round 4: scheduling knobs (0 = default), input cache, entropy-stage options
+                ("link_slots", C.c_int), ("device_slots", C.c_int), ("groups_per_lane", C.c_int),
+                ("min_group", C.c_int), ("ramp_first", C.c_int), ("spin_waits", C.c_int),
+                ("offload_at", C.c_int), ("copy_streams", C.c_int), ("trace", C.c_int),
+                ("input_cache_mb", C.c_int), ("input_cache_sight", C.c_int),
+                ("huff_sub_bytes", C.c_int), ("huff_assist_after", C.c_int), ("huff_speculate", C.c_int),
+                ("short_job", C.c_int), ("reserved_", C.c_int * 6)]
 
 
 class jga_job(C.Structure):
     _fields_ = [("jpeg", C.c_void_p), ("size", C.c_int), ("host_out", C.c_void_p),
                 ("dev_out", C.c_void_p), ("status", C.c_int), ("width", C.c_int),
                 ("height", C.c_int), ("nplanes", C.c_int), ("h2d_bytes", C.c_longlong),
-                ("pinned", C.c_int)]
+                ("pinned", C.c_int), ("host_bytes", C.c_longlong)]
+
+
+class jga_plugin_config(C.Structure):
+    _fields_ = [("struct_size", C.c_int), ("register_buffers", C.c_int), ("host_entropy", C.c_int),
+                ("copy_team", C.c_int), ("band_copy", C.c_int)]
+
+
+JGA_HUFF_OPT_SUB_BYTES, JGA_HUFF_OPT_ASSIST_AFTER, JGA_HUFF_OPT_SPECULATE, JGA_HUFF_OPT_PIECES, \
+    JGA_HUFF_OPT_TRACE = 1, 2, 3, 4, 5
 
 
 # SURVEY.md §8b ABI numbers (x86-64 SysV)

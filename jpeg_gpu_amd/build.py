@@ -28,6 +28,10 @@ CXX_SOURCES = ["device_api.cpp", "vtbl.cpp", "pipeline.cpp", "huff_prepare.cpp",
                "huff_api.cpp"]                           # host only: g++ + HIP API
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 LIB = os.path.join(HERE, "libjpeg_gpu_amd.so")
+# The same objects with layout.c compiled -DJGA_TUNING: the A/B knobs of rounds 1-3 (JGA_* environment
+# variables, csrc/jga_tune.h) exist in this one only.  For tests of alternate code paths and tools/.
+TUNING_LIB = os.path.join(HERE, "libjpeg_gpu_amd_tuning.so")
+TUNING_HARNESS = os.path.join(HERE, "jpeg_gpu_hip_tuning")
 SYNTH_LIB = os.path.join(HERE, "libjga_synth.so")
 HARNESS = os.path.join(HERE, "jpeg_gpu_hip")            # headless harness (csrc/harness.c)
 
@@ -83,7 +87,7 @@ def build(force=False, verbose=False):
 def _build_locked(force, verbose):
     headers = [os.path.join(CSRC, h) for h in ("jga_internal.h", "kernel_params.h", "huff_common.h",
                                                "huff_kernels.h", "huff_prepare.h", "pack_params.h",
-                                               "libjpeg8_abi.h", "unstuff_kernels.h")]
+                                               "libjpeg8_abi.h", "unstuff_kernels.h", "jga_tune.h", "host_wait.h")]
     headers.append(os.path.join(HERE, "..", "include", "jpeg_gpu_amd.h"))
     all_src = [os.path.join(CSRC, s) for s in C_SOURCES + HIP_SOURCES + CXX_SOURCES] + headers
 
@@ -92,16 +96,22 @@ def _build_locked(force, verbose):
         _run(["gcc", "-std=c99", "-O2", "-Wall", "-Wextra", "-fPIC", "-shared",
               "-fvisibility=hidden", "-o", SYNTH_LIB, synth_src, "-lm"])
 
-    if not force and _newer(LIB, all_src):
+    if not force and _newer(LIB, all_src) and _newer(TUNING_LIB, all_src):
         _build_harness(force)
         return LIB
     hipcc = _hipcc()
     objs = []
+    tuning_objs = []
     for s in C_SOURCES:
         o = os.path.join(OBJ, s + ".o")
-        _run(["gcc", "-std=gnu11", "-O3", "-Wall", "-Wextra", "-fPIC",
-              "-fvisibility=hidden", "-c", os.path.join(CSRC, s), "-o", o])
+        cc = ["gcc", "-std=gnu11", "-O3", "-Wall", "-Wextra", "-fPIC",
+              "-fvisibility=hidden", "-c", os.path.join(CSRC, s)]
+        _run(cc + ["-o", o])
         objs.append(o)
+        if s == "layout.c":                      # (where jga_tune() lives)
+            o = os.path.join(OBJ, s + ".tuning.o")
+            _run(cc + ["-DJGA_TUNING", "-o", o])
+        tuning_objs.append(o)
     for s in CXX_SOURCES:
         o = os.path.join(OBJ, s + ".o")
         _run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-fPIC", "-fvisibility=hidden",
@@ -132,16 +142,19 @@ def _build_locked(force, verbose):
                 print("ISA check ok: %s (%d bytes, no fma)" % (os.path.basename(asm), n))
     _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs +
          ["-lpthread", "-ldl"])
+    _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", TUNING_LIB] + tuning_objs +
+         objs[len(tuning_objs):] + ["-lpthread", "-ldl"])
     _build_harness(True)
     return LIB
 
 
 def _build_harness(force):
     src = os.path.join(CSRC, "harness.c")
-    if force or not _newer(HARNESS, [src, LIB]):
-        _run(["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", "-o", HARNESS, src,
-              "-L" + HERE, "-ljpeg_gpu_amd", "-Wl,-rpath,$ORIGIN",
-              "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+    for exe, lib, name in ((HARNESS, LIB, "jpeg_gpu_amd"), (TUNING_HARNESS, TUNING_LIB, "jpeg_gpu_amd_tuning")):
+        if force or not _newer(exe, [src, lib]):
+            _run(["gcc", "-std=gnu11", "-O2", "-Wall", "-Wextra", "-o", exe, src,
+                  "-L" + HERE, "-l" + name, "-Wl,-rpath,$ORIGIN",
+                  "-Wl,-rpath," + os.path.join(ROCM, "lib")])
 
 
 if __name__ == "__main__":

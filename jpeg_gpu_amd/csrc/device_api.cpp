@@ -26,7 +26,7 @@ static jga_divisor make_divisor(uint32_t d) {
 // YUV / grey kernels: 1 = coalesced 1 KB loads staged through LDS (default,
 // ~5 % faster than per-lane strided loads), 0 = per-lane loads.  JGA_STAGED=0|1.
 static int staged_loads(void) {
-  static const int mode = [] { const char *e = getenv("JGA_STAGED"); return e ? (int)(atoi(e) != 0) : 1; }();
+  static const int mode = [] { const char *e = jga_tune("JGA_STAGED"); return e ? (int)(atoi(e) != 0) : 1; }();
   return mode;
 }
 

@@ -334,8 +334,16 @@ int main(int argc, char *argv[]) {
   int c;
   memset(&info, 0, sizeof(info));
   /* this program keeps one image for the life of each decoder context, so the plugin may
-   * register its buffers and copy results straight into them */
-  setenv("JGA_PLUGIN_REGISTER", "1", 0);
+   * register its buffers and copy results straight into them (JPEG_GPU_HIP_REGISTER=0: as a caller
+   * that makes no such promise) */
+  {
+    jga_plugin_config pc;
+    const char *e = getenv("JPEG_GPU_HIP_REGISTER"), *h = getenv("JPEG_GPU_HIP_ENTROPY");
+    jga_plugin_config_init(&pc);
+    pc.register_buffers = !(e && *e == '0');
+    pc.host_entropy = h && strcmp(h, "host") == 0;           /* Huffman decoding on the host for -o yuv / rgb too */
+    if (jga_plugin_configure(&pc) != EXIT_SUCCESS) return EXIT_FAILURE;
+  }
   while ((c = next_option(argc, argv)) >= 0) {
     switch ((enum opt_id)c) {
       case OPT_NO_CPU : no_cpu = 1; break;
@@ -347,7 +355,7 @@ int main(int argc, char *argv[]) {
       case OPT_HEADER : head = 1; break;
       case OPT_IMPL : {
         if (strcmp(optarg, "hipjpeg") == 0) vtbl = HIPJPEG_DECODE_CTX_VTBL;
-        else if (strcmp(optarg, "libjpeg") == 0) vtbl = LIBJPEG_DECODE_CTX_VTBL;
+        else if (strcmp(optarg, "libjpeg") == 0) vtbl = JGA_LIBJPEG_DECODE_CTX_VTBL;
         else {
           fprintf(stderr, "Invalid decoder implementation: %s\n", optarg);
           usage();

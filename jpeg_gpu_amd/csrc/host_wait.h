@@ -15,6 +15,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdlib.h>
 #include <time.h>
+#include "jga_tune.h"
 
 static inline hipError_t jga_event_wait_sleeping(hipEvent_t ev) {
   hipError_t e = hipSuccess;
@@ -22,7 +23,7 @@ static inline hipError_t jga_event_wait_sleeping(hipEvent_t ev) {
     e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
   }
-  static const long nap_cap = getenv("JGA_WAIT_NAP_US") ? atol(getenv("JGA_WAIT_NAP_US"))*1000 : 40000;   // tuning knob
+  static const long nap_cap = jga_tune("JGA_WAIT_NAP_US") ? atol(jga_tune("JGA_WAIT_NAP_US"))*1000 : 40000;   // tuning knob
   long nap_ns = 20000;
   for (;;) {
     timespec ts = {0, nap_ns};

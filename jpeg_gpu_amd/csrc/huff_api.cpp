@@ -69,12 +69,15 @@ struct jga_huff_batch {
   // segment tables are made in HBM; the host-side copies assist_chains() needs are fetched lazily
   int device_unstuff, unstuffed_on_device;
   int inputs_pinned;           // callers' JPEG buffers are pinned/registered: DMA the scans straight from them
+  long long host_bytes;        // bytes of the callers' files the last prepare() read on the host
+  int assist_after, speculate, trace, pieces;   // jga_huff_set_option (0: defaults)
   size_t off_raw, off_uimg, off_part, off_bnd, off_info, off_perr;
   int max_chunks;
   jga_geom geom;
   std::vector<unsigned short> qtab;
   std::vector<unsigned char> verdict;   // last prepare(), per image: 0 ok, 1 unusable, 2 host entropy stage
   std::vector<unsigned char> shadow;    // device unstuffing: images | segs | clean scans read back (blob offsets)
+  std::vector<unsigned char> input_flags;   // per image: buffer pinned / registered (jga_huff_set_input_flags); empty: inputs_pinned for all
   int last_rounds;
 };
 
@@ -110,11 +113,11 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   // (grow_batch covers streams cut into very many restart intervals)
   // (sized for the shortest subsequences a batch of this capacity can be given)
   b->sub_cap = (size_t)(max_scan_bytes >> hj_choose_sub_log2((uint64_t)max_scan_bytes, 1, 1)) + (size_t)max_images*4096 + 1024;
-  if (const char *e = getenv("JGA_HUFF_SUB")) {               // tuning knob / tests: 32, 64 or 128
-    const int v = atoi(e);
-    b->force_sub_log2 = v == 32 ? 5 : v == 64 ? 6 : v == 128 ? 7 : v == 256 ? 8 : v == 512 ? 9 : 0;
-  }
-  if (const char *e = getenv("JGA_HUFF_DEVICE_UNSTUFF")) b->device_unstuff = atoi(e) != 0;
+  if (const char *e = jga_tune("JGA_HUFF_SUB")) (void)jga_huff_set_option(b, JGA_HUFF_OPT_SUB_BYTES, atoi(e));
+  if (const char *e = jga_tune("JGA_HUFF_DEVICE_UNSTUFF")) b->device_unstuff = atoi(e) != 0;
+  if (const char *e = jga_tune("JGA_HUFF_ASSIST_AFTER")) b->assist_after = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char *e = jga_tune("JGA_HUFF_SPECULATE")) b->speculate = atoi(e) == 0 ? -1 : 0;
+  if (jga_tune("JGA_PIPE_TRACE")) b->trace = 1;
   const size_t seg_cap = b->sub_cap;   // worst case one segment per subsequence
   b->blob_cap = align_up(sizeof(hj_image)*max_images, 256) + align_up(sizeof(hj_segment)*seg_cap, 256)
    + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_tables)*max_images, 256)
@@ -225,7 +228,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
  jga_geom *geom, void *stream) {
   std::vector<hj_prepared> prep((size_t)n);
   std::atomic<int> next_a(0), next_b(0), failed(0), irregular(0);
-  const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  const bool trace = b->trace != 0;
   const auto t_0 = std::chrono::steady_clock::now();
   int nt = b->prepare_threads;
   if (nt <= 0) {
@@ -233,9 +236,17 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     if (nt > 64) nt = 64;
   }
   if (nt > n) nt = n;
+  // which files are DMA'd where they lie: all (jga_huff_set_inputs_pinned), or those the caller flagged
+  std::vector<unsigned char> in_place((size_t)n, (unsigned char)(b->inputs_pinned != 0));
+  if (!b->input_flags.empty()) {
+    for (int i = 0; i < n; i++) in_place[(size_t)i] = (size_t)i < b->input_flags.size() && b->input_flags[(size_t)i] != 0;
+  }
+  int n_in_place = 0;
+  for (int i = 0; i < n; i++) n_in_place += in_place[(size_t)i];
   // files that stay where they are leave ~10 us of host work per image (marker parse, tables):
   // starting and joining a thread team costs more than it saves until the batch is large
-  if (b->inputs_pinned && n <= 128) nt = 1;
+  if (n_in_place == n && n <= 128) nt = 1;
+  b->host_bytes = 0;
   b->qtab.assign((size_t)n*192, 0);
   b->verdict.assign((size_t)n, 0);
   b->nimages = 0;
@@ -317,11 +328,11 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   hj_image *images = (hj_image *)(b->h_blob + b->off_images);
   hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
   memcpy(b->h_blob + b->off_uimg, uimg.data(), sizeof(hj_unstuff_image)*(size_t)n);
-  const bool zero_copy = b->inputs_pinned != 0;
+  const bool zero_copy = n_in_place > 0;
   auto copies = [&]() {
     for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
       hj_prepared &p = prep[i];
-      if (!zero_copy) memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + p.desc->scan_off, p.avail);
+      if (!in_place[(size_t)i]) memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + p.desc->scan_off, p.avail);
       p.im.sub0 = sub0v[(size_t)i];
       p.im.seg0 = seg0v[(size_t)i];
       p.im.scan_off = uimg[(size_t)i].raw_off;
@@ -356,14 +367,29 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->shadow.clear();
   hipStream_t st = (hipStream_t)stream;
   hipStream_t up = b->copy_stream ? b->copy_stream : st;       // (see jga_huff_set_copy_stream)
-  if (b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, zero_copy ? n + 1 : 1);
+  int ncopies = 1;
+  for (int i = 0; i < n; i++) {
+    if (!in_place[(size_t)i]) b->host_bytes += (long long)prep[i].avail;
+    if (in_place[(size_t)i] || (i > 0 && in_place[(size_t)i - 1])) ncopies++;
+  }
+  if (b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, ncopies);
   const auto t_1 = std::chrono::steady_clock::now();
   if (zero_copy) {
-    // the files lie in pinned memory: the DMA engine reads the scans where they are (the host
-    // never touches an entropy-coded byte); descriptors + tables go up from the blob as usual
-    for (int i = 0; i < n; i++) {
-      HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
-       prep[i].avail, hipMemcpyHostToDevice, up));
+    // files lying in pinned / registered memory: the DMA engine reads their scans where they are
+    // (the host never touches an entropy-coded byte); runs of files that were copied into the blob go up
+    // from there, one copy call per run, and so do the descriptors + tables
+    for (int i = 0; i < n; ) {
+      if (in_place[(size_t)i]) {
+        HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
+         prep[i].avail, hipMemcpyHostToDevice, up));
+        i++;
+        continue;
+      }
+      int j = i;
+      while (j + 1 < n && !in_place[(size_t)j + 1]) j++;
+      const size_t from = uimg[(size_t)i].raw_off, to = (size_t)uimg[(size_t)j].raw_off + uimg[(size_t)j].avail;
+      HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, to - from, hipMemcpyHostToDevice, up));
+      i = j + 1;
     }
     HOK(hipMemcpyAsync(b->d_blob + b->off_images, b->h_blob + b->off_images, b->upload_size - b->off_images,
      hipMemcpyHostToDevice, up));
@@ -391,8 +417,8 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   if (trace) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
       return std::chrono::duration<double, std::milli>(c - a).count(); };
-    fprintf(stderr, "  prepare (device clean-up%s, %d threads): heads + blob %.2f ms, %d copy call(s) + 2 memsets %.2f ms, 4 launches %.2f ms\n",
-     zero_copy ? ", files pinned" : "", nt, ms(t_0, t_1), zero_copy ? n + 1 : 1, ms(t_1, t_2),
+    fprintf(stderr, "  prepare (device clean-up, %d of %d files in place, %d threads): heads + blob %.2f ms, %d copy call(s) + 2 memsets %.2f ms, 4 launches %.2f ms\n",
+     n_in_place, n, nt, ms(t_0, t_1), ncopies, ms(t_1, t_2),
      ms(t_2, std::chrono::steady_clock::now()));
   }
   if (geom) *geom = b->geom;
@@ -407,6 +433,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
   if (b->device_unstuff) return prepare_raw(b, jpegs, sizes, n, geom, stream);
   b->unstuffed_on_device = 0;
+  b->host_bytes = 0;
   const auto t_p0 = std::chrono::steady_clock::now();
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
@@ -530,9 +557,10 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   if (fatal.load() == 1) return jga_fail("huff: images of one batch must share a geometry");
   if (fatal.load()) return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
   b->nimages = n;
+  for (int i = 0; i < n; i++) b->host_bytes += (long long)prep[i].avail;
   // the scan region is sized from the raw lengths; the bytes between an image's clean
   // stream (+16 pad) and the next image's start are never read
-  const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  const bool trace = b->trace != 0;
   if (b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, 1);
   const auto t_h = std::chrono::steady_clock::now();
   if (b->copy_stream && b->copy_stream != (hipStream_t)stream) {
@@ -587,6 +615,24 @@ JGA_EXPORT void jga_huff_set_copy_stream(jga_huff_batch *b, void *copy_stream) {
 
 // Host threads prepare() may use (0 = up to 64, one per image).
 JGA_EXPORT void jga_huff_set_threads(jga_huff_batch *b, int nthreads) { b->prepare_threads = nthreads; }
+// Per-image "this buffer is pinned / registered" for the next prepare() (NULL: the all-or-nothing flag).
+JGA_EXPORT void jga_huff_set_input_flags(jga_huff_batch *b, const unsigned char *flags, int n) {
+  if (flags && n > 0) b->input_flags.assign(flags, flags + n);
+  else b->input_flags.clear();
+}
+JGA_EXPORT long long jga_huff_host_bytes(const jga_huff_batch *b) { return b->host_bytes; }
+JGA_EXPORT int jga_huff_set_option(jga_huff_batch *b, int option, int value) {
+  switch (option) {
+    case JGA_HUFF_OPT_SUB_BYTES :
+      b->force_sub_log2 = value == 32 ? 5 : value == 64 ? 6 : value == 128 ? 7 : value == 256 ? 8 : value == 512 ? 9 : 0;
+      return value == 0 || b->force_sub_log2 ? EXIT_SUCCESS : jga_fail("huff: subsequence length %d (32, 64, 128, 256 or 512)", value);
+    case JGA_HUFF_OPT_ASSIST_AFTER : b->assist_after = value > 0 ? value : 0; return EXIT_SUCCESS;
+    case JGA_HUFF_OPT_SPECULATE : b->speculate = value < 0 ? -1 : 0; return EXIT_SUCCESS;
+    case JGA_HUFF_OPT_PIECES : b->pieces = value > 1 ? (value > 16 ? 16 : value) : 0; return EXIT_SUCCESS;
+    case JGA_HUFF_OPT_TRACE : b->trace = value != 0; return EXIT_SUCCESS;
+    default : return jga_fail("huff: unknown option %d", option);
+  }
+}
 
 // Bytes uploaded by the last prepare() (tables + states + compressed scan data).
 JGA_EXPORT long long jga_huff_upload_bytes(const jga_huff_batch *b) { return (long long)b->upload_size; }
@@ -715,7 +761,7 @@ static double thread_cpu_ms() {
 
 static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
  hipStream_t st) {
-  static const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  const bool trace = b->trace != 0;
   double c0 = trace ? thread_cpu_ms() : 0.0, c_launch = 0.0, c_wait = 0.0;
   auto lap = [&](double &acc) { if (trace) { const double c = thread_cpu_ms(); acc += c - c0; c0 = c; } };
   hj_args A;
@@ -772,20 +818,18 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   b->image_errors = 0;
   // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
   struct knobs {
-    int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, assist_after = 12, lean = 1;
+    int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1;
     knobs() {
-      const char *e = getenv("JGA_HUFF_ITERS");       // "first,later,group": in-group iterations, rounds per host check
+      const char *e = jga_tune("JGA_HUFF_ITERS");     // "first,later,group": in-group iterations, rounds per host check
       if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
       if (e && it0 < 1) it0 = 1;
       if (e && it1 < 1) it1 = 1;
       if (group < 1) group = 1;
-      e = getenv("JGA_HUFF_SPARSE_FROM");              // first round run by the sparse kernel (default: by batch size)
+      e = jga_tune("JGA_HUFF_SPARSE_FROM");            // first round run by the sparse kernel (default: by batch size)
       if (e) sparse_from = atoi(e);
-      e = getenv("JGA_HUFF_LEAN");                     // 0: the dense kernel's stateless row reader (A/B knob)
+      e = jga_tune("JGA_HUFF_LEAN");                   // 0: the dense kernel's stateless row reader (A/B knob)
       if (e) lean = atoi(e) != 0;
-      e = getenv("JGA_HUFF_ASSIST_AFTER");             // rounds before the host walks the unsettled stretches
-      if (e) assist_after = atoi(e) > 0 ? atoi(e) : 1;
-      e = getenv("JGA_HUFF_FLUSH");                    // write-pass batching
+      e = jga_tune("JGA_HUFF_FLUSH");                  // write-pass batching
       if (e) flush_lanes = atoi(e);
       if (flush_lanes < 1) flush_lanes = 1;
     }
@@ -801,7 +845,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
    && b->total_seg > 0 && b->total_sub/b->total_seg >= 64u;
   const int it_auto = long_intervals ? 6 : 3;
   const int it0 = K.it0 > 0 ? K.it0 : it_auto, it1 = K.it1 > 0 ? K.it1 : it_auto, group = K.group,
-            flush_lanes = K.flush_lanes, assist_after = K.assist_after;
+            flush_lanes = K.flush_lanes, assist_after = b->assist_after > 0 ? b->assist_after : 12;
   // Which kernel runs the later rounds.  The sparse one (a wave per 256 subsequences, rows read from
   // global memory) is for batches that fill the device: there a dense launch pays staging for
   // every group that still has one moving lane.  Up to ~200k subsequences (8 x 4K, 32 x 1080p) the
@@ -865,8 +909,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   // states — bounded like a corrupt stream's, but wrong: outputs and verdicts are reset, the
   // rounds go on, the tail runs again, and the next decode of this batch object queues more
   // rounds first (JGA_HUFF_SPECULATE=0: never).
-  static const bool speculate_ok = !(getenv("JGA_HUFF_SPECULATE") && atoi(getenv("JGA_HUFF_SPECULATE")) == 0);
-  bool speculated = speculate_ok && !b->assist_hint, tail_done = false;
+  bool speculated = b->speculate >= 0 && !b->assist_hint, tail_done = false;
   if (b->spec_rounds < GROUP) b->spec_rounds = GROUP;
   for (;;) {
     const int burst = speculated && round == 0 ? b->spec_rounds : GROUP;

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include "huff_common.h"
 #include "huff_kernels.h"
+#include "jga_tune.h"
 
 #define HJ_BLOCK 256
 // staged scan bytes: 256 subsequences x 35 dwords (3 alignment + 128 + look-ahead bytes)
@@ -1074,7 +1075,7 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
   // starts n - 1 bytes into its subsequence (A/B knob)
   // (default 49: measured 2.45 ms / 5 rounds from the first bit, 2.42-2.47 ms / 4 rounds from byte 48,
   // a lone 1080p frame 0.77 -> 0.70 ms: profiles/r2_lite_first_run_ab.txt)
-  static const int lite_first = getenv("JGA_HUFF_LITE") ? atoi(getenv("JGA_HUFF_LITE")) : 49;
+  static const int lite_first = jga_tune("JGA_HUFF_LITE") ? atoi(jga_tune("JGA_HUFF_LITE")) : 49;
   dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
   if (sparse > 0) {
     const dim3 sgrid((grid.x + HJ_SPARSE_GROUPS - 1)/HJ_SPARSE_GROUPS, grid.y);

@@ -85,7 +85,7 @@ static int build_table(hj_tables *T, uint16_t *l1, bool is_dc, int *l2_used, con
 // The pack of every 9-bit pattern (hj_tables): as many whole AC symbols — code and magnitude
 // bits — as the pattern holds, at most three, an EOB only as the last; none if fewer than two.
 static void build_packs(uint32_t *ac, const uint16_t *l1) {
-  static const bool off = getenv("JGA_HUFF_PACKS") && atoi(getenv("JGA_HUFF_PACKS")) == 0;   // (A/B knob)
+  static const bool off = jga_tune("JGA_HUFF_PACKS") && atoi(jga_tune("JGA_HUFF_PACKS")) == 0;   // (A/B knob)
   for (unsigned v = 0; v < (1u << HJ_FAST_BITS); v++) {
     int rem = HJ_FAST_BITS, n = 0, bits = 0, adv = 0, prefix = 0;
     unsigned val = v;

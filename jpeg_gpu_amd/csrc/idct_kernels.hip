@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "kernel_params.h"
+#include "jga_tune.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -1029,7 +1030,7 @@ extern "C" int jga_launch_rgb(const jga_kparams *P, int xdec, int ydec,
   }
   else {
     // 4:4:4, 4:2:2, 4:4:0: the row-parallel kernel (JGA_RGB_ROWS=0 selects the tile kernel, for A/B)
-    static const bool tile_only = getenv("JGA_RGB_ROWS") && atoi(getenv("JGA_RGB_ROWS")) == 0;
+    static const bool tile_only = jga_tune("JGA_RGB_ROWS") && atoi(jga_tune("JGA_RGB_ROWS")) == 0;
     if (!tile_only && xdec == 0 && ydec == 0) e = launch_rows_t<0, 0>(*P, st);
     else if (!tile_only && xdec == 1 && ydec == 0) e = launch_rows_t<1, 0>(*P, st);
     else if (!tile_only && xdec == 0 && ydec == 1) e = launch_rows_t<0, 1>(*P, st);

@@ -10,6 +10,8 @@ extern "C" {
 
 #define JGA_EXPORT __attribute__((visibility("default")))
 
+#include "jga_tune.h"
+
 /* Record an error (thread-local), print it to stderr unless JGA_QUIET is set,
  * return EXIT_FAILURE. */
 int jga_fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));

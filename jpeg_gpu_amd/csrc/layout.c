@@ -65,6 +65,16 @@ int jga_fail(const char *fmt, ...) {
 }
 
 const char *jga_last_error(void) { return jga_err; }
+
+/* A/B knobs (jga_tune.h): an environment variable in the tuning build, nothing in the product. */
+const char *jga_tune(const char *name) {
+#ifdef JGA_TUNING
+  return getenv(name);
+#else
+  (void)name;
+  return NULL;
+#endif
+}
 const char *jga_version(void) { return "jpeg_gpu_amd 0.1 (gfx950)"; }
 
 /* quota / period of one cgroup directory: cgroup v2 "cpu.max" ("quota period" or "max period"),

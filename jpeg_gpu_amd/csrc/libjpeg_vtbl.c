@@ -281,7 +281,7 @@ static void lj_free(jpeg_decode_ctx *dec) {
   free(ctx);
 }
 
-JGA_EXPORT const jpeg_decode_ctx_vtbl LIBJPEG_DECODE_CTX_VTBL = {
+JGA_EXPORT const jpeg_decode_ctx_vtbl JGA_LIBJPEG_DECODE_CTX_VTBL = {
   lj_alloc, lj_header, lj_image, lj_reset, lj_free
 };
 

@@ -35,11 +35,135 @@
 
 namespace {
 
-// JGA_PIPE_TRACE: offsets from the start of the current jga_pipeline_run (one run at a time when tracing)
-std::chrono::steady_clock::time_point g_run_t0;
-double since_run_start_ms() {
-  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_run_t0).count();
+// What jga_pipeline_config's scheduling fields come to once the defaults are filled in (and, in the
+// tuning build, the JGA_PIPE_* variables of rounds 2-3 have had their say): one helper for
+// jga_pipeline_create and jga_pipeline_plan_cfg, so that a plan is the plan a run makes.
+struct sched_knobs {
+  int lanes, batch, link_slots, dev_slots, groups_per_lane, min_group_eq, offload_at, copy_streams;
+  bool ramp_first, blocking, trace;
+};
+sched_knobs resolve_knobs(const jga_pipeline_config &c) {
+  sched_knobs k;
+  k.lanes = c.depth > 0 ? c.depth : 6;
+  k.batch = c.batch > 0 ? c.batch : 48;
+  k.link_slots = c.link_slots < 0 ? 0 : c.link_slots > 0 ? c.link_slots : 2;
+  k.dev_slots = c.device_slots > 0 ? c.device_slots : 3;
+  k.groups_per_lane = c.groups_per_lane > 0 ? c.groups_per_lane : 4;
+  k.min_group_eq = c.min_group > 0 ? c.min_group : 4;
+  k.ramp_first = c.ramp_first >= 0;
+  k.blocking = c.spin_waits == 0;
+  k.offload_at = c.offload_at > 0 ? c.offload_at : 8;
+  k.copy_streams = c.copy_streams > 0 ? (c.copy_streams > 8 ? 8 : c.copy_streams) : 0;
+  k.trace = c.trace != 0;
+  if (const char *e = jga_tune("JGA_PIPE_DEVICE_SLOTS")) k.dev_slots = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char *e = jga_tune("JGA_PIPE_SPIN")) k.blocking = atoi(e) == 0;
+  if (const char *e = jga_tune("JGA_PIPE_COPY_STREAMS")) k.copy_streams = atoi(e) > 8 ? 8 : atoi(e) > 0 ? atoi(e) : 0;
+  if (const char *e = jga_tune("JGA_PIPE_GROUPS_PER_LANE")) k.groups_per_lane = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char *e = jga_tune("JGA_PIPE_MIN_GROUP")) k.min_group_eq = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char *e = jga_tune("JGA_PIPE_RAMP_FIRST")) k.ramp_first = atoi(e) != 0;
+  if (const char *e = jga_tune("JGA_PIPE_LINK_SLOTS")) k.link_slots = atoi(e) > 0 ? atoi(e) : 0;
+  if (const char *e = jga_tune("JGA_PIPE_OFFLOAD_AT")) k.offload_at = atoi(e);
+  if (jga_tune("JGA_PIPE_TRACE")) k.trace = true;
+  if (k.dev_slots > k.lanes) k.dev_slots = k.lanes;
+  return k;
 }
+
+// Callers' pageable JPEG buffers kept registered with the device (jga_pipeline_config.input_cache_mb):
+// (address, size) -> registration, least recently used out first.  A lane ACQUIRES the buffers of its
+// group before it queues copies that read them and RELEASES them when its stream has drained; only
+// buffers nobody holds are evicted or forgotten.  hipHostRegister runs outside the lock (it takes
+// a few hundred microseconds; lanes register different buffers side by side) — a buffer in the middle of
+// being registered by one lane reads as "not registered" to the others, who copy it as before.
+struct input_cache {
+  struct entry { size_t bytes = 0; unsigned long long last = 0; int users = 0, sights = 0; bool registered = false, busy = false; };
+  std::mutex m;
+  std::unordered_map<const void *, entry> map;
+  size_t cap = 0, held = 0;
+  unsigned long long tick = 0;
+  int sight = 1;
+  static constexpr size_t MIN_BYTES = 64u << 10;     // (below this a copy is cheaper than a registration can ever be)
+  std::atomic<long long> n_registered{0}, n_evicted{0}, us_register{0}, n_in_place{0}, n_copied{0}, host_bytes{0};
+  bool enabled() const { return cap > 0; }
+  // make room for `bytes` by unregistering idle entries, oldest first (lock held)
+  bool make_room(size_t bytes) {
+    while (held + bytes > cap) {
+      const void *victim = nullptr;
+      unsigned long long oldest = ~0ull;
+      for (auto &kv : map) {
+        if (kv.second.registered && !kv.second.busy && kv.second.users == 0 && kv.second.last < oldest) {
+          oldest = kv.second.last; victim = kv.first;
+        }
+      }
+      if (!victim) return false;
+      (void)hipHostUnregister(const_cast<void *>(victim));
+      held -= map[victim].bytes;
+      map.erase(victim);
+      n_evicted++;
+    }
+    return true;
+  }
+  // true: [p, p + bytes) is registered and now held by the caller (release() it).  `count_sight`: a run is
+  // looking at the buffer (explicit registration passes false and registers at once)
+  bool acquire(const void *p, size_t bytes, bool count_sight = true) {
+    if (!enabled() || !p || bytes < MIN_BYTES || bytes > cap) return false;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      auto it = map.find(p);
+      if (it != map.end() && it->second.busy) return false;
+      if (it != map.end() && it->second.registered) {
+        if (bytes <= it->second.bytes) { it->second.users++; it->second.last = ++tick; return true; }
+        if (it->second.users > 0) return false;        // the same address, longer now, and still in use: copy
+        (void)hipHostUnregister(const_cast<void *>(p));
+        held -= it->second.bytes;
+        map.erase(it);
+        it = map.end();
+      }
+      entry &e = it != map.end() ? it->second : map[p];
+      e.last = ++tick;
+      if (count_sight && ++e.sights < sight) return false;
+      if (!make_room(bytes)) return false;
+      e.busy = true;                                   // (`e` stays valid: unordered_map nodes do not move)
+      e.bytes = bytes;
+      held += bytes;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t rc = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
+    us_register += (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lk(m);
+    entry &e = map[p];
+    e.busy = false;
+    if (rc != hipSuccess) {
+      (void)hipGetLastError();
+      held -= bytes;
+      map.erase(p);
+      return false;
+    }
+    e.registered = true;
+    e.users = 1;
+    n_registered++;
+    return true;
+  }
+  void release(const void *p) {
+    std::lock_guard<std::mutex> lk(m);
+    auto it = map.find(p);
+    if (it != map.end() && it->second.users > 0) it->second.users--;
+  }
+  int forget(const void *p) {
+    std::lock_guard<std::mutex> lk(m);
+    auto it = map.find(p);
+    if (it == map.end()) return EXIT_SUCCESS;
+    if (it->second.users > 0 || it->second.busy) return EXIT_FAILURE;
+    if (it->second.registered) { (void)hipHostUnregister(const_cast<void *>(p)); held -= it->second.bytes; }
+    map.erase(it);
+    return EXIT_SUCCESS;
+  }
+  void clear() {
+    std::lock_guard<std::mutex> lk(m);
+    for (auto &kv : map) if (kv.second.registered) (void)hipHostUnregister(const_cast<void *>(kv.first));
+    map.clear();
+    held = 0;
+  }
+};
 
 struct slot {
   short *h_coef = nullptr;          // pinned
@@ -93,6 +217,12 @@ struct jga_pipeline {
   std::condition_variable dev_cv;
   int dev_slots = 3;
   int dev_capacity = 0, dev_free = 0;          // dev_slots x batch frame equivalents (device_turn)
+  bool trace = false;                          // cfg.trace: a timeline of every run on stderr, offsets from run_t0
+  std::chrono::steady_clock::time_point run_t0;
+  double since_run_start_ms() const {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - run_t0).count();
+  }
+  input_cache inputs;                          // cfg.input_cache_mb: callers' pageable buffers kept registered
   // Lanes wait for the device several times per group; spinning in hipStreamSynchronize would
   // hold a core each, and a container may grant fewer cores than there are lanes: they poll and
   // sleep instead (host_wait.h; JGA_PIPE_SPIN=1 restores the spinning).
@@ -376,7 +506,8 @@ struct link_turn {
 // (its per-member verdicts then say who is to blame), EXIT_FAILURE for anything else.
 enum { GROUP_REJECTED = 2 };
 uint64_t geometry_key(const unsigned char *p, int size);
-int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads, bool shared = true) {
+int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads, bool shared = true,
+ bool reserve_full = false) {
   const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
   const bool copy_back = pl->cfg.copy_back != 0;
   std::vector<const unsigned char *> ptrs((size_t)m);
@@ -388,11 +519,14 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     sizes[i] = jobv[i]->size;
     total += jobv[i]->size + 4096;
   }
-  // Buffers are sized for a FULL group of this geometry (cfg.batch frame equivalents) the first
-  // time, whatever this group holds: a short first job (cut into small groups) must not leave the
-  // lanes re-allocating — pinned host memory at that — in the middle of the next, longer one.
+  // In a run that gives every lane several groups, buffers are sized for a FULL group of this
+  // geometry (cfg.batch frame equivalents) whatever this group holds: the ramped first groups of a
+  // long job must not leave the lanes re-allocating — pinned host memory at that — a few groups
+  // later.  A lone image or a short run takes what it needs (a full 4K group is ~2.5 GB of HBM per
+  // lane and, with copy_back, over 1 GB of pinned host memory); and if the full size cannot be had
+  // the group's own size is tried before the jobs are failed.
   int full = m;
-  {
+  if (reserve_full) {
     const uint64_t key = geometry_key(jobv[0]->jpeg, jobv[0]->size);
     const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
     const long long batch = pl->cfg.batch > 0 ? pl->cfg.batch : 48;
@@ -406,13 +540,24 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   if (on_device) total *= 2;
   if (!l.hb || m > l.hb_images || total > l.hb_scan) {
     if (l.hb) jga_huff_destroy(l.hb);
-    l.hb_images = full > l.hb_images ? full : l.hb_images;
-    l.hb_scan = total_full > l.hb_scan ? total_full : l.hb_scan;
+    const int had_images = l.hb_images;
+    const long long had_scan = l.hb_scan;
+    l.hb_images = full > had_images ? full : had_images;
+    l.hb_scan = total_full > had_scan ? total_full : had_scan;
     l.hb = jga_huff_create(l.hb_images, l.hb_scan);
+    if (!l.hb && (l.hb_images > m || l.hb_scan > total)) {     // not at the full size: at this group's, then
+      l.hb_images = m > had_images ? m : had_images;
+      l.hb_scan = total > had_scan ? total : had_scan;
+      full = m;
+      l.hb = jga_huff_create(l.hb_images, l.hb_scan);
+    }
     if (!l.hb) { l.hb_images = 0; l.hb_scan = 0; return EXIT_FAILURE; }
-
+    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_SUB_BYTES, pl->cfg.huff_sub_bytes);
+    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_ASSIST_AFTER, pl->cfg.huff_assist_after);
+    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_SPECULATE, pl->cfg.huff_speculate);
+    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_TRACE, pl->trace);
   }
-  const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
+  const bool trace = pl->trace;
   auto thread_cpu_ms = []() {          // CPU time this lane thread has burnt so far
     timespec ts;
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
@@ -421,11 +566,25 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   const auto t_a = std::chrono::steady_clock::now();
   const double c_a = trace ? thread_cpu_ms() : 0.0;
   jga_huff_set_threads(l.hb, threads);
+  // Which files the DMA engine reads where they lie (clean-up on the device only): those the caller
+  // says are pinned, and ordinary buffers the input cache holds registered (or registers now).
+  struct held_inputs {
+    input_cache &c;
+    std::vector<const void *> v;
+    ~held_inputs() { for (const void *p : v) c.release(p); }
+  } held{pl->inputs, {}};
+  std::vector<unsigned char> in_place((size_t)m, 0);
   {
-    bool pinned = true;
-    for (int i = 0; i < m; i++) pinned = pinned && (jobv[i]->pinned & 1) != 0;
+    for (int i = 0; i < m && on_device; i++) {
+      if (jobv[i]->pinned & 1) in_place[(size_t)i] = 1;
+      else if (pl->inputs.acquire(jobv[i]->jpeg, (size_t)jobv[i]->size)) {
+        in_place[(size_t)i] = 1;
+        held.v.push_back(jobv[i]->jpeg);
+      }
+    }
     jga_huff_set_device_unstuff(l.hb, on_device);
-    jga_huff_set_inputs_pinned(l.hb, on_device && pinned);
+    jga_huff_set_inputs_pinned(l.hb, 0);
+    jga_huff_set_input_flags(l.hb, in_place.data(), m);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
     jga_huff_set_device_shared(l.hb, shared);
     jga_huff_set_copy_stream(l.hb, pl->copy_streams.empty() ? nullptr
@@ -480,15 +639,14 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     for (int i = 1; i < m && strided; i++) strided = jobv[i]->dev_out == jobv[0]->dev_out + pitch*i;
   }
   const long long dcstride = (g.coef_shorts/64 + 127) & ~127ll;
-  if (!grow((void **)&l.d_coef, &l.cap_coef, cstride*2*full, false)
-   || !grow((void **)&l.d_dc, &l.cap_dc, dcstride*2*full, false)
-   || !grow((void **)&l.d_q, &l.cap_q, 384ll*full, false)) {
-    return EXIT_FAILURE;
-  }
-  if ((!all_given && !grow((void **)&l.d_out, &l.cap_out, ostride*full, false))
-   || (copy_back && !grow((void **)&l.h_out, &l.cap_hout, ostride*full, true))) {
-    return EXIT_FAILURE;
-  }
+  auto reserve = [&](int cnt) {
+    return grow((void **)&l.d_coef, &l.cap_coef, cstride*2*cnt, false)
+     && grow((void **)&l.d_dc, &l.cap_dc, dcstride*2*cnt, false)
+     && grow((void **)&l.d_q, &l.cap_q, 384ll*cnt, false)
+     && (all_given || grow((void **)&l.d_out, &l.cap_out, ostride*cnt, false))
+     && (!copy_back || grow((void **)&l.h_out, &l.cap_hout, ostride*cnt, true));
+  };
+  if (!reserve(full) && (full == m || !reserve(m))) return EXIT_FAILURE;   // (the full size first, this group's if that fails)
   device_turn turn(pl);
   turn.take((int)(((long long)m*g.width*g.height + 3840ll*2160 - 1)/(3840ll*2160)));   // (the group's upload is already in flight)
   const auto t_b = std::chrono::steady_clock::now();
@@ -533,6 +691,15 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
       }
     }
   }
+  if (damaged) {
+    // a damaged member's planes hold whatever its lanes reached plus leftovers of earlier groups in this
+    // lane's buffers: its pixels are not handed out — the job fails with a zeroed output
+    for (int i = 0; i < m; i++) {
+      if (jga_huff_image_error(l.hb, i) == 0) continue;
+      unsigned char *dst = jobv[i]->dev_out ? jobv[i]->dev_out : strided ? jobv[0]->dev_out + pitch*i : l.d_out + ostride*i;
+      if (!HOK(hipMemsetAsync(dst, 0, (size_t)out_bytes, l.stream))) return EXIT_FAILURE;
+    }
+  }
   if (copy_back) {
     for (int i = 0; i < m; i++) {
       if (!jobv[i]->host_out) continue;
@@ -553,7 +720,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     const double c_d = thread_cpu_ms();
     fprintf(stderr, "lane group of %d: began at %.2f ms; prepare + wait for a device slot %.2f ms (%.2f of this thread's CPU), "
      "entropy decode %.2f ms (%.2f), idct+out+sync %.2f ms (%.2f); done at %.2f ms\n",
-     m, ms(g_run_t0, t_a), ms(t_a, t_b), c_b - c_a, ms(t_b, t_c), c_c - c_b, ms(t_c, t_d), c_d - c_c, since_run_start_ms());
+     m, ms(pl->run_t0, t_a), ms(t_a, t_b), c_b - c_a, ms(t_b, t_c), c_c - c_b, ms(t_c, t_d), c_d - c_c, pl->since_run_start_ms());
   }
   const long long up = host_entropy ? g.coef_shorts*2 : jga_huff_upload_bytes(l.hb)/m;
   if (copy_back) {
@@ -574,6 +741,9 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   for (int i = 0; i < m; i++) {
     jobv[i]->width = g.width; jobv[i]->height = g.height; jobv[i]->nplanes = g.nplanes;
     jobv[i]->h2d_bytes = up;
+    jobv[i]->host_bytes = in_place[(size_t)i] ? 0 : jobv[i]->size;
+    (in_place[(size_t)i] ? pl->inputs.n_in_place : pl->inputs.n_copied)++;
+    pl->inputs.host_bytes += jobv[i]->host_bytes;
     jobv[i]->status = (damaged && jga_huff_image_error(l.hb, i) != 0) ? EXIT_FAILURE : EXIT_SUCCESS;
   }
   return EXIT_SUCCESS;
@@ -657,12 +827,13 @@ void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<
 
 void lane_groups(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>> *groups,
  std::atomic<int> *next, int threads) {
+  const bool long_run = groups->size() > 2*pl->lanes.size();       // every lane sees several groups
   for (;;) {
     const int gi = next->fetch_add(1);
     if (gi >= (int)groups->size()) break;
     std::vector<jga_job *> &grp = (*groups)[gi];
     const int m = (int)grp.size();
-    const int rc = lane_group(pl, *l, grp.data(), m, threads, groups->size() > 1);
+    const int rc = lane_group(pl, *l, grp.data(), m, threads, groups->size() > 1, long_run);
     if (rc == EXIT_SUCCESS || m == 1) continue;
     // One member with an unparsable header, or with Huffman tables outside the device lookup
     // format, must not cost the other 47 their batch: the members prepare() found usable go
@@ -687,7 +858,7 @@ void run_lane(jga_pipeline *pl, hlane *l) {
   const bool dev_ok = HOK(hipSetDevice(pl->cfg.device));
   // the naps of host_wait.h are tens of microseconds: the default 50 us of timer slack would
   // more than double them
-  if (!getenv("JGA_PIPE_KEEP_TIMERSLACK")) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL);
+  if (!jga_tune("JGA_PIPE_KEEP_TIMERSLACK")) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL);
   unsigned long long seen = 0;
   for (;;) {
     std::vector<std::vector<jga_job *>> *groups;
@@ -740,38 +911,38 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->cfg.nthreads = pl->cfg.transport == 2 ? cpus + cpus/2 : 3*cpus;
     if (pl->cfg.nthreads > 96) pl->cfg.nthreads = 96;
   }
+  const sched_knobs K = resolve_knobs(pl->cfg);
+  pl->trace = K.trace;
   {
     // how many cores the host side can count on: what the process is granted, or fewer if the
     // caller asked for fewer threads (a rank that shares its grant with seven others does)
     const int cpus = jga_cpu_budget();
-    const int at = getenv("JGA_PIPE_OFFLOAD_AT") ? atoi(getenv("JGA_PIPE_OFFLOAD_AT")) : 8;      // tuning knob
-    pl->offload_cleanup = (cpus < pl->cfg.nthreads ? cpus : pl->cfg.nthreads) <= at;
+    pl->offload_cleanup = (cpus < pl->cfg.nthreads ? cpus : pl->cfg.nthreads) <= K.offload_at;
   }
   if (!hip_ok(hipSetDevice(pl->cfg.device), "hipSetDevice")) {
     delete pl;
     return nullptr;
   }
   if (pl->cfg.transport == 2) {
-    pl->lanes.resize(pl->cfg.depth > 0 ? pl->cfg.depth : 6);
-    if (const char *e = getenv("JGA_PIPE_DEVICE_SLOTS")) pl->dev_slots = atoi(e) > 0 ? atoi(e) : 1;   // tuning knob
-    if (pl->dev_slots > (int)pl->lanes.size()) pl->dev_slots = (int)pl->lanes.size();
-    pl->dev_capacity = pl->dev_free = pl->dev_slots*(pl->cfg.batch > 0 ? pl->cfg.batch : 48);
-    if (const char *e = getenv("JGA_PIPE_SPIN")) pl->blocking = atoi(e) == 0;         // tuning knob
-    {
-      int ncopy = getenv("JGA_PIPE_COPY_STREAMS") ? atoi(getenv("JGA_PIPE_COPY_STREAMS")) : 0;   // (measured: profiles/r3_pipe_sweep.txt)
-      if (ncopy > 8) ncopy = 8;
-      for (int i = 0; i < ncopy; i++) {
-        hipStream_t cs = nullptr;
-        if (!hip_ok(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate")) {
-          jga_pipeline_destroy(pl);
-          return nullptr;
-        }
-        pl->copy_streams.push_back(cs);
+    pl->lanes.resize(K.lanes);
+    pl->dev_slots = K.dev_slots;
+    pl->dev_capacity = pl->dev_free = pl->dev_slots*K.batch;
+    pl->blocking = K.blocking;
+    pl->groups_per_lane = K.groups_per_lane;
+    pl->min_group_eq = K.min_group_eq;
+    pl->ramp_first = K.ramp_first;
+    pl->link_slots = pl->link_free = K.link_slots;
+    if (pl->cfg.input_cache_mb > 0) {
+      pl->inputs.cap = (size_t)pl->cfg.input_cache_mb << 20;
+      pl->inputs.sight = pl->cfg.input_cache_sight > 0 ? pl->cfg.input_cache_sight : 1;
+    }
+    for (int i = 0; i < K.copy_streams; i++) {                 // (measured: profiles/r3_pipe_sweep.txt)
+      hipStream_t cs = nullptr;
+      if (!hip_ok(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate")) {
+        jga_pipeline_destroy(pl);
+        return nullptr;
       }
-      if (const char *e = getenv("JGA_PIPE_GROUPS_PER_LANE")) pl->groups_per_lane = atoi(e) > 0 ? atoi(e) : 1;
-      if (const char *e = getenv("JGA_PIPE_MIN_GROUP")) pl->min_group_eq = atoi(e) > 0 ? atoi(e) : 1;
-      if (const char *e = getenv("JGA_PIPE_RAMP_FIRST")) pl->ramp_first = atoi(e) != 0;
-      if (const char *e = getenv("JGA_PIPE_LINK_SLOTS")) pl->link_slots = pl->link_free = atoi(e) > 0 ? atoi(e) : 0;   // tuning knob
+      pl->copy_streams.push_back(cs);
     }
     for (auto &l : pl->lanes) {
       if (!hip_ok(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking), "hipStreamCreate")
@@ -799,8 +970,8 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
   int failed = 0;
   for (int i = 0; i < n; i++) jobs[i].status = EXIT_FAILURE;
   if (pl->cfg.transport == 2) {
-    const bool trace = getenv("JGA_PIPE_TRACE") != nullptr;
-    if (trace) g_run_t0 = std::chrono::steady_clock::now();
+    const bool trace = pl->trace;
+    pl->run_t0 = std::chrono::steady_clock::now();
     const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 48;
     const int nl = (int)pl->lanes.size();
     int per = pl->cfg.nthreads/nl;
@@ -815,7 +986,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
         for (int i : plan[k]) groups[k].push_back(&jobs[i]);
       }
     }
-    if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), since_run_start_ms());
+    if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), pl->since_run_start_ms());
     {
       std::lock_guard<std::mutex> lk(pl->run_mutex);
       pl->run_groups = &groups; pl->run_next = &next; pl->run_threads = per;
@@ -823,12 +994,12 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
       pl->run_gen++;
     }
     pl->run_cv.notify_all();
-    if (trace) fprintf(stderr, "run: posted to %d lanes at %.2f ms\n", nl, since_run_start_ms());
+    if (trace) fprintf(stderr, "run: posted to %d lanes at %.2f ms\n", nl, pl->since_run_start_ms());
     {
       std::unique_lock<std::mutex> lk(pl->run_mutex);
       pl->done_cv.wait(lk, [&] { return pl->run_done == nl; });
     }
-    if (trace) fprintf(stderr, "run: lanes reported back at %.2f ms\n", since_run_start_ms());
+    if (trace) fprintf(stderr, "run: lanes reported back at %.2f ms\n", pl->since_run_start_ms());
     for (int i = 0; i < n; i++) failed += jobs[i].status != EXIT_SUCCESS;
     return failed ? EXIT_FAILURE : EXIT_SUCCESS;
   }
@@ -844,13 +1015,43 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
 // The plan jga_pipeline_run() would make for these jobs on a transport-2 pipeline of `lanes` lanes and
 // `batch` 4K-frame equivalents per group (0: the defaults): group_of[i] = the group job i goes to.
 // Returns the number of groups.  Host logic only: no device is touched.
-JGA_EXPORT int jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int n, int *group_of) {
+JGA_EXPORT int jga_pipeline_plan_cfg(const jga_pipeline_config *cfg, const jga_job *jobs, int n, int *group_of) {
   std::vector<std::vector<int>> plan;
-  jga_pipeline defaults_of;                      // (its knob defaults; nothing of it is started)
-  plan_groups({lanes > 0 ? lanes : 6, batch > 0 ? batch : 48, defaults_of.groups_per_lane, defaults_of.min_group_eq,
-   defaults_of.ramp_first != 0}, jobs, n, plan);
+  const sched_knobs K = resolve_knobs(*cfg);     // (what jga_pipeline_create makes of the same configuration)
+  plan_groups({K.lanes, K.batch, K.groups_per_lane, K.min_group_eq, K.ramp_first}, jobs, n, plan);
   for (size_t k = 0; k < plan.size(); k++) for (int i : plan[k]) group_of[i] = (int)k;
   return (int)plan.size();
+}
+JGA_EXPORT int jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int n, int *group_of) {
+  jga_pipeline_config cfg;
+  jga_pipeline_config_init(&cfg);
+  cfg.depth = lanes;
+  cfg.batch = batch;
+  return jga_pipeline_plan_cfg(&cfg, jobs, n, group_of);
+}
+
+JGA_EXPORT int jga_pipeline_register_input(jga_pipeline *pl, const unsigned char *jpeg, int size) {
+  if (!pl->inputs.enabled()) return jga_fail("pipeline: no input cache (jga_pipeline_config.input_cache_mb = 0)");
+  if (!hip_ok(hipSetDevice(pl->cfg.device), "hipSetDevice")) return EXIT_FAILURE;
+  if (!pl->inputs.acquire(jpeg, (size_t)(size > 0 ? size : 0), false)) {
+    return jga_fail("pipeline: could not register %d bytes at %p (cache of %d MB, buffers under 64 KB are never registered)",
+     size, (const void *)jpeg, pl->cfg.input_cache_mb);
+  }
+  pl->inputs.release(jpeg);
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_pipeline_forget_input(jga_pipeline *pl, const unsigned char *jpeg) {
+  (void)hipSetDevice(pl->cfg.device);
+  if (pl->inputs.forget(jpeg) != EXIT_SUCCESS) return jga_fail("pipeline: %p is in use by a running group", (const void *)jpeg);
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_pipeline_counters(const jga_pipeline *pl, long long *out, int n) {
+  const input_cache &c = pl->inputs;
+  const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pl->offload_cleanup);
+  const long long v[8] = {c.n_registered.load(), (long long)(c.held >> 20), c.n_in_place.load(), c.n_copied.load(),
+   c.n_evicted.load(), c.us_register.load(), on_device ? 1 : 0, c.host_bytes.load()};
+  for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
+  return 8;
 }
 
 JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {
@@ -863,6 +1064,7 @@ JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {
   pl->run_cv.notify_all();
   for (auto &th : pl->lane_threads) th.join();
   for (auto &l : pl->lanes) free_lane(l);
+  pl->inputs.clear();
   for (auto cs : pl->copy_streams) (void)hipStreamDestroy(cs);
   for (auto &w : pl->workers) {
     free_slot(w.slots[0]);

@@ -16,7 +16,7 @@
 //
 // For the YUV and RGB stages the scan itself is decoded on the GPU too
 // (jga_huff_*): the host only parses the markers and unstuffs the
-// scan into pinned memory.  JGA_PLUGIN_ENTROPY=host selects the host entropy
+// scan into pinned memory.  jga_plugin_config.host_entropy selects the host entropy
 // stage (csrc/entropy.c) instead; it is also what a file whose Huffman tables do
 // not fit the device lookup format ("too irregular") is decoded with.
 #include <hip/hip_runtime_api.h>
@@ -55,6 +55,7 @@ struct hipjpeg_ctx {
   struct { void *ptr; size_t bytes; } reg[6];
   hipEvent_t ev_piece[8];     // copy_back_staged
   struct copy_team *team;     // ... and its two helpers, started by the first big frame
+  struct { int register_buffers, host_entropy, copy_team, band_copy; } opt;   // jga_plugin_configure, as of decode_alloc
 };
 
 // Two helper threads that move pieces of a frame from the pinned staging buffer into the caller's
@@ -115,18 +116,27 @@ struct copy_team {
   }
 };
 
-int gpu_entropy_wanted(void) {
-  static const int mode = [] { const char *e = getenv("JGA_PLUGIN_ENTROPY"); return (e && strcmp(e, "host") == 0) ? 0 : 1; }();
-  return mode;
+// The plugin's settings (jga_plugin_configure): process-wide, copied into a context when it is
+// allocated.  Builds made with -DJGA_TUNING also listen to the JGA_PLUGIN_* variables of rounds 2-3.
+struct plugin_settings { int register_buffers, host_entropy, copy_team, band_copy; };
+std::mutex g_settings_mutex;
+plugin_settings g_settings = {0, 0, 0, 0};
+plugin_settings current_settings() {
+  std::lock_guard<std::mutex> lk(g_settings_mutex);
+  plugin_settings s = g_settings;
+  if (const char *e = jga_tune("JGA_PLUGIN_ENTROPY")) s.host_entropy = strcmp(e, "host") == 0;
+  if (const char *e = jga_tune("JGA_PLUGIN_REGISTER")) s.register_buffers = strcmp(e, "1") == 0;
+  if (const char *e = jga_tune("JGA_PLUGIN_COPY_TEAM")) s.copy_team = atoi(e) == 0 ? -1 : 0;
+  if (const char *e = jga_tune("JGA_PLUGIN_BAND_COPY")) s.band_copy = atoi(e) == 0 ? -1 : 0;
+  return s;
 }
 
-// True if [p, p+bytes) is (now) registered.  OPT-IN (JGA_PLUGIN_REGISTER=1): it is only
+// True if [p, p+bytes) is (now) registered.  OPT-IN (jga_plugin_config.register_buffers): it is only
 // safe for a caller that keeps the image's buffers alive and in place for as long as the
 // decoder context lives (the harness does; a caller that frees and re-allocates its image
 // between frames would leave a stale registration behind).  Default: the staged copy.
 bool registered(hipjpeg_ctx *c, void *p, size_t bytes) {
-  static const int want = [] { const char *e = getenv("JGA_PLUGIN_REGISTER"); return (e && strcmp(e, "1") == 0) ? 1 : 0; }();
-  if (!want || !p || !bytes) return false;
+  if (!c->opt.register_buffers || !p || !bytes) return false;
   int free_slot = -1;
   for (int i = 0; i < 6; i++) {
     if (c->reg[i].ptr == p && c->reg[i].bytes >= bytes) return true;
@@ -154,9 +164,33 @@ bool registered(hipjpeg_ctx *c, void *p, size_t bytes) {
 // k+1 crosses the link this thread moves piece k from the staging buffer into the caller's memory
 // (one core copies ~28 GB/s, the link carries 56: the frame's pixels arrive in about the time the
 // slower of the two takes, not in their sum — a 4K RGB frame 1.3 -> 0.9 ms).
-int copy_back_staged(hipjpeg_ctx *c, unsigned char *dst, const unsigned char *d_src, unsigned char *h_stage, size_t bytes) {
-  static const bool team_ok = !(getenv("JGA_PLUGIN_COPY_TEAM") && atoi(getenv("JGA_PLUGIN_COPY_TEAM")) == 0);   // A/B knob
-  const bool teamed = team_ok && bytes >= ((size_t)12 << 20);      // (a 1080p frame's 6 MB: the calling thread alone is quicker)
+// `bytes` of device memory at d_src land in pinned staging at h_stage and from there in the caller's
+// memory, which is `nseg` separate buffers: seg[k].len bytes at seg[k].dst, in the order they lie in
+// d_src (a frame's RGB pixels are one segment, its Y/Cb/Cr planes three).
+struct out_segment { unsigned char *dst; size_t len; };
+void scatter(const out_segment *seg, int nseg, size_t o, size_t len, const unsigned char *h_stage, copy_team *team) {
+  size_t base = 0;
+  for (int k = 0; k < nseg && len; k++) {       // the piece [o, o + len) may straddle two of the caller's buffers
+    if (o < base + seg[k].len) {
+      const size_t in = o - base, take = seg[k].len - in < len ? seg[k].len - in : len;
+      if (team) team->push({seg[k].dst + in, h_stage + o, take});
+      else memcpy(seg[k].dst + in, h_stage + o, take);
+      o += take; len -= take;
+    }
+    base += seg[k].len;
+  }
+}
+int copy_back_staged(hipjpeg_ctx *c, const out_segment *seg, int nseg, const unsigned char *d_src, unsigned char *h_stage, size_t bytes) {
+  // A small frame (a thumbnail, a 1080p plane set): one copy, one wait, one pass over the host memory —
+  // cutting it into pieces only adds launches and event waits that the overlap cannot win back
+  // (a YUV frame used to issue up to 18 copies + event waits, a plane at a time).
+  if (bytes < ((size_t)2 << 20)) {
+    HIP_OK(hipMemcpyAsync(h_stage, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    scatter(seg, nseg, 0, bytes, h_stage, NULL);
+    return EXIT_SUCCESS;
+  }
+  const bool teamed = c->opt.copy_team >= 0 && bytes >= ((size_t)12 << 20);      // (a 1080p frame's 6 MB: the calling thread alone is quicker)
   if (teamed && !c->team) c->team = new copy_team();
   const int PIECES = teamed ? 8 : 6;
   const size_t piece = ((bytes + PIECES - 1)/PIECES + 4095) & ~(size_t)4095;
@@ -175,8 +209,7 @@ int copy_back_staged(hipjpeg_ctx *c, unsigned char *dst, const unsigned char *d_
       if (teamed) c->team->finish();               // (nothing of ours may still be writing into the caller's memory)
       return jga_fail("hipjpeg: HIP error %d (%s) waiting for a piece of the frame", (int)e, hipGetErrorString(e));
     }
-    if (teamed) c->team->push({dst + o, h_stage + o, len});
-    else memcpy(dst + o, h_stage + o, len);
+    scatter(seg, nseg, o, len, h_stage, teamed ? c->team : NULL);
   }
   if (teamed) c->team->finish();
   return EXIT_SUCCESS;
@@ -230,8 +263,11 @@ int ensure_device(hipjpeg_ctx *c, long long coef_shorts, long long out_bytes) {
 jpeg_decode_ctx *hipjpeg_alloc(jpeg_info *info) {
   hipjpeg_ctx *c = (hipjpeg_ctx *)calloc(1, sizeof(hipjpeg_ctx));
   if (c != NULL) {
+    const plugin_settings s = current_settings();
     c->buf = info->buf;
     c->size = info->size;
+    c->opt.register_buffers = s.register_buffers; c->opt.host_entropy = s.host_entropy;
+    c->opt.copy_team = s.copy_team; c->opt.band_copy = s.band_copy;
   }
   return (jpeg_decode_ctx *)c;
 }
@@ -312,7 +348,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     if (ensure_device(c, g->coef_shorts, (out_bytes + 15) & ~15ll) != EXIT_SUCCESS) {
       return EXIT_FAILURE;
     }
-    int on_gpu = gpu_entropy_wanted();
+    int on_gpu = !c->opt.host_entropy;
     if (on_gpu) {
       jga_geom g2;
       if (!c->hb || c->size + 4096ll > c->hb_scan) {
@@ -362,8 +398,9 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
         HIP_OK(hipMemcpyAsync(img->pixels, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
       }
-      else if (copy_back_staged(c, img->pixels, c->d_out, c->h_out, (size_t)out_bytes) != EXIT_SUCCESS) {
-        return EXIT_FAILURE;
+      else {
+        const out_segment one = {img->pixels, (size_t)out_bytes};
+        if (copy_back_staged(c, &one, 1, c->d_out, c->h_out, (size_t)out_bytes) != EXIT_SUCCESS) return EXIT_FAILURE;
       }
     }
     else {
@@ -380,12 +417,11 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
         HIP_OK(hipStreamSynchronize(c->stream));
       }
       else {
-        for (i = 0; i < img->nplanes; i++) {
-          if (copy_back_staged(c, img->plane[i].data, c->d_out + g->plane[i].data_off, c->h_out + g->plane[i].data_off,
-           (size_t)img->plane[i].ystride*img->plane[i].height) != EXIT_SUCCESS) {
-            return EXIT_FAILURE;
-          }
-        }
+        // (the padded planes lie back to back in d_out, g->plane[i].data_off: ONE staged copy of all of
+        // them, scattered into the caller's three buffers as the pieces arrive)
+        out_segment planes[NPLANES_MAX];
+        for (i = 0; i < img->nplanes; i++) planes[i] = {img->plane[i].data, (size_t)img->plane[i].ystride*img->plane[i].height};
+        if (copy_back_staged(c, planes, img->nplanes, c->d_out, c->h_out, (size_t)out_bytes) != EXIT_SUCCESS) return EXIT_FAILURE;
       }
     }
   }
@@ -408,6 +444,19 @@ void hipjpeg_free(jpeg_decode_ctx *dec) {
 }
 
 }  // namespace
+
+extern "C" JGA_EXPORT int jga_plugin_configure(const jga_plugin_config *cfg) {
+  if (!cfg || cfg->struct_size != (int)sizeof(jga_plugin_config)) {
+    return jga_fail("plugin: caller built against another revision of jpeg_gpu_amd.h (jga_plugin_config %d bytes, this "
+     "library: %d) - use jga_plugin_config_init()", cfg ? cfg->struct_size : 0, (int)sizeof(jga_plugin_config));
+  }
+  std::lock_guard<std::mutex> lk(g_settings_mutex);
+  g_settings.register_buffers = cfg->register_buffers != 0;
+  g_settings.host_entropy = cfg->host_entropy != 0;
+  g_settings.copy_team = cfg->copy_team < 0 ? -1 : 0;
+  g_settings.band_copy = cfg->band_copy < 0 ? -1 : 0;
+  return EXIT_SUCCESS;
+}
 
 extern "C" JGA_EXPORT const jpeg_decode_ctx_vtbl HIPJPEG_DECODE_CTX_VTBL = {
   hipjpeg_alloc,

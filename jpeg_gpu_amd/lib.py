@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("JGA_LIB_PATH") or os.path.join(_HERE, "libjpeg_gpu_am
 
 # Symbols include/jpeg_gpu_amd.h declares (checked by tests/test_layout_abi.py).
 EXPORTED = [
-    "HIPJPEG_DECODE_CTX_VTBL", "LIBJPEG_DECODE_CTX_VTBL", "jga_libjpeg_available", "jga_version", "jga_last_error", "jga_image_init",
+    "HIPJPEG_DECODE_CTX_VTBL", "JGA_LIBJPEG_DECODE_CTX_VTBL", "jga_libjpeg_available", "jga_version", "jga_last_error", "jga_image_init",
     "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",
     "jga_parse_header", "jga_entropy_decode", "jga_entropy_decode_pack",
     "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_idct_rgb_batch_dc", "jga_idct_yuv_batch_dc", "jga_huff_decode_split", "jga_kernel_name",
@@ -25,6 +25,8 @@ EXPORTED = [
     "jga_huff_decode", "jga_huff_prepare_verdict", "jga_huff_upload_bytes", "jga_huff_last_rounds", "jga_huff_last_assisted", "jga_huff_image_errors", "jga_huff_image_error", "jga_huff_qtabs",
     "jga_huff_set_threads", "jga_huff_set_device_unstuff", "jga_huff_set_inputs_pinned", "jga_huff_set_blocking_waits", "jga_huff_set_copy_stream", "jga_huff_set_device_shared", "jga_huff_set_upload_gate", "jga_huff_wait_upload",
     "jga_host_register", "jga_host_unregister",
+    "jga_pipeline_plan_cfg", "jga_pipeline_register_input", "jga_pipeline_forget_input", "jga_pipeline_counters",
+    "jga_huff_set_input_flags", "jga_huff_host_bytes", "jga_huff_set_option", "jga_plugin_configure",
 ]
 
 
@@ -98,6 +100,17 @@ L.jga_pipeline_create.restype = _vp
 L.jga_pipeline_run.argtypes = [_vp, C.POINTER(abi.jga_job), _i]
 L.jga_pipeline_destroy.argtypes = [_vp]
 L.jga_pipeline_destroy.restype = None
+L.jga_pipeline_plan.argtypes = [_i, _i, C.POINTER(abi.jga_job), _i, C.POINTER(_i)]
+L.jga_pipeline_plan_cfg.argtypes = [C.POINTER(abi.jga_pipeline_config), C.POINTER(abi.jga_job), _i, C.POINTER(_i)]
+L.jga_pipeline_register_input.argtypes = [_vp, _vp, _i]
+L.jga_pipeline_forget_input.argtypes = [_vp, _vp]
+L.jga_pipeline_counters.argtypes = [_vp, C.POINTER(_ll), _i]
+L.jga_huff_set_input_flags.argtypes = [_vp, C.c_char_p, _i]
+L.jga_huff_set_input_flags.restype = None
+L.jga_huff_host_bytes.argtypes = [_vp]
+L.jga_huff_host_bytes.restype = _ll
+L.jga_huff_set_option.argtypes = [_vp, _i, _i]
+L.jga_plugin_configure.argtypes = [C.POINTER(abi.jga_plugin_config)]
 
 L.jga_huff_create.argtypes = [_i, _ll]
 L.jga_huff_create.restype = _vp
@@ -134,7 +147,7 @@ L.jga_huff_qtabs.argtypes = [_vp]
 L.jga_huff_qtabs.restype = C.POINTER(C.c_ushort)
 
 VTBL = abi.jpeg_decode_ctx_vtbl.in_dll(L, "HIPJPEG_DECODE_CTX_VTBL")
-LIBJPEG_VTBL = abi.jpeg_decode_ctx_vtbl.in_dll(L, "LIBJPEG_DECODE_CTX_VTBL")
+LIBJPEG_VTBL = abi.jpeg_decode_ctx_vtbl.in_dll(L, "JGA_LIBJPEG_DECODE_CTX_VTBL")
 
 
 def check(rc):
@@ -388,16 +401,42 @@ class PinnedBytes:
 # ---- pipeline -------------------------------------------------------------------
 
 class Pipeline:
-    def __init__(self, device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
-                 max_coef_shorts=0, max_out_bytes=0, transport=0, batch=0, depth=0, unstuff=0):
+    @staticmethod
+    def config(device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
+               max_coef_shorts=0, max_out_bytes=0, transport=0, batch=0, depth=0, unstuff=0, **more):
+        """A jga_pipeline_config; `more` = any of its round-4 fields by name (link_slots, device_slots,
+        groups_per_lane, min_group, ramp_first, spin_waits, offload_at, copy_streams, trace,
+        input_cache_mb, input_cache_sight, huff_sub_bytes, huff_assist_after, huff_speculate, short_job)."""
         cfg = abi.jga_pipeline_config(C.sizeof(abi.jga_pipeline_config), C.sizeof(abi.jga_job),
                                       device, nthreads, depth, out, int(copy_back),
                                       max_coef_shorts, max_out_bytes, int(transport), int(batch),
                                       int(unstuff))
+        names = {f[0] for f in abi.jga_pipeline_config._fields_}
+        for k, v in more.items():
+            if k not in names or k == "reserved_":
+                raise TypeError("jga_pipeline_config has no field %r" % k)
+            setattr(cfg, k, int(v))
+        return cfg
+
+    def __init__(self, *a, **k):
+        cfg = self.config(*a, **k)
         self.ptr = L.jga_pipeline_create(C.byref(cfg))
         if not self.ptr:
             raise JgaError((L.jga_last_error() or b"pipeline_create failed").decode())
-        self.copy_back = copy_back
+        self.copy_back = bool(cfg.copy_back)
+
+    def counters(self):
+        """{registered, registered_MB, jobs_in_place, jobs_copied, evicted, register_us} since create."""
+        v = (_ll * 8)()
+        L.jga_pipeline_counters(self.ptr, v, 8)
+        return dict(zip(("registered", "registered_MB", "jobs_in_place", "jobs_copied", "evicted", "register_us",
+                         "cleanup_on_device", "host_bytes"), [int(x) for x in v]))
+
+    def register_input(self, array):
+        check(L.jga_pipeline_register_input(self.ptr, array.ctypes.data, array.size))
+
+    def forget_input(self, array):
+        check(L.jga_pipeline_forget_input(self.ptr, array.ctypes.data))
 
     @staticmethod
     def make_jobs(jpegs, host_outs=None, dev_outs=None, pinned=False, outs_pinned=False):

@@ -121,11 +121,25 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     d = run_bench("--steps", "2", "--warmup", "1", "--batch", "4", "--group", "2", "--distinct", "4", "--lanes", "2",
                   "--prewarm", "0", "--kernel-reps", "3", "--kernel-batch", "4", "--cpu-rounds", "1", "--cpu-frames", "1",
                   "--no-e2e", "--no-pack", "--no-other", "--no-gpu-entropy", "--quick-configs",
-                  "--no-measure-traffic", timeout=1500)
+                  "--no-measure-traffic", "--scale-proxy", "8", timeout=1500)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
-              "cpu_baseline", "value_pageable", "value_pinned_ingest", "per_rank", "configs"):
+              "cpu_baseline", "value_pageable", "value_pinned_ingest", "per_rank", "configs", "scale_proxy",
+              "host_cost"):
         assert k in d, k
+    # the scale proxy: the same steps by a child confined to one rank-of-8's CPUs, every image verified;
+    # with that few cores the clean-up runs on the device and pageable files go through the input cache:
+    # registered at first sight INSIDE the timed region (4 distinct files), DMA'd in place afterwards
+    sp = d["scale_proxy"]
+    assert sp["as_rank_of"] == 8 and sp["cpus"] == sp["cpu_budget"] == len(sp["cpu_list"]) >= 1
+    assert sp["images"] == 8 and sp["images_verified"] == 16
+    for v in ("pageable", "pinned"):
+        assert sp[v]["Mpixel_s"] > 0 and sp[v]["cpu_ms_per_image"] >= 0 and sp[v]["scan_cleanup"] in ("host", "device")
+    if sp["pageable"]["scan_cleanup"] == "device":
+        # (a lane that meets a file another lane is registering at that moment copies it: rare, allowed)
+        assert sp["pageable"]["registered_in_timed_region"] == 4 and sp["pageable"]["jobs_dma_in_place"] >= 6
+        assert sp["pageable"]["host_bytes_per_image"] < 1_000_000 and sp["pinned"]["host_bytes_per_image"] == 0
+    assert d["host_cost"]["pageable"]["cpu_ms_per_image"] >= 0
     # `value` is the conservative variant (ordinary pageable files); the pinned-ingest rate sits beside it
     assert d["value"] == d["value_pageable"] and d["value_pinned_ingest"] > 0
     # EVERY image of the timed region kept its pixels and was compared with the oracle
@@ -188,7 +202,7 @@ def test_one_wrong_byte_in_the_timed_regions_outputs_fails_the_bench(gpu):
     env["JGA_BENCH_CORRUPT"] = "5"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--batch", "4",
                         "--group", "2", "--distinct", "4", "--lanes", "2", "--prewarm", "0", "--no-cpu", "--no-e2e",
-                        "--no-pack", "--no-other", "--no-gpu-entropy", "--no-configs", "--no-measure-traffic"],
+                        "--no-pack", "--no-other", "--no-gpu-entropy", "--no-configs", "--no-measure-traffic", "--scale-proxy", "0"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode != 0
     assert "differ from the oracle" in r.stderr and "job 5" in r.stderr

@@ -304,13 +304,12 @@ def test_pipeline_gpu_entropy_group_with_a_damaged_scan(gpu, orc, synth):
 
 
 @pytest.mark.parametrize("device_slots", [None, "1", "9"])
-def test_pipeline_gpu_entropy_batches(gpu, orc, synth, monkeypatch, device_slots):
+def test_pipeline_gpu_entropy_batches(gpu, orc, synth, device_slots):
     """transport 2 on a stream of same-geometry images: full groups, a ragged last group,
     results left in HBM at caller-given addresses and in internal buffers; with the default
     number of lanes allowed on the device at a time, with one, and with no limit."""
     from jpeg_gpu_amd import abi
-    if device_slots:
-        monkeypatch.setenv("JGA_PIPE_DEVICE_SLOTS", device_slots)
+    more = {"device_slots": int(device_slots)} if device_slots else {}
     datas = [synth.synthetic_jpeg(640, 360, "420", quality=50 + i, seed=i, restart_interval=(i % 2) * 40)
              for i in range(37)]
     _, g = gpu.geom_of(datas[0])
@@ -318,7 +317,7 @@ def test_pipeline_gpu_entropy_batches(gpu, orc, synth, monkeypatch, device_slots
     outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in datas]
     # `batch` counts 4K frames: 640x360 frames fill a group 16 to 1 -> groups of 16, 16 and 5
     pl = gpu.Pipeline(device=0, nthreads=6, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2,
-                      batch=1, depth=3)
+                      batch=1, depth=3, **more)
     dbuf = gpu.DeviceBuffer(gpu._align(g.rgb_bytes) * len(datas))
     try:
         rc, jobs = pl.run(datas, host_outs=outs)
@@ -399,10 +398,84 @@ def test_pipeline_unstuff_modes_and_pinned_inputs(gpu, orc, synth, mode):
         for i in range(len(datas)):
             if i != 7:
                 assert np.array_equal(outs[i], want[i]), (mode, i)
+        assert not outs[7].any()              # a failed job hands out zeros, not leftovers of other images
+        assert all(j.host_bytes == (0 if (j.pinned & 1) and mode != "host" else j.size) for j in jobs)
     finally:
         pl.close()
         for p in pins:
             p.free()
+
+
+def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
+    """jga_pipeline_config.input_cache_mb: callers' ordinary (pageable) buffers are registered with the
+    device the first (or input_cache_sight-th) time a run sees them and DMA'd where they lie from then
+    on — no host core reads a scan byte (jga_job.host_bytes == 0) — least recently used out first when
+    the cache is full; buffers under 64 KB and buffers larger than the cache are copied as before;
+    forget / explicit register; same pixels as the oracle's every time."""
+    from jpeg_gpu_amd import abi
+    datas = [synth.synthetic_jpeg(1280, 720, "420", quality=90, seed=40 + i, restart_interval=(i % 2) * 80)
+             for i in range(10)]
+    small = synth.synthetic_jpeg(1280, 720, "420", quality=5, seed=3)
+    assert all(len(d) > 200_000 for d in datas) and len(small) < 64 * 1024
+    _, g = gpu.geom_of(datas[0])
+    want = [orc.decode_rgb(d)[1].reshape(-1) for d in datas + [small]]
+    arrs = [np.frombuffer(d, np.uint8).copy() for d in datas + [small]]        # (malloc memory: pageable)
+    outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in arrs]
+
+    def run(pl, idx):
+        for o in outs:
+            o[:] = 0
+        jobs = gpu.Pipeline.make_jobs([arrs[i] for i in idx], host_outs=[outs[i] for i in idx])
+        assert pl.run_jobs(jobs) == 0
+        for i in idx:
+            assert np.array_equal(outs[i], want[i]), i
+        return jobs
+    total_mb = sum(a.size for a in arrs[:10]) / 2**20
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2,
+                      unstuff=2, input_cache_mb=int(total_mb) + 2)
+    try:
+        jobs = run(pl, list(range(11)))
+        c = pl.counters()
+        assert c["cleanup_on_device"] == 1 and c["registered"] == 10 and c["evicted"] == 0
+        assert [j.host_bytes for j in jobs] == [0] * 10 + [len(small)]          # first sight registers; the small file is copied
+        jobs = run(pl, [3, 3, 9, 0, 3])
+        c2 = pl.counters()
+        assert c2["registered"] == 10 and c2["jobs_in_place"] == c["jobs_in_place"] + 5
+        assert all(j.host_bytes == 0 for j in jobs)
+        pl.forget_input(arrs[3])
+        assert pl.counters()["registered_MB"] <= c2["registered_MB"]
+        run(pl, [3])
+        assert pl.counters()["registered"] == 11                                # ... and is registered again when it comes back
+        gpu.check(0)
+    finally:
+        pl.close()
+    # a cache too small for all of them: least recently used out first, never the ones a running group holds;
+    # second-sight policy: a buffer seen once is copied
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2,
+                      unstuff=2, input_cache_mb=1, input_cache_sight=2)
+    try:
+        jobs = run(pl, list(range(10)))
+        assert pl.counters()["registered"] == 0 and all(j.host_bytes == j.size for j in jobs)
+        run(pl, list(range(10)))
+        c = pl.counters()
+        assert c["registered"] >= 2 and c["evicted"] >= 1 and c["registered_MB"] <= 1
+        pl.register_input(arrs[0])                                              # explicit: at once, whatever the sight count
+        jobs = run(pl, [0])
+        assert jobs[0].host_bytes == 0
+        big = np.frombuffer(synth.synthetic_jpeg(1280, 720, "444", quality=100, seed=1), np.uint8).copy()
+        assert big.size > 1 << 20
+        with pytest.raises(gpu.JgaError):
+            pl.register_input(big)                                              # larger than the whole cache
+    finally:
+        pl.close()
+    # with the clean-up on the host the cache is not used at all (the host reads every byte anyway)
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2,
+                      unstuff=1, input_cache_mb=64)
+    try:
+        jobs = run(pl, list(range(10)))
+        assert pl.counters()["registered"] == 0 and all(j.host_bytes == j.size for j in jobs)
+    finally:
+        pl.close()
 
 
 # ---- PACK wire format expanded on the GPU (SURVEY.md §8f-2) ---------------------------
@@ -766,7 +839,8 @@ def test_split_decode_dc_values_beside_the_planes(gpu, orc, synth, sampling, ri)
 def test_speculative_tail_that_ran_too_early_is_undone(gpu):
     """The tail of a decode (prefix sums, write pass, DC pass) is queued behind the first group of
     rounds without waiting for them to settle.  With ONE round per group and one in-group iteration
-    (JGA_HUFF_ITERS=1,1,1: read once per process, hence the child) the first tail always runs on
+    (JGA_HUFF_ITERS=1,1,1: a knob of the tuning build, read once per process — hence the child on
+    libjpeg_gpu_amd_tuning.so) the first tail always runs on
     unsettled states: outputs and verdicts must be reset and the decode must still end equal to
     the oracle — planes, DC array, pixels — on the second decode of the same batch object too
     (which queues more rounds first), for clean and for damaged members."""
@@ -802,7 +876,8 @@ for batch, damaged in ((files, None), (files[:2] + [bad], 2)):
     hb.close(); d.free()
 print("OK", lib.L.jga_huff_last_rounds.__name__)
 """ % ROOT
-    env = dict(os.environ, JGA_HUFF_ITERS="1,1,1")
+    env = dict(os.environ, JGA_HUFF_ITERS="1,1,1",
+               JGA_LIB_PATH=os.path.join(ROOT, "jpeg_gpu_amd", "libjpeg_gpu_amd_tuning.so"))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]

@@ -11,11 +11,14 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "jpeg_gpu_amd", "jpeg_gpu_hip")
+# the same program on libjpeg_gpu_amd_tuning.so: the only build in which the JGA_* A/B variables of
+# rounds 1-3 exist (csrc/jga_tune.h) — tests of alternate code paths run this one
+EXE_TUNING = os.path.join(ROOT, "jpeg_gpu_amd", "jpeg_gpu_hip_tuning")
 SUBSAMP = ["Unknown", "4:4:4", "4:2:2", "4:2:0", "4:4:0", "4:1:1", "Mono"]
 
 
-def run(*args, ok=True, env=None):
-    r = subprocess.run([EXE] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+def run(*args, ok=True, env=None, exe=None):
+    r = subprocess.run([exe or EXE] + list(args), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=300, env=dict(os.environ, JGA_QUIET="0", **(env or {})))
     if ok:
         assert r.returncode == 0, r.stderr
@@ -142,10 +145,11 @@ def test_main_loop_finishes_every_stage_on_the_device(gpu, orc, jpg, stage, samp
 @pytest.mark.parametrize("entropy", ["gpu", "host"])
 def test_plugin_entropy_stage_choice(gpu, orc, jpg, entropy):
     """decode_image(YUV|RGB) decodes the scan on the GPU by default and on the host with
-    JGA_PLUGIN_ENTROPY=host: identical planes and pixels either way."""
+    jga_plugin_config.host_entropy (the harness sets it from JPEG_GPU_HIP_ENTROPY=host): identical
+    planes and pixels either way."""
     import oracle
     path, data = jpg(517, 389, "420", quality=92, restart_interval=7)
-    env = {"JGA_PLUGIN_ENTROPY": entropy}
+    env = {"JPEG_GPU_HIP_ENTROPY": entropy}
     _, planes = orc.decode(data, oracle.YUV)
     for a, b in zip(numbers(run("--dump", "-o", "yuv", path, env=env).stdout), planes):
         assert np.array_equal(a, b)
@@ -157,7 +161,7 @@ def test_plugin_entropy_stage_choice(gpu, orc, jpg, entropy):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"JGA_STAGED": "0"}, {"JGA_HUFF_WRITE_GMEM": "0"},
                                  {"JGA_HUFF_SPARSE_FROM": "99"}, {"JGA_HUFF_ITERS": "1,1,3"},
-                                 {"JGA_HUFF_FLUSH": "1"}, {"JGA_PLUGIN_REGISTER": "0"},
+                                 {"JGA_HUFF_FLUSH": "1"}, {"JPEG_GPU_HIP_REGISTER": "0"},
                                  {"JGA_HUFF_SUB": "32"}, {"JGA_HUFF_SUB": "64"},
                                  {"JGA_HUFF_LITE": "0"}, {"JGA_HUFF_LITE": "1", "JGA_HUFF_ITERS": "1,1,2"},
                                  {"JGA_HUFF_LITE": "120"}, {"JGA_HUFF_PACKS": "0"},
@@ -174,26 +178,26 @@ def test_alternate_code_paths_give_the_same_pixels(gpu, orc, jpg, env):
     _, rgb = orc.decode_rgb(data)
     want = "%08x" % zlib.adler32(rgb.tobytes())
     for stage in ("rgb", "yuv"):
-        out = run("-o", stage, "--frames", "2", "--check", path, env=env).stdout.strip().split("\n")
+        out = run("-o", stage, "--frames", "2", "--check", path, env=env, exe=EXE_TUNING).stdout.strip().split("\n")
         assert out[-1].endswith(want), (env, stage)
     _, planes = orc.decode(data, oracle.YUV)
-    for a, b in zip(numbers(run("--dump", "-o", "yuv", path, env=env).stdout), planes):
+    for a, b in zip(numbers(run("--dump", "-o", "yuv", path, env=env, exe=EXE_TUNING).stdout), planes):
         assert np.array_equal(a, b)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ri", [0, -1])
 def test_registered_buffers_big_file(gpu, orc, jpg, ri):
-    """JGA_PLUGIN_REGISTER=1 with a file of 1.5 MB or more: the file itself is registered, DMA'd
+    """jga_plugin_config.register_buffers (the harness's default; JPEG_GPU_HIP_REGISTER=0 turns it off) with a file of 1.5 MB or more: the file itself is registered, DMA'd
     where it lies and cleaned up on the device, the pixels come straight into the caller's
     registered buffers — same checksum as the oracle's pixels, frame after frame."""
     path, data = jpg(3840, 2160, "420", quality=90, restart_interval=ri)
     assert len(data) >= 3 << 19
     _, rgb = orc.decode_rgb(data)
     want = "%08x" % zlib.adler32(rgb.tobytes())
-    for env in ({"JGA_PLUGIN_REGISTER": "1"}, {"JGA_PLUGIN_REGISTER": "0"}):
+    for env in ({"JPEG_GPU_HIP_REGISTER": "1"}, {"JPEG_GPU_HIP_REGISTER": "0"}):
         out = run("-o", "rgb", "--frames", "3", "--check", path, env=env).stdout.strip().split("\n")
         assert out[-1].endswith(want), (env, ri)
-    out = run("-o", "yuv", "--frames", "2", "--check", path, env={"JGA_PLUGIN_REGISTER": "1"}).stdout.strip().split("\n")
+    out = run("-o", "yuv", "--frames", "2", "--check", path, env={"JPEG_GPU_HIP_REGISTER": "1"}).stdout.strip().split("\n")
     assert out[-1].split()[-1] == run("-o", "yuv", "--frames", "2", "--check", path,
-                                      env={"JGA_PLUGIN_REGISTER": "0"}).stdout.strip().split("\n")[-1].split()[-1]
+                                      env={"JPEG_GPU_HIP_REGISTER": "0"}).stdout.strip().split("\n")[-1].split()[-1]
