@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <thread>
 #include <time.h>
@@ -71,6 +72,12 @@ struct jga_huff_batch {
   int inputs_pinned;           // callers' JPEG buffers are pinned/registered: DMA the scans straight from them
   long long host_bytes;        // bytes of the callers' files the last prepare() read on the host
   int assist_after, speculate, trace, pieces;   // jga_huff_set_option (0: defaults)
+  // a batch whose upload arrives in pieces (JGA_HUFF_OPT_PIECES): prepare() has queued the start states and the
+  // first synchronisation round of every piece behind that piece's upload; the next decode goes on from round 1
+  int round0_queued;
+  hipStream_t own_copy;        // the pieces' uploads, when the caller gave no copy stream (kernels and copies of one
+                               // stream run in order: the next piece's copy would wait for this piece's round)
+  hipEvent_t ev_piece[16];
   size_t off_raw, off_uimg, off_part, off_bnd, off_info, off_perr;
   int max_chunks;
   jga_geom geom;
@@ -159,6 +166,8 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_ran) (void)hipFree(b->d_ran);
   if (b->d_errors) (void)hipFree(b->d_errors);
   if (b->side) (void)hipStreamDestroy(b->side);
+  if (b->own_copy) (void)hipStreamDestroy(b->own_copy);
+  for (hipEvent_t e : b->ev_piece) if (e) (void)hipEventDestroy(e);
   if (b->ev_begin) (void)hipEventDestroy(b->ev_begin);
   if (b->ev_zeroed) (void)hipEventDestroy(b->ev_zeroed);
   if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
@@ -219,6 +228,96 @@ struct phase_barrier {
 }  // namespace
 
 
+// The launch arguments of the synchronisation rounds (what a decode and a piece's early start share).
+static void fill_sync_args(const jga_huff_batch *b, hj_args &A) {
+  memset(&A, 0, sizeof(A));
+  A.images = (const hj_image *)(b->d_blob + b->off_images);
+  A.segs = (const hj_segment *)(b->d_blob + b->off_segs);
+  A.sub_seg = (const uint32_t *)(b->d_blob + b->off_subseg);
+  A.tables = (const hj_tables *)(b->d_blob + b->off_tables);
+  A.scan = b->d_blob + b->off_scan;
+  A.S = (uint64_t *)(b->d_blob + b->off_S);
+  A.last_in = b->d_last_in;
+  A.R = b->d_R;
+  A.B = b->d_B;
+  A.scan_part = b->d_part;
+  A.ran = b->d_ran;
+  A.errors = b->d_errors;
+  A.nimages = b->nimages;
+  A.sub_log2 = b->sub_log2;
+}
+// tuning knobs of the rounds, read once (thread-safe: several pipeline lanes decode at the same time)
+namespace {
+struct round_knobs {
+  int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1;
+  round_knobs() {
+    const char *e = jga_tune("JGA_HUFF_ITERS");     // "first,later,group": in-group iterations, rounds per host check
+    if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
+    if (e && it0 < 1) it0 = 1;
+    if (e && it1 < 1) it1 = 1;
+    if (group < 1) group = 1;
+    e = jga_tune("JGA_HUFF_SPARSE_FROM");            // first round run by the sparse kernel (default: by batch size)
+    if (e) sparse_from = atoi(e);
+    e = jga_tune("JGA_HUFF_LEAN");                   // 0: the dense kernel's stateless row reader (A/B knob)
+    if (e) lean = atoi(e) != 0;
+    e = jga_tune("JGA_HUFF_FLUSH");                  // write-pass batching
+    if (e) flush_lanes = atoi(e);
+    if (flush_lanes < 1) flush_lanes = 1;
+  }
+};
+const round_knobs &the_round_knobs() { static const round_knobs K; return K; }
+}  // namespace
+// In-group iterations per launch: three — the long, thin tail of the propagation is cheaper as
+// further launches than as resident groups — except for a small batch of frames cut into long
+// restart intervals with 64-byte subsequences (hj_choose_sub_log2), whose chains are twice as
+// many steps of half the length: six (one 1080p frame with an interval per MCU row 0.41 -> 0.39
+// ms, the 8K frame of BASELINE config 5 0.64 -> 0.60; intervals of a few subsequences: worse).
+static int auto_iters(const jga_huff_batch *b) {
+  const bool long_intervals = b->geom.restart_interval > 0 && b->sub_log2 == HJ_SUB_LOG2_MAX - 1
+   && b->total_seg > 0 && b->total_sub/b->total_seg >= 64u;
+  return long_intervals ? 6 : 3;
+}
+// Images [i0, i1) of the batch have landed (the caller has made `st` wait for their upload): their start
+// states and their first synchronisation round, exactly as a decode's first launches would run them.
+static int queue_piece_start(jga_huff_batch *b, int i0, int i1, uint32_t seg_base, uint32_t nsegs, uint32_t max_nsub,
+ hipStream_t st) {
+  const round_knobs &K = the_round_knobs();
+  hj_args A;
+  fill_sync_args(b, A);
+  A.images += i0;
+  A.tables += i0;
+  A.nimages = i1 - i0;
+  if (hj_launch_init_piece(&A, (int)seg_base, (int)nsegs, (int)max_nsub, st)) return jga_fail("huff: launch failed");
+  const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;
+  const int it0 = K.it0 > 0 ? K.it0 : auto_iters(b);
+  if (hj_launch_round(&A, (int)max_nsub, 0, it0, long_subs || K.sparse_from == 0 ? 1 : K.lean ? -1 : 0, st)) {
+    return jga_fail("huff: launch failed");
+  }
+  return EXIT_SUCCESS;
+}
+// Piece boundaries: `pieces` runs of consecutive images of about equal byte counts (piece k = images
+// [cut[k], cut[k+1])); fewer when the batch has fewer images.
+static std::vector<int> cut_pieces(const std::vector<uint32_t> &bytes, int pieces) {
+  const int n = (int)bytes.size();
+  uint64_t total = 0;
+  for (uint32_t v : bytes) total += v;
+  std::vector<int> cut{0};
+  uint64_t run = 0;
+  for (int i = 0; i < n; i++) {
+    run += bytes[(size_t)i];
+    const int k = (int)cut.size();                             // pieces closed so far + 1
+    if (k < pieces && i + 1 < n && run*(uint64_t)pieces >= total*(uint64_t)k) cut.push_back(i + 1);
+  }
+  cut.push_back(n);
+  return cut;
+}
+static int piece_events(jga_huff_batch *b, int np) {
+  for (int k = 0; k < np; k++) {
+    if (!b->ev_piece[k]) HOK(hipEventCreateWithFlags(&b->ev_piece[k], hipEventDisableTiming));
+  }
+  return EXIT_SUCCESS;
+}
+
 // prepare() with the unstuffing left to the device: the host parses the marker segments
 // (phase A, as below), copies the RAW entropy-coded bytes of every image into the pinned blob,
 // uploads, and queues unstuff_kernels.hip behind the copy.  Per-lane arrays are sized by what
@@ -250,6 +349,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->qtab.assign((size_t)n*192, 0);
   b->verdict.assign((size_t)n, 0);
   b->nimages = 0;
+  b->round0_queued = 0;
   auto heads = [&]() {
     for (int i = next_a.fetch_add(1); i < n; i = next_a.fetch_add(1)) {
       const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
@@ -328,6 +428,138 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   hj_image *images = (hj_image *)(b->h_blob + b->off_images);
   hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
   memcpy(b->h_blob + b->off_uimg, uimg.data(), sizeof(hj_unstuff_image)*(size_t)n);
+  b->nimages = n;
+  b->total_sub = (uint32_t)total_sub;
+  b->total_seg = (uint32_t)total_seg;
+  b->max_nsub = max_nsub;
+  b->max_chunks = (int)max_chunks;
+  b->geom = prep[0].geom;
+  b->max_seg_mcus = 0; b->max_segs_image = 0;
+  for (int i = 0; i < n; i++) {
+    const hj_unstuff_image &u = uimg[(size_t)i];
+    const uint32_t sm = u.ri && u.ri < u.total_mcus ? u.ri : u.total_mcus;
+    if (sm > b->max_seg_mcus) b->max_seg_mcus = sm;
+    if (u.nseg > b->max_segs_image) b->max_segs_image = u.nseg;
+  }
+  b->unstuffed_on_device = 1;
+  b->shadow.clear();
+  hipStream_t st = (hipStream_t)stream;
+  hipStream_t up = b->copy_stream ? b->copy_stream : st;       // (see jga_huff_set_copy_stream)
+  // ---- the upload in pieces (JGA_HUFF_OPT_PIECES): runs of consecutive images of about equal byte counts go up
+  // one after the other on a copy stream of their own, and behind each one's arrival its clean-up, its start
+  // states and its first synchronisation round are queued at once — the device works on the first images
+  // while the link still carries the last (a short job's tail after its upload is what it waits for)
+  if (b->pieces > 1 && n >= 2) {
+    std::vector<uint32_t> sizes_v((size_t)n);
+    for (int i = 0; i < n; i++) sizes_v[(size_t)i] = prep[i].avail;
+    const std::vector<int> cut = cut_pieces(sizes_v, b->pieces < 16 ? b->pieces : 16);
+    const int np = (int)cut.size() - 1;
+    if (piece_events(b, np) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (!b->copy_stream && !b->own_copy) HOK(hipStreamCreateWithFlags(&b->own_copy, hipStreamNonBlocking));
+    up = b->copy_stream ? b->copy_stream : b->own_copy;
+    HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));        // (the pieces' first rounds flag ran[0])
+    std::vector<int> piece_of((size_t)n);
+    std::vector<std::atomic<int>> left((size_t)np);
+    for (int k = 0; k < np; k++) {
+      left[(size_t)k].store(cut[(size_t)k + 1] - cut[(size_t)k]);
+      for (int i = cut[(size_t)k]; i < cut[(size_t)k + 1]; i++) piece_of[(size_t)i] = k;
+    }
+    for (int i = 0; i < n; i++) if (!in_place[(size_t)i]) b->host_bytes += (long long)prep[i].avail;
+    std::mutex qm;
+    bool gated = false;
+    int queue_rc = EXIT_SUCCESS;
+    hj_unstuff_args U0;
+    memset(&U0, 0, sizeof(U0));
+    U0.raw = b->d_blob + b->off_raw;
+    U0.clean = b->d_blob + b->off_scan;
+    U0.images = (hj_image *)(b->d_blob + b->off_images);
+    U0.segs = (hj_segment *)(b->d_blob + b->off_segs);
+    U0.uimg = (const hj_unstuff_image *)(b->d_blob + b->off_uimg);
+    U0.part = (uint32_t *)(b->d_blob + b->off_part);
+    U0.bnd = (uint32_t *)(b->d_blob + b->off_bnd);
+    U0.info = (hj_unstuff_info *)(b->d_blob + b->off_info);
+    U0.errors = (uint32_t *)(b->d_blob + b->off_perr);
+    U0.sub_log2 = b->sub_log2;
+    auto queue_piece = [&](int k) -> int {                        // (qm held)
+      const int i0 = cut[(size_t)k], i1 = cut[(size_t)k + 1], cnt = i1 - i0;
+      if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
+      gated = true;
+      for (int i = i0; i < i1; ) {
+        if (in_place[(size_t)i]) {
+          HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
+           prep[i].avail, hipMemcpyHostToDevice, up));
+          i++;
+          continue;
+        }
+        int j = i;
+        while (j + 1 < i1 && !in_place[(size_t)j + 1]) j++;
+        const size_t from = uimg[(size_t)i].raw_off, to = (size_t)uimg[(size_t)j].raw_off + uimg[(size_t)j].avail;
+        HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, to - from, hipMemcpyHostToDevice, up));
+        i = j + 1;
+      }
+      const size_t slices[3][2] = {{b->off_images + sizeof(hj_image)*(size_t)i0, sizeof(hj_image)*(size_t)cnt},
+       {b->off_tables + sizeof(hj_tables)*(size_t)i0, sizeof(hj_tables)*(size_t)cnt},
+       {b->off_uimg + sizeof(hj_unstuff_image)*(size_t)i0, sizeof(hj_unstuff_image)*(size_t)cnt}};
+      for (const auto &sl : slices) HOK(hipMemcpyAsync(b->d_blob + sl[0], b->h_blob + sl[0], sl[1], hipMemcpyHostToDevice, up));
+      HOK(hipEventRecord(b->ev_piece[k], up));
+      HOK(hipStreamWaitEvent(st, b->ev_piece[k], 0));
+      HOK(hipMemsetAsync(b->d_blob + b->off_info + sizeof(hj_unstuff_info)*(size_t)i0, 0xFF, sizeof(hj_unstuff_info)*(size_t)cnt, st));
+      HOK(hipMemsetAsync(b->d_blob + b->off_perr + 4*(size_t)i0, 0, 4*(size_t)cnt, st));
+      hj_unstuff_args U = U0;
+      U.images += i0; U.uimg += i0; U.info += i0; U.errors += i0;
+      U.nimages = cnt;
+      uint32_t chunks = 1, nsegs = 0, nsub_max = 1;
+      for (int i = i0; i < i1; i++) {
+        const hj_unstuff_image &u = uimg[(size_t)i];
+        if (u.nchunks > chunks) chunks = u.nchunks;
+        nsegs += u.nseg;
+        const uint32_t bound = ((u.avail + (1u << b->sub_log2) - 1) >> b->sub_log2) + u.nseg;
+        if (bound > nsub_max) nsub_max = bound;
+      }
+      if (hj_launch_unstuff(&U, (int)chunks, st)) return jga_fail("huff: launch failed");
+      return queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, st);
+    };
+    auto work = [&]() {
+      for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
+        hj_prepared &p = prep[i];
+        if (!in_place[(size_t)i]) memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + p.desc->scan_off, p.avail);
+        p.im.sub0 = sub0v[(size_t)i];
+        p.im.seg0 = seg0v[(size_t)i];
+        p.im.scan_off = uimg[(size_t)i].raw_off;
+        p.im.nseg = uimg[(size_t)i].nseg;
+        p.im.nsub = 0;                                         // (the device fills these two in)
+        p.im.scan_len = 0;
+        images[i] = p.im;
+        tables[i] = p.tabs;
+        memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
+        const int k = piece_of[(size_t)i];
+        if (left[(size_t)k].fetch_sub(1) == 1) {                // the piece's last image: off it goes
+          std::lock_guard<std::mutex> lk(qm);
+          if (queue_rc == EXIT_SUCCESS) queue_rc = queue_piece(k);
+        }
+      }
+    };
+    {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nt; t++) pool.emplace_back(work);
+      work();
+      for (auto &th : pool) th.join();
+    }
+    if (queue_rc != EXIT_SUCCESS) {
+      (void)hipStreamSynchronize(up);                          // (copies out of the callers' buffers may be in flight)
+      (void)hipStreamSynchronize(st);
+      b->nimages = 0;
+      return EXIT_FAILURE;
+    }
+    HOK(hipEventRecord(b->ev_up, up));                          // (jga_huff_wait_upload: the last piece is on its way)
+    b->round0_queued = 1;
+    if (trace) {
+      fprintf(stderr, "  prepare (device clean-up, %d of %d files in place, %d threads, %d pieces): %.2f ms\n", n_in_place, n, nt, np,
+       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
+    }
+    if (geom) *geom = b->geom;
+    return EXIT_SUCCESS;
+  }
   const bool zero_copy = n_in_place > 0;
   auto copies = [&]() {
     for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
@@ -350,23 +582,6 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     copies();
     for (auto &th : pool) th.join();
   }
-  b->nimages = n;
-  b->total_sub = (uint32_t)total_sub;
-  b->total_seg = (uint32_t)total_seg;
-  b->max_nsub = max_nsub;
-  b->max_chunks = (int)max_chunks;
-  b->geom = prep[0].geom;
-  b->max_seg_mcus = 0; b->max_segs_image = 0;
-  for (int i = 0; i < n; i++) {
-    const hj_unstuff_image &u = uimg[(size_t)i];
-    const uint32_t sm = u.ri && u.ri < u.total_mcus ? u.ri : u.total_mcus;
-    if (sm > b->max_seg_mcus) b->max_seg_mcus = sm;
-    if (u.nseg > b->max_segs_image) b->max_segs_image = u.nseg;
-  }
-  b->unstuffed_on_device = 1;
-  b->shadow.clear();
-  hipStream_t st = (hipStream_t)stream;
-  hipStream_t up = b->copy_stream ? b->copy_stream : st;       // (see jga_huff_set_copy_stream)
   int ncopies = 1;
   for (int i = 0; i < n; i++) {
     if (!in_place[(size_t)i]) b->host_bytes += (long long)prep[i].avail;
@@ -425,6 +640,186 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   return EXIT_SUCCESS;
 }
 
+// prepare() with the clean-up on the host and the upload in pieces (JGA_HUFF_OPT_PIECES).  Everything a piece's
+// kernels need must be known when ITS images are clean, not when all are — so the lanes' index spaces are laid
+// out from what the headers promise instead of from what the scans turn out to hold: image i owns
+// ceil(avail / subsequence) + nseg subsequence slots (a clean stream is never longer than the raw one) and
+// the ceil(MCUs / DRI) segments its frame must have (hj_prepare_scan fails a file that has any other number).
+// The thread that cleans a piece's last image queues that piece: scan bytes + descriptors on the copy stream,
+// and behind their arrival the start states and the first synchronisation round.
+static int prepare_pieces_host(jga_huff_batch *b, const unsigned char *const *jpegs, const int *sizes, int n,
+ jga_geom *geom, void *stream) {
+  const auto t_0 = std::chrono::steady_clock::now();
+  std::vector<hj_prepared> prep((size_t)n);
+  std::atomic<int> next_a(0), next_b(0), failed(0), irregular(0);
+  int nt = b->prepare_threads;
+  if (nt <= 0) {
+    nt = jga_cpu_budget();
+    if (nt > 64) nt = 64;
+  }
+  if (nt > n) nt = n;
+  b->unstuffed_on_device = 0;
+  b->host_bytes = 0;
+  b->round0_queued = 0;
+  b->qtab.assign((size_t)n*192, 0);
+  b->verdict.assign((size_t)n, 0);
+  b->nimages = 0;
+  auto heads = [&]() {
+    for (int i = next_a.fetch_add(1); i < n; i = next_a.fetch_add(1)) {
+      const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
+      if (rc != EXIT_SUCCESS) failed.fetch_add(1);
+      if (rc == HJ_PREPARE_IRREGULAR) irregular.fetch_add(1);
+      b->verdict[i] = (unsigned char)(rc == EXIT_SUCCESS ? 0 : rc == HJ_PREPARE_IRREGULAR ? 2 : 1);
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(heads);
+    heads();
+    for (auto &th : pool) th.join();
+  }
+  if (irregular.load()) {
+    return jga_fail("huff: %d image(s) of the batch have Huffman tables too irregular (or a frame too "
+     "large) for the GPU entropy stage", irregular.load());
+  }
+  if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
+  std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n), nsegv((size_t)n), avail((size_t)n);
+  size_t o = 0, total_sub = 0, total_seg = 0;
+  for (int i = 0; i < n; i++) {
+    if (i && !same_geometry(prep[i].geom, prep[0].geom)) return jga_fail("huff: images of one batch must share a geometry");
+    scan_off[(size_t)i] = (uint32_t)o;
+    avail[(size_t)i] = prep[i].avail;
+    o += align_up((size_t)prep[i].avail + 16, 16);
+  }
+  if ((long long)o > b->max_scan + 64ll*n || o >= ((size_t)1 << 32)) {
+    return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
+  }
+  b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o, prep[0].im.nslots, prep[0].geom.restart_interval);
+  b->max_seg_mcus = 0; b->max_segs_image = 0;
+  for (int i = 0; i < n; i++) {
+    const jga_geom &g = prep[i].geom;
+    const uint32_t mcus = (uint32_t)g.nhmb*(uint32_t)g.nvmb, ri = (uint32_t)g.restart_interval;
+    nsegv[(size_t)i] = ri ? (mcus + ri - 1)/ri : 1u;
+    sub0v[(size_t)i] = (uint32_t)total_sub;
+    seg0v[(size_t)i] = (uint32_t)total_seg;
+    total_sub += ((prep[i].avail + (1u << b->sub_log2) - 1) >> b->sub_log2) + nsegv[(size_t)i];
+    total_seg += nsegv[(size_t)i];
+    const uint32_t sm = ri && ri < mcus ? ri : mcus;
+    if (sm > b->max_seg_mcus) b->max_seg_mcus = sm;
+    if (nsegv[(size_t)i] > b->max_segs_image) b->max_segs_image = nsegv[(size_t)i];
+    prep[i].sub_log2 = b->sub_log2;
+  }
+  b->off_scan = 0;
+  b->scan_bytes = 0;                                           // (nothing written yet: nothing to carry over if the blob grows)
+  {
+    size_t q = align_up(o, 256);
+    b->off_images = q; q += align_up(sizeof(hj_image)*n, 256);
+    b->off_segs = q; q += align_up(sizeof(hj_segment)*total_seg, 256);
+    b->off_tables = q; q += align_up(sizeof(hj_tables)*n, 256);
+    b->upload_size = q;
+    b->off_subseg = q; q += align_up(4*total_sub, 256);
+    b->off_S = q; q += align_up(8*(total_sub + total_seg), 256);
+    b->blob_size = q;
+    const size_t need_sub = total_sub > total_seg ? total_sub : total_seg;
+    if ((need_sub > b->sub_cap || q > b->blob_cap) && !grow_batch(b, need_sub, q)) {
+      return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
+    }
+  }
+  b->scan_bytes = align_up(o, 256);
+  b->total_sub = (uint32_t)total_sub;
+  b->total_seg = (uint32_t)total_seg;
+  b->geom = prep[0].geom;
+  b->max_nsub = 0;
+  const std::vector<int> cut = cut_pieces(avail, b->pieces < 16 ? b->pieces : 16);
+  const int np = (int)cut.size() - 1;
+  if (piece_events(b, np) != EXIT_SUCCESS) return EXIT_FAILURE;
+  hipStream_t st = (hipStream_t)stream;
+  if (!b->copy_stream && !b->own_copy) HOK(hipStreamCreateWithFlags(&b->own_copy, hipStreamNonBlocking));
+  hipStream_t up = b->copy_stream ? b->copy_stream : b->own_copy;
+  HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));          // (the pieces' first rounds flag ran[0])
+  std::vector<int> piece_of((size_t)n);
+  std::vector<std::atomic<int>> left((size_t)np);
+  for (int k = 0; k < np; k++) {
+    left[(size_t)k].store(cut[(size_t)k + 1] - cut[(size_t)k]);
+    for (int i = cut[(size_t)k]; i < cut[(size_t)k + 1]; i++) piece_of[(size_t)i] = k;
+  }
+  hj_image *images = (hj_image *)(b->h_blob + b->off_images);
+  hj_segment *segs = (hj_segment *)(b->h_blob + b->off_segs);
+  hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
+  std::mutex qm;
+  bool gated = false;
+  int queue_rc = EXIT_SUCCESS;
+  uint32_t max_nsub = 0;                                        // (qm held)
+  auto queue_piece = [&](int k) -> int {                        // (qm held)
+    const int i0 = cut[(size_t)k], i1 = cut[(size_t)k + 1], cnt = i1 - i0;
+    if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
+    gated = true;
+    const size_t from = scan_off[(size_t)i0], to = (size_t)scan_off[(size_t)i1 - 1] + align_up((size_t)avail[(size_t)i1 - 1] + 16, 16);
+    uint32_t nsegs = 0, nsub_max = 1;
+    for (int i = i0; i < i1; i++) {
+      nsegs += nsegv[(size_t)i];
+      if (prep[i].im.nsub > nsub_max) nsub_max = prep[i].im.nsub;
+    }
+    if (nsub_max > max_nsub) max_nsub = nsub_max;
+    const size_t slices[4][2] = {{from, to - from},
+     {b->off_images + sizeof(hj_image)*(size_t)i0, sizeof(hj_image)*(size_t)cnt},
+     {b->off_segs + sizeof(hj_segment)*(size_t)seg0v[(size_t)i0], sizeof(hj_segment)*(size_t)nsegs},
+     {b->off_tables + sizeof(hj_tables)*(size_t)i0, sizeof(hj_tables)*(size_t)cnt}};
+    for (const auto &sl : slices) HOK(hipMemcpyAsync(b->d_blob + sl[0], b->h_blob + sl[0], sl[1], hipMemcpyHostToDevice, up));
+    HOK(hipEventRecord(b->ev_piece[k], up));
+    HOK(hipStreamWaitEvent(st, b->ev_piece[k], 0));
+    return queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, st);
+  };
+  auto work = [&]() {
+    for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
+      hj_prepared &p = prep[i];
+      bool ok = hj_prepare_scan(jpegs[i], sizes[i], &p, b->h_blob + scan_off[(size_t)i]) == EXIT_SUCCESS;
+      if (ok && p.segs.size() != (size_t)nsegv[(size_t)i]) ok = false;      // (cannot happen: a file that passes has its frame's intervals)
+      if (!ok) {
+        failed.fetch_add(1);
+        b->verdict[i] = 1;
+        continue;                                              // (its piece is never queued; the whole prepare fails)
+      }
+      p.im.sub0 = sub0v[(size_t)i];
+      p.im.seg0 = seg0v[(size_t)i];
+      p.im.scan_off = scan_off[(size_t)i];
+      images[i] = p.im;
+      tables[i] = p.tabs;
+      memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
+      for (size_t si = 0; si < p.segs.size(); si++) segs[seg0v[(size_t)i] + si] = p.segs[si];
+      const int k = piece_of[(size_t)i];
+      if (left[(size_t)k].fetch_sub(1) == 1) {                  // the piece's last image: off it goes
+        std::lock_guard<std::mutex> lk(qm);
+        if (queue_rc == EXIT_SUCCESS && !failed.load()) queue_rc = queue_piece(k);
+      }
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+  }
+  if (failed.load() || queue_rc != EXIT_SUCCESS) {
+    // pieces already queued read the blob and run their rounds: wait them out before anybody reuses either
+    (void)hipStreamSynchronize(up);
+    (void)hipStreamSynchronize(st);
+    if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
+    return EXIT_FAILURE;
+  }
+  for (int i = 0; i < n; i++) b->host_bytes += (long long)avail[(size_t)i];
+  b->nimages = n;
+  b->max_nsub = max_nsub;
+  HOK(hipEventRecord(b->ev_up, up));                            // (jga_huff_wait_upload: the last piece is on its way)
+  b->round0_queued = 1;
+  if (b->trace) {
+    fprintf(stderr, "  prepare (host clean-up, %d threads, %d pieces): %.2f ms\n", nt, np,
+     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
+  }
+  if (geom) *geom = b->geom;
+  return EXIT_SUCCESS;
+}
+
 // Parse + stage a batch.  All images must share one geometry (returned in *geom).
 // Host work per image (marker parse, table build, unstuffing straight into the pinned
 // upload buffer, lane start states) is independent and fanned out over a thread team.
@@ -432,8 +827,10 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
  const int *sizes, int n, jga_geom *geom, void *stream) {
   if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
   if (b->device_unstuff) return prepare_raw(b, jpegs, sizes, n, geom, stream);
+  if (b->pieces > 1 && n >= 2) return prepare_pieces_host(b, jpegs, sizes, n, geom, stream);
   b->unstuffed_on_device = 0;
   b->host_bytes = 0;
+  b->round0_queued = 0;
   const auto t_p0 = std::chrono::steady_clock::now();
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
@@ -765,16 +1162,7 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   double c0 = trace ? thread_cpu_ms() : 0.0, c_launch = 0.0, c_wait = 0.0;
   auto lap = [&](double &acc) { if (trace) { const double c = thread_cpu_ms(); acc += c - c0; c0 = c; } };
   hj_args A;
-  memset(&A, 0, sizeof(A));
-  A.images = (const hj_image *)(b->d_blob + b->off_images);
-  A.segs = (const hj_segment *)(b->d_blob + b->off_segs);
-  A.sub_seg = (const uint32_t *)(b->d_blob + b->off_subseg);
-  A.tables = (const hj_tables *)(b->d_blob + b->off_tables);
-  A.scan = b->d_blob + b->off_scan;
-  A.S = (uint64_t *)(b->d_blob + b->off_S);
-  A.last_in = b->d_last_in;
-  A.R = b->d_R;
-  A.B = b->d_B;
+  fill_sync_args(b, A);
   {
     // DC differences (scan order) and, unless the caller brings its own array, DC values (by
     // buffer slot); one stride for both: the caller's, or the slot count rounded up
@@ -800,50 +1188,31 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
     A.dc_val = d_dc ? (int16_t *)d_dc : b->d_dc + b->dc_cap;
     A.dc_stride = (long long)stride;
   }
-  A.scan_part = b->d_part;
-  A.ran = b->d_ran;
-  A.errors = b->d_errors;
   A.coef = (int16_t *)d_coef;
   A.coef_stride = coef_stride;
-  A.nimages = b->nimages;
+  int round = 0;
+  if (b->round0_queued) {
+    // prepare() has queued every piece's start states and first round behind that piece's upload: go on
+    // from round 1 (the images' verdicts — what the on-device clean-up found, or nothing — are set here)
+    b->round0_queued = 0;
+    if (b->unstuffed_on_device) {
+      HOK(hipMemcpyAsync(b->d_errors, b->d_blob + b->off_perr, 4*(size_t)b->nimages, hipMemcpyDeviceToDevice, st));
+    }
+    else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
+    round = 1;
+  }
   // reset: states back to the guesses, "never ran"
-  A.sub_log2 = b->sub_log2;
   // (on-device unstuffing has already had its say about every image: early end, RSTn counters)
-  if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub,
+  else if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub,
    b->unstuffed_on_device ? (const uint32_t *)(b->d_blob + b->off_perr) : NULL, st)) {
     return jga_fail("huff: launch failed");
   }
-  int round = 0;
+  const int first_round = round;
   b->last_assisted = 0;
   b->image_errors = 0;
-  // tuning knobs, read once (thread-safe: several pipeline lanes decode at the same time)
-  struct knobs {
-    int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1;
-    knobs() {
-      const char *e = jga_tune("JGA_HUFF_ITERS");     // "first,later,group": in-group iterations, rounds per host check
-      if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
-      if (e && it0 < 1) it0 = 1;
-      if (e && it1 < 1) it1 = 1;
-      if (group < 1) group = 1;
-      e = jga_tune("JGA_HUFF_SPARSE_FROM");            // first round run by the sparse kernel (default: by batch size)
-      if (e) sparse_from = atoi(e);
-      e = jga_tune("JGA_HUFF_LEAN");                   // 0: the dense kernel's stateless row reader (A/B knob)
-      if (e) lean = atoi(e) != 0;
-      e = jga_tune("JGA_HUFF_FLUSH");                  // write-pass batching
-      if (e) flush_lanes = atoi(e);
-      if (flush_lanes < 1) flush_lanes = 1;
-    }
-  };
-  static const knobs K;
+  const round_knobs &K = the_round_knobs();
   const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;     // no LDS rows that long: global-memory readers only
-  // In-group iterations per launch: three — the long, thin tail of the propagation is cheaper as
-  // further launches than as resident groups — except for a small batch of frames cut into long
-  // restart intervals with 64-byte subsequences (hj_choose_sub_log2), whose chains are twice as
-  // many steps of half the length: six (one 1080p frame with an interval per MCU row 0.41 -> 0.39
-  // ms, the 8K frame of BASELINE config 5 0.64 -> 0.60; intervals of a few subsequences: worse).
-  const bool long_intervals = b->geom.restart_interval > 0 && b->sub_log2 == HJ_SUB_LOG2_MAX - 1
-   && b->total_seg > 0 && b->total_sub/b->total_seg >= 64u;
-  const int it_auto = long_intervals ? 6 : 3;
+  const int it_auto = auto_iters(b);
   const int it0 = K.it0 > 0 ? K.it0 : it_auto, it1 = K.it1 > 0 ? K.it1 : it_auto, group = K.group,
             flush_lanes = K.flush_lanes, assist_after = b->assist_after > 0 ? b->assist_after : 12;
   // Which kernel runs the later rounds.  The sparse one (a wave per 256 subsequences, rows read from
@@ -912,14 +1281,15 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   bool speculated = b->speculate >= 0 && !b->assist_hint, tail_done = false;
   if (b->spec_rounds < GROUP) b->spec_rounds = GROUP;
   for (;;) {
-    const int burst = speculated && round == 0 ? b->spec_rounds : GROUP;
+    const bool first_burst = round == first_round;
+    const int burst = (speculated && first_burst ? b->spec_rounds : GROUP) - (first_burst ? first_round : 0);
     for (int k = 0; k < burst && round < HJ_MAX_ROUNDS; k++, round++) {
       if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, round >= sparse_from ? 1 : K.lean ? -1 : 0, st)) {
         return jga_fail("huff: launch failed");
       }
     }
     if (queue_side() != EXIT_SUCCESS) return EXIT_FAILURE;
-    const bool with_tail = speculated && round == burst;
+    const bool with_tail = speculated && first_burst;
     HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
     if (with_tail && queue_tail() != EXIT_SUCCESS) return EXIT_FAILURE;
     lap(c_launch);

@@ -37,6 +37,10 @@ extern "C" {
 /* fills sub_seg and the start states S (guesses) on the device */
 /* ... and clears ran[] and sets errors[] (to verdicts0[], device memory, or to 0) */
 int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream);
+/* the same for the `nsegs` segments from batch-global segment `seg_base` on, which belong to the images
+ * A->images[0 .. A->nimages) of a PIECE of the batch (A->images / A->tables shifted to the piece's first
+ * image); leaves ran[] and errors[] alone */
+int hj_launch_init_piece(const hj_args *A, int seg_base, int nsegs, int max_nsub, void *stream);
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);

@@ -1034,12 +1034,16 @@ __global__ __launch_bounds__(256) void hj_dc_apply(const hj_args A, int slots_pe
 // uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
 // (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
 // their first byte.  A workgroup takes 4096 subsequences of one segment.
-__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg, const uint32_t *verdicts0) {
-  const uint32_t gs = blockIdx.x;
+// `seg_base`: the launch covers the segments of a PIECE of the batch (A.images / A.nimages are the piece's
+// images; a batch whose upload arrives in pieces starts each piece's first round as it lands) — the
+// bookkeeping words are then none of its business (`book` = 0: the caller has cleared them).
+__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg, const uint32_t *verdicts0,
+ uint32_t seg_base, int book) {
+  const uint32_t gs = blockIdx.x + seg_base;
   // (also the decode's bookkeeping words, instead of two memsets in front of it: "did anything
   // run in round r", and every image's verdict — what the on-device scan clean-up already
   // found, or nothing)
-  if (gs == 0 && blockIdx.y == 0) {
+  if (book && blockIdx.x == 0 && blockIdx.y == 0) {
     for (int i = threadIdx.x; i < HJ_MAX_ROUNDS; i += 256) A.ran[i] = 0;
     for (int i = threadIdx.x; i < A.nimages; i += 256) A.errors[i] = verdicts0 ? verdicts0[i] : 0u;
   }
@@ -1066,7 +1070,12 @@ __global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t 
 }
 extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream) {
   hipLaunchKernelGGL(hj_init_states, dim3(total_segs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
-   const_cast<uint32_t *>(A->sub_seg), verdicts0);
+   const_cast<uint32_t *>(A->sub_seg), verdicts0, 0u, 1);
+  return (int)hipGetLastError();
+}
+extern "C" int hj_launch_init_piece(const hj_args *A, int seg_base, int nsegs, int max_nsub, void *stream) {
+  hipLaunchKernelGGL(hj_init_states, dim3(nsegs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
+   const_cast<uint32_t *>(A->sub_seg), (const uint32_t *)nullptr, (uint32_t)seg_base, 0);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,

@@ -39,7 +39,7 @@ namespace {
 // tuning build, the JGA_PIPE_* variables of rounds 2-3 have had their say): one helper for
 // jga_pipeline_create and jga_pipeline_plan_cfg, so that a plan is the plan a run makes.
 struct sched_knobs {
-  int lanes, batch, link_slots, dev_slots, groups_per_lane, min_group_eq, offload_at, copy_streams;
+  int lanes, batch, link_slots, dev_slots, groups_per_lane, min_group_eq, offload_at, copy_streams, short_job;
   bool ramp_first, blocking, trace;
 };
 sched_knobs resolve_knobs(const jga_pipeline_config &c) {
@@ -55,6 +55,7 @@ sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   k.offload_at = c.offload_at > 0 ? c.offload_at : 8;
   k.copy_streams = c.copy_streams > 0 ? (c.copy_streams > 8 ? 8 : c.copy_streams) : 0;
   k.trace = c.trace != 0;
+  k.short_job = c.short_job == 2 ? 2 : 1;                       // (0 = auto: cut like any other job, for now)
   if (const char *e = jga_tune("JGA_PIPE_DEVICE_SLOTS")) k.dev_slots = atoi(e) > 0 ? atoi(e) : 1;
   if (const char *e = jga_tune("JGA_PIPE_SPIN")) k.blocking = atoi(e) == 0;
   if (const char *e = jga_tune("JGA_PIPE_COPY_STREAMS")) k.copy_streams = atoi(e) > 8 ? 8 : atoi(e) > 0 ? atoi(e) : 0;
@@ -263,6 +264,8 @@ struct jga_pipeline {
   int run_done = 0;
   bool quit = false;
   std::vector<std::vector<jga_job *>> *run_groups = nullptr;
+  std::vector<int> *run_pieces = nullptr;         // per group: pieces of its upload (short_job = 2)
+  int short_job = 1;
   std::atomic<int> *run_next = nullptr;
   int run_threads = 1;
 };
@@ -480,9 +483,11 @@ struct link_turn {
   jga_pipeline *pl;
   int held = 0;
   explicit link_turn(jga_pipeline *p) : pl(p) {}
+  bool whole = false;                  // an upload in pieces (a short job's batch): the link to itself, so that the
+                                       // batches' uploads follow each other instead of sharing it
   static void take_hook(void *arg, long long bytes, int copies) {
     link_turn *t = static_cast<link_turn *>(arg);
-    t->take(copies == 1 && bytes >= (64ll << 20) ? t->pl->link_slots : 1);
+    t->take(t->whole || (copies == 1 && bytes >= (64ll << 20)) ? t->pl->link_slots : 1);
   }
   void take(int units) {
     if (pl->link_slots <= 0) return;
@@ -507,7 +512,7 @@ struct link_turn {
 enum { GROUP_REJECTED = 2 };
 uint64_t geometry_key(const unsigned char *p, int size);
 int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads, bool shared = true,
- bool reserve_full = false) {
+ bool reserve_full = false, int pieces = 0) {
   const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
   const bool copy_back = pl->cfg.copy_back != 0;
   std::vector<const unsigned char *> ptrs((size_t)m);
@@ -583,6 +588,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
       }
     }
     jga_huff_set_device_unstuff(l.hb, on_device);
+    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_PIECES, pieces);
     jga_huff_set_inputs_pinned(l.hb, 0);
     jga_huff_set_input_flags(l.hb, in_place.data(), m);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
@@ -595,6 +601,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   bool host_entropy = false, damaged = false;
   jpeg_header hdr;
   link_turn link(pl);
+  link.whole = pieces > 1;
   jga_huff_set_upload_gate(l.hb, pl->link_slots > 0 ? &link_turn::take_hook : nullptr, &link);
   const int prc = jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream);
   jga_huff_set_upload_gate(l.hb, nullptr, nullptr);
@@ -781,8 +788,16 @@ uint64_t geometry_key(const unsigned char *p, int size) {
 // files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
 // entropy stage and block decode of different groups overlap: about groups_per_lane groups
 // per lane, none below min_group_eq frame equivalents.
-struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; };
-void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups) {
+// short_job = 2 (jga_pipeline_config): a geometry whose jobs would all fit ONE full group is not cut into
+// small groups — eight 16-file decodes keep the device busy 3.2 ms where one 128-file batch takes 1.8, each
+// paying the launches' latencies anew — but into two batches (the first 60 % of the files, then the rest:
+// the second one's tail after the last byte has landed is what the run waits for, so it is the shorter)
+// whose uploads arrive in pieces of ~12 MB: a piece's scan clean-up, start states and first synchronisation
+// round start when ITS bytes are there (jga_huff_set_option JGA_HUFF_OPT_PIECES).  `pieces[k]` = pieces
+// of group k's upload (0: one upload).
+struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; int short_job; };
+void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups,
+ std::vector<int> *pieces = nullptr) {
   const int nl = pp.lanes, batch = pp.batch;
   std::unordered_map<uint64_t, long long> pixels;            // geometry -> pixels of all its jobs
   std::vector<uint64_t> keys((size_t)n);
@@ -821,7 +836,25 @@ void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<
       cap = (cap*(made + 1) + nl - 1)/nl;
       if (cap < 1) cap = 1;
     }
+    const bool short_mode = pp.short_job == 2 && px > 0 && pixels[key] <= (long long)batch*frame;
+    if (short_mode) {
+      const long long count = pixels[key]/px;
+      cap = pixels[key] >= 8*frame && count >= 4 ? (made == 0 ? (count*3 + 4)/5 : count) : count;
+    }
     if ((long long)groups[it->second].size() >= cap) { open.erase(it); made++; }
+  }
+  if (pieces) {
+    pieces->assign(groups.size(), 0);
+    for (size_t k = 0; k < groups.size(); k++) {
+      const uint64_t key = groups[k].empty() ? 0 : keys[(size_t)groups[k][0]];
+      const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
+      if (pp.short_job != 2 || !key || pixels[key] > (long long)batch*frame) continue;
+      long long bytes = 0;
+      for (int i : groups[k]) bytes += jobs[i].size;
+      const long long p = (bytes + (6ll << 20))/(12ll << 20);
+      (*pieces)[k] = (int)(p < 2 ? (bytes >= (8ll << 20) ? 2 : 0) : p > 8 ? 8 : p);
+      (void)px;
+    }
   }
 }
 
@@ -833,7 +866,8 @@ void lane_groups(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>>
     if (gi >= (int)groups->size()) break;
     std::vector<jga_job *> &grp = (*groups)[gi];
     const int m = (int)grp.size();
-    const int rc = lane_group(pl, *l, grp.data(), m, threads, groups->size() > 1, long_run);
+    const int rc = lane_group(pl, *l, grp.data(), m, threads, groups->size() > 1, long_run,
+     pl->run_pieces && (size_t)gi < pl->run_pieces->size() ? (*pl->run_pieces)[(size_t)gi] : 0);
     if (rc == EXIT_SUCCESS || m == 1) continue;
     // One member with an unparsable header, or with Huffman tables outside the device lookup
     // format, must not cost the other 47 their batch: the members prepare() found usable go
@@ -932,6 +966,7 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->min_group_eq = K.min_group_eq;
     pl->ramp_first = K.ramp_first;
     pl->link_slots = pl->link_free = K.link_slots;
+    pl->short_job = K.short_job;
     if (pl->cfg.input_cache_mb > 0) {
       pl->inputs.cap = (size_t)pl->cfg.input_cache_mb << 20;
       pl->inputs.sight = pl->cfg.input_cache_sight > 0 ? pl->cfg.input_cache_sight : 1;
@@ -977,9 +1012,10 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     int per = pl->cfg.nthreads/nl;
     if (per < 1) per = 1;
     std::vector<std::vector<jga_job *>> groups;
+    std::vector<int> pieces;
     {
       std::vector<std::vector<int>> plan;
-      plan_groups({nl, batch, pl->groups_per_lane, pl->min_group_eq, pl->ramp_first != 0}, jobs, n, plan);
+      plan_groups({nl, batch, pl->groups_per_lane, pl->min_group_eq, pl->ramp_first != 0, pl->short_job}, jobs, n, plan, &pieces);
       groups.resize(plan.size());
       for (size_t k = 0; k < plan.size(); k++) {
         groups[k].reserve(plan[k].size());
@@ -989,7 +1025,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), pl->since_run_start_ms());
     {
       std::lock_guard<std::mutex> lk(pl->run_mutex);
-      pl->run_groups = &groups; pl->run_next = &next; pl->run_threads = per;
+      pl->run_groups = &groups; pl->run_next = &next; pl->run_threads = per; pl->run_pieces = &pieces;
       pl->run_done = 0;
       pl->run_gen++;
     }
@@ -1018,7 +1054,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
 JGA_EXPORT int jga_pipeline_plan_cfg(const jga_pipeline_config *cfg, const jga_job *jobs, int n, int *group_of) {
   std::vector<std::vector<int>> plan;
   const sched_knobs K = resolve_knobs(*cfg);     // (what jga_pipeline_create makes of the same configuration)
-  plan_groups({K.lanes, K.batch, K.groups_per_lane, K.min_group_eq, K.ramp_first}, jobs, n, plan);
+  plan_groups({K.lanes, K.batch, K.groups_per_lane, K.min_group_eq, K.ramp_first, K.short_job}, jobs, n, plan);
   for (size_t k = 0; k < plan.size(); k++) for (int i : plan[k]) group_of[i] = (int)k;
   return (int)plan.size();
 }

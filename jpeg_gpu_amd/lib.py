@@ -486,6 +486,9 @@ class HuffBatch:
         self.n = 0
         self.geom = None
 
+    def set_option(self, option, value):
+        check(L.jga_huff_set_option(self.ptr, int(option), int(value)))
+
     def prepare(self, jpegs, stream=None):
         n = len(jpegs)
         self._keep = [bytes(j) for j in jpegs]
