@@ -337,6 +337,10 @@ int jga_time_idct_batch(const jga_geom *g, int nimages, const short *d_coef,
  unsigned char *d_out, long long out_stride, int rgb, int reps, void *stream,
  float *ms);
 
+/* `reps` device-to-device copies (hipMemcpyDtoDAsync) of `bytes`, HIP events on `stream` around them: the copy
+ * ceiling the bench prints beside the kernels' rates; average milliseconds per copy in *ms. */
+int jga_time_device_copy(void *d_dst, const void *d_src, size_t bytes, int reps, void *stream, float *ms);
+
 /* --- pipelined batch decoder (build addition; SURVEY.md §8b "batch/async
  *     entry"): N host entropy threads -> pinned ring -> H2D on a copy stream
  *     -> fused kernel on a compute stream (-> optional D2H).  One pipeline
@@ -549,9 +553,12 @@ typedef struct jga_plugin_config {
   int struct_size;             /* sizeof(jga_plugin_config) of the caller's header */
   int register_buffers;        /* 1: the caller keeps its image and file buffers alive and in place for as long
                                 * as a decoder context lives (the reference's main loop does,
-                                * src/jpeg_gpu.c:612-613, 1231-1237): they are registered with the device, pixels
-                                * are copied straight into them, big files DMA'd where they lie.  0 (default):
-                                * staged copies, safe for any caller */
+                                * src/jpeg_gpu.c:612-613, 1231-1237): they are registered with the device once,
+                                * pixels are copied straight into them, big files DMA'd where they lie.
+                                * 0 (default, safe for any caller): the same, but each buffer is registered for the
+                                * length of ONE decode_image call and let go before it returns (hipHostRegister
+                                * takes ~50 us per buffer, a host pass over a 4K frame's pixels ~1 ms).
+                                * -1: never — copies staged through the context's pinned buffers */
   int host_entropy;            /* 1: Huffman decoding on the host (csrc/entropy.c) for YUV / RGB too */
   int copy_team;               /* staged copy back of frames of 12 MB and more: 0 = two helper threads move the
                                 * pieces (default), -1 = the calling thread alone */

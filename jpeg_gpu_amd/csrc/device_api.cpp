@@ -326,6 +326,25 @@ JGA_EXPORT int jga_time_idct_batch(const jga_geom *g, int nimages,
   return rc;
 }
 
+// The copy ceiling beside the kernels' rates ("state the measured copy ceiling next to the spec"):
+// `reps` hipMemcpyDtoDAsync of `bytes` between two device buffers, HIP events on `stream` around them.
+JGA_EXPORT int jga_time_device_copy(void *d_dst, const void *d_src, size_t bytes, int reps, void *stream, float *ms) {
+  hipEvent_t e0, e1;
+  float t = 0.0f;
+  if (reps < 1) reps = 1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
+  for (int i = 0; i < reps; i++) HIP_TRY(hipMemcpyDtoDAsync(d_dst, const_cast<void *>(d_src), bytes, (hipStream_t)stream));
+  HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (ms) *ms = t/(float)reps;
+  return EXIT_SUCCESS;
+}
+
 // ---- thin device-memory helpers -------------------------------------------
 
 JGA_EXPORT void *jga_device_malloc(size_t bytes) {

@@ -334,13 +334,13 @@ int main(int argc, char *argv[]) {
   int c;
   memset(&info, 0, sizeof(info));
   /* this program keeps one image for the life of each decoder context, so the plugin may
-   * register its buffers and copy results straight into them (JPEG_GPU_HIP_REGISTER=0: as a caller
-   * that makes no such promise) */
+   * register its buffers once and copy results straight into them (JPEG_GPU_HIP_REGISTER=0: as a caller
+   * that makes no such promise — buffers registered per call; -1: staged copies only) */
   {
     jga_plugin_config pc;
     const char *e = getenv("JPEG_GPU_HIP_REGISTER"), *h = getenv("JPEG_GPU_HIP_ENTROPY");
     jga_plugin_config_init(&pc);
-    pc.register_buffers = !(e && *e == '0');
+    pc.register_buffers = e ? atoi(e) : 1;
     pc.host_entropy = h && strcmp(h, "host") == 0;           /* Huffman decoding on the host for -o yuv / rgb too */
     if (jga_plugin_configure(&pc) != EXIT_SUCCESS) return EXIT_FAILURE;
   }

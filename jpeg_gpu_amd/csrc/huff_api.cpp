@@ -74,10 +74,15 @@ struct jga_huff_batch {
   int assist_after, speculate, trace, pieces;   // jga_huff_set_option (0: defaults)
   // a batch whose upload arrives in pieces (JGA_HUFF_OPT_PIECES): prepare() has queued the start states and the
   // first synchronisation round of every piece behind that piece's upload; the next decode goes on from round 1
-  int round0_queued;
-  hipStream_t own_copy;        // the pieces' uploads, when the caller gave no copy stream (kernels and copies of one
-                               // stream run in order: the next piece's copy would wait for this piece's round)
-  hipEvent_t ev_piece[16];
+  int round0_queued;           // (how many rounds: the decode goes on from that one)
+  int npieces;                 // pieces of the last prepare()'s upload (0: one upload, ev_up)
+  // pieces' uploads alternate between two copy streams of the batch's own (a 0.8 MB file DMA'd where it lies moves
+  // at 32 GB/s on one stream, two streams fill the link; and kernels and copies of ONE stream run in order: the
+  // next piece's copy would wait for this piece's rounds), their kernels go round three streams (a piece's rounds
+  // are a chain of short launches: three chains side by side keep up with the link), the caller's stream waits for
+  // all of them
+  hipStream_t own_copy[2], piece_st[3];
+  hipEvent_t ev_piece[16], ev_sync[16], ev_pieces_begin;
   size_t off_raw, off_uimg, off_part, off_bnd, off_info, off_perr;
   int max_chunks;
   jga_geom geom;
@@ -166,8 +171,11 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_ran) (void)hipFree(b->d_ran);
   if (b->d_errors) (void)hipFree(b->d_errors);
   if (b->side) (void)hipStreamDestroy(b->side);
-  if (b->own_copy) (void)hipStreamDestroy(b->own_copy);
+  for (hipStream_t s_ : b->own_copy) if (s_) (void)hipStreamDestroy(s_);
+  for (hipStream_t s_ : b->piece_st) if (s_) (void)hipStreamDestroy(s_);
   for (hipEvent_t e : b->ev_piece) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : b->ev_sync) if (e) (void)hipEventDestroy(e);
+  if (b->ev_pieces_begin) (void)hipEventDestroy(b->ev_pieces_begin);
   if (b->ev_begin) (void)hipEventDestroy(b->ev_begin);
   if (b->ev_zeroed) (void)hipEventDestroy(b->ev_zeroed);
   if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
@@ -279,6 +287,13 @@ static int auto_iters(const jga_huff_batch *b) {
 }
 // Images [i0, i1) of the batch have landed (the caller has made `st` wait for their upload): their start
 // states and their first synchronisation round, exactly as a decode's first launches would run them.
+static int piece_events(jga_huff_batch *b, int np) {
+  for (int k = 0; k < np; k++) {
+    if (!b->ev_piece[k]) HOK(hipEventCreateWithFlags(&b->ev_piece[k], hipEventDisableTiming));
+  }
+  return EXIT_SUCCESS;
+}
+#define HJ_PIECE_ROUNDS 6
 static int queue_piece_start(jga_huff_batch *b, int i0, int i1, uint32_t seg_base, uint32_t nsegs, uint32_t max_nsub,
  hipStream_t st) {
   const round_knobs &K = the_round_knobs();
@@ -289,9 +304,37 @@ static int queue_piece_start(jga_huff_batch *b, int i0, int i1, uint32_t seg_bas
   A.nimages = i1 - i0;
   if (hj_launch_init_piece(&A, (int)seg_base, (int)nsegs, (int)max_nsub, st)) return jga_fail("huff: launch failed");
   const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;
-  const int it0 = K.it0 > 0 ? K.it0 : auto_iters(b);
-  if (hj_launch_round(&A, (int)max_nsub, 0, it0, long_subs || K.sparse_from == 0 ? 1 : K.lean ? -1 : 0, st)) {
-    return jga_fail("huff: launch failed");
+  const int it0 = K.it0 > 0 ? K.it0 : auto_iters(b), it1 = K.it1 > 0 ? K.it1 : auto_iters(b);
+  // the piece's whole first burst of rounds (HJ_PIECE_ROUNDS: what a photograph settles in): its chain of
+  // synchronisation steps is over by the time the last piece lands, whose own chain is what is left
+  for (int r = 0; r < HJ_PIECE_ROUNDS; r++) {
+    const int kind = long_subs || (K.sparse_from >= 0 ? r >= K.sparse_from : r >= 1) ? 1 : K.lean ? -1 : 0;
+    if (hj_launch_round(&A, (int)max_nsub, r, r ? it1 : it0, kind, st)) return jga_fail("huff: launch failed");
+  }
+  return EXIT_SUCCESS;
+}
+// Streams and events of piece k: its upload goes on *up, its kernels on *ps (which has been made to wait for
+// whatever the caller had queued on `st` before prepare()).
+static int piece_streams(jga_huff_batch *b, int k, hipStream_t *up, hipStream_t *ps) {
+  hipStream_t &c = b->own_copy[k & 1], &p = b->piece_st[k % 3];
+  if (!c) HOK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+  if (!p) HOK(hipStreamCreateWithFlags(&p, hipStreamNonBlocking));
+  *up = b->copy_stream ? b->copy_stream : c;
+  *ps = p;
+  return EXIT_SUCCESS;
+}
+static int pieces_begin(jga_huff_batch *b, int np, hipStream_t st) {
+  if (piece_events(b, np) != EXIT_SUCCESS) return EXIT_FAILURE;
+  for (int k = 0; k < np; k++) {
+    if (!b->ev_sync[k]) HOK(hipEventCreateWithFlags(&b->ev_sync[k], hipEventDisableTiming));
+  }
+  if (!b->ev_pieces_begin) HOK(hipEventCreateWithFlags(&b->ev_pieces_begin, hipEventDisableTiming));
+  HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));        // (the pieces' rounds flag ran[])
+  HOK(hipEventRecord(b->ev_pieces_begin, st));
+  for (int q = 0; q < 3 && q < np; q++) {
+    hipStream_t up, ps;
+    if (piece_streams(b, q, &up, &ps) != EXIT_SUCCESS) return EXIT_FAILURE;
+    HOK(hipStreamWaitEvent(ps, b->ev_pieces_begin, 0));
   }
   return EXIT_SUCCESS;
 }
@@ -310,12 +353,6 @@ static std::vector<int> cut_pieces(const std::vector<uint32_t> &bytes, int piece
   }
   cut.push_back(n);
   return cut;
-}
-static int piece_events(jga_huff_batch *b, int np) {
-  for (int k = 0; k < np; k++) {
-    if (!b->ev_piece[k]) HOK(hipEventCreateWithFlags(&b->ev_piece[k], hipEventDisableTiming));
-  }
-  return EXIT_SUCCESS;
 }
 
 // prepare() with the unstuffing left to the device: the host parses the marker segments
@@ -342,14 +379,17 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   }
   int n_in_place = 0;
   for (int i = 0; i < n; i++) n_in_place += in_place[(size_t)i];
-  // files that stay where they are leave ~10 us of host work per image (marker parse, tables):
-  // starting and joining a thread team costs more than it saves until the batch is large
-  if (n_in_place == n && n <= 128) nt = 1;
+  // files that stay where they are leave 10-30 us of host work per image (marker parse, tables):
+  // starting and joining a thread team costs more than it saves until the batch is large — except
+  // when the upload goes in pieces, where the first piece waits for ALL the heads (a 77-file batch:
+  // 2.3 ms on one thread, round 4's first trace of a short job)
+  if (n_in_place == n && n <= 128) nt = b->pieces > 1 && n > 16 ? (nt < (n + 7)/8 ? nt : (n + 7)/8) : 1;
   b->host_bytes = 0;
   b->qtab.assign((size_t)n*192, 0);
   b->verdict.assign((size_t)n, 0);
   b->nimages = 0;
   b->round0_queued = 0;
+  b->npieces = 0;
   auto heads = [&]() {
     for (int i = next_a.fetch_add(1); i < n; i = next_a.fetch_add(1)) {
       const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
@@ -454,10 +494,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     for (int i = 0; i < n; i++) sizes_v[(size_t)i] = prep[i].avail;
     const std::vector<int> cut = cut_pieces(sizes_v, b->pieces < 16 ? b->pieces : 16);
     const int np = (int)cut.size() - 1;
-    if (piece_events(b, np) != EXIT_SUCCESS) return EXIT_FAILURE;
-    if (!b->copy_stream && !b->own_copy) HOK(hipStreamCreateWithFlags(&b->own_copy, hipStreamNonBlocking));
-    up = b->copy_stream ? b->copy_stream : b->own_copy;
-    HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));        // (the pieces' first rounds flag ran[0])
+    if (pieces_begin(b, np, st) != EXIT_SUCCESS) return EXIT_FAILURE;
     std::vector<int> piece_of((size_t)n);
     std::vector<std::atomic<int>> left((size_t)np);
     for (int k = 0; k < np; k++) {
@@ -467,7 +504,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     for (int i = 0; i < n; i++) if (!in_place[(size_t)i]) b->host_bytes += (long long)prep[i].avail;
     std::mutex qm;
     bool gated = false;
-    int queue_rc = EXIT_SUCCESS;
+    std::atomic<int> queue_failed(0);
     hj_unstuff_args U0;
     memset(&U0, 0, sizeof(U0));
     U0.raw = b->d_blob + b->off_raw;
@@ -480,10 +517,10 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     U0.info = (hj_unstuff_info *)(b->d_blob + b->off_info);
     U0.errors = (uint32_t *)(b->d_blob + b->off_perr);
     U0.sub_log2 = b->sub_log2;
-    auto queue_piece = [&](int k) -> int {                        // (qm held)
+    auto queue_piece = [&](int k) -> int {
       const int i0 = cut[(size_t)k], i1 = cut[(size_t)k + 1], cnt = i1 - i0;
-      if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
-      gated = true;
+      hipStream_t up, ps;
+      if (piece_streams(b, k, &up, &ps) != EXIT_SUCCESS) return EXIT_FAILURE;
       for (int i = i0; i < i1; ) {
         if (in_place[(size_t)i]) {
           HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
@@ -502,9 +539,9 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
        {b->off_uimg + sizeof(hj_unstuff_image)*(size_t)i0, sizeof(hj_unstuff_image)*(size_t)cnt}};
       for (const auto &sl : slices) HOK(hipMemcpyAsync(b->d_blob + sl[0], b->h_blob + sl[0], sl[1], hipMemcpyHostToDevice, up));
       HOK(hipEventRecord(b->ev_piece[k], up));
-      HOK(hipStreamWaitEvent(st, b->ev_piece[k], 0));
-      HOK(hipMemsetAsync(b->d_blob + b->off_info + sizeof(hj_unstuff_info)*(size_t)i0, 0xFF, sizeof(hj_unstuff_info)*(size_t)cnt, st));
-      HOK(hipMemsetAsync(b->d_blob + b->off_perr + 4*(size_t)i0, 0, 4*(size_t)cnt, st));
+      HOK(hipStreamWaitEvent(ps, b->ev_piece[k], 0));
+      HOK(hipMemsetAsync(b->d_blob + b->off_info + sizeof(hj_unstuff_info)*(size_t)i0, 0xFF, sizeof(hj_unstuff_info)*(size_t)cnt, ps));
+      HOK(hipMemsetAsync(b->d_blob + b->off_perr + 4*(size_t)i0, 0, 4*(size_t)cnt, ps));
       hj_unstuff_args U = U0;
       U.images += i0; U.uimg += i0; U.info += i0; U.errors += i0;
       U.nimages = cnt;
@@ -516,8 +553,11 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
         const uint32_t bound = ((u.avail + (1u << b->sub_log2) - 1) >> b->sub_log2) + u.nseg;
         if (bound > nsub_max) nsub_max = bound;
       }
-      if (hj_launch_unstuff(&U, (int)chunks, st)) return jga_fail("huff: launch failed");
-      return queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, st);
+      if (hj_launch_unstuff(&U, (int)chunks, ps)) return jga_fail("huff: launch failed");
+      if (queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, ps) != EXIT_SUCCESS) return EXIT_FAILURE;
+      HOK(hipEventRecord(b->ev_sync[k], ps));
+      HOK(hipStreamWaitEvent(st, b->ev_sync[k], 0));
+      return EXIT_SUCCESS;
     };
     auto work = [&]() {
       for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
@@ -534,8 +574,14 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
         memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
         const int k = piece_of[(size_t)i];
         if (left[(size_t)k].fetch_sub(1) == 1) {                // the piece's last image: off it goes
-          std::lock_guard<std::mutex> lk(qm);
-          if (queue_rc == EXIT_SUCCESS) queue_rc = queue_piece(k);
+          {
+            // (only the turn on the link is taken one at a time: the ~35 API calls of a piece cost their thread
+            // 0.2 ms, and eight pieces queued one after the other kept the last one's upload waiting 1.5 ms)
+            std::lock_guard<std::mutex> lk(qm);
+            if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
+            gated = true;
+          }
+          if (queue_piece(k) != EXIT_SUCCESS) queue_failed.store(1);
         }
       }
     };
@@ -545,14 +591,16 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
       work();
       for (auto &th : pool) th.join();
     }
-    if (queue_rc != EXIT_SUCCESS) {
-      (void)hipStreamSynchronize(up);                          // (copies out of the callers' buffers may be in flight)
+    if (queue_failed.load()) {
+      for (hipStream_t s_ : b->own_copy) if (s_) (void)hipStreamSynchronize(s_);   // (copies out of the callers' buffers may be in flight)
+      if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+      for (hipStream_t s_ : b->piece_st) if (s_) (void)hipStreamSynchronize(s_);
       (void)hipStreamSynchronize(st);
       b->nimages = 0;
       return EXIT_FAILURE;
     }
-    HOK(hipEventRecord(b->ev_up, up));                          // (jga_huff_wait_upload: the last piece is on its way)
-    b->round0_queued = 1;
+    b->round0_queued = HJ_PIECE_ROUNDS;
+    b->npieces = np;
     if (trace) {
       fprintf(stderr, "  prepare (device clean-up, %d of %d files in place, %d threads, %d pieces): %.2f ms\n", n_in_place, n, nt, np,
        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
@@ -732,11 +780,8 @@ static int prepare_pieces_host(jga_huff_batch *b, const unsigned char *const *jp
   b->max_nsub = 0;
   const std::vector<int> cut = cut_pieces(avail, b->pieces < 16 ? b->pieces : 16);
   const int np = (int)cut.size() - 1;
-  if (piece_events(b, np) != EXIT_SUCCESS) return EXIT_FAILURE;
   hipStream_t st = (hipStream_t)stream;
-  if (!b->copy_stream && !b->own_copy) HOK(hipStreamCreateWithFlags(&b->own_copy, hipStreamNonBlocking));
-  hipStream_t up = b->copy_stream ? b->copy_stream : b->own_copy;
-  HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));          // (the pieces' first rounds flag ran[0])
+  if (pieces_begin(b, np, st) != EXIT_SUCCESS) return EXIT_FAILURE;
   std::vector<int> piece_of((size_t)n);
   std::vector<std::atomic<int>> left((size_t)np);
   for (int k = 0; k < np; k++) {
@@ -748,27 +793,29 @@ static int prepare_pieces_host(jga_huff_batch *b, const unsigned char *const *jp
   hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
   std::mutex qm;
   bool gated = false;
-  int queue_rc = EXIT_SUCCESS;
+  std::atomic<int> queue_failed(0);
   uint32_t max_nsub = 0;                                        // (qm held)
-  auto queue_piece = [&](int k) -> int {                        // (qm held)
+  auto queue_piece = [&](int k) -> int {
     const int i0 = cut[(size_t)k], i1 = cut[(size_t)k + 1], cnt = i1 - i0;
-    if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
-    gated = true;
     const size_t from = scan_off[(size_t)i0], to = (size_t)scan_off[(size_t)i1 - 1] + align_up((size_t)avail[(size_t)i1 - 1] + 16, 16);
     uint32_t nsegs = 0, nsub_max = 1;
     for (int i = i0; i < i1; i++) {
       nsegs += nsegv[(size_t)i];
       if (prep[i].im.nsub > nsub_max) nsub_max = prep[i].im.nsub;
     }
-    if (nsub_max > max_nsub) max_nsub = nsub_max;
     const size_t slices[4][2] = {{from, to - from},
      {b->off_images + sizeof(hj_image)*(size_t)i0, sizeof(hj_image)*(size_t)cnt},
      {b->off_segs + sizeof(hj_segment)*(size_t)seg0v[(size_t)i0], sizeof(hj_segment)*(size_t)nsegs},
      {b->off_tables + sizeof(hj_tables)*(size_t)i0, sizeof(hj_tables)*(size_t)cnt}};
+    hipStream_t up, ps;
+    if (piece_streams(b, k, &up, &ps) != EXIT_SUCCESS) return EXIT_FAILURE;
     for (const auto &sl : slices) HOK(hipMemcpyAsync(b->d_blob + sl[0], b->h_blob + sl[0], sl[1], hipMemcpyHostToDevice, up));
     HOK(hipEventRecord(b->ev_piece[k], up));
-    HOK(hipStreamWaitEvent(st, b->ev_piece[k], 0));
-    return queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, st);
+    HOK(hipStreamWaitEvent(ps, b->ev_piece[k], 0));
+    if (queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, ps) != EXIT_SUCCESS) return EXIT_FAILURE;
+    HOK(hipEventRecord(b->ev_sync[k], ps));
+    HOK(hipStreamWaitEvent(st, b->ev_sync[k], 0));
+    return EXIT_SUCCESS;
   };
   auto work = [&]() {
     for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
@@ -788,9 +835,14 @@ static int prepare_pieces_host(jga_huff_batch *b, const unsigned char *const *jp
       memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
       for (size_t si = 0; si < p.segs.size(); si++) segs[seg0v[(size_t)i] + si] = p.segs[si];
       const int k = piece_of[(size_t)i];
-      if (left[(size_t)k].fetch_sub(1) == 1) {                  // the piece's last image: off it goes
-        std::lock_guard<std::mutex> lk(qm);
-        if (queue_rc == EXIT_SUCCESS && !failed.load()) queue_rc = queue_piece(k);
+      if (left[(size_t)k].fetch_sub(1) == 1 && !failed.load()) { // the piece's last image: off it goes
+        {
+          std::lock_guard<std::mutex> lk(qm);                   // (the link turn, and the batch's widest piece)
+          if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
+          gated = true;
+          for (int q = cut[(size_t)k]; q < cut[(size_t)k + 1]; q++) if (prep[q].im.nsub > max_nsub) max_nsub = prep[q].im.nsub;
+        }
+        if (queue_piece(k) != EXIT_SUCCESS) queue_failed.store(1);
       }
     }
   };
@@ -800,9 +852,11 @@ static int prepare_pieces_host(jga_huff_batch *b, const unsigned char *const *jp
     work();
     for (auto &th : pool) th.join();
   }
-  if (failed.load() || queue_rc != EXIT_SUCCESS) {
+  if (failed.load() || queue_failed.load()) {
     // pieces already queued read the blob and run their rounds: wait them out before anybody reuses either
-    (void)hipStreamSynchronize(up);
+    for (hipStream_t s_ : b->own_copy) if (s_) (void)hipStreamSynchronize(s_);
+    if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+    for (hipStream_t s_ : b->piece_st) if (s_) (void)hipStreamSynchronize(s_);
     (void)hipStreamSynchronize(st);
     if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
     return EXIT_FAILURE;
@@ -810,8 +864,8 @@ static int prepare_pieces_host(jga_huff_batch *b, const unsigned char *const *jp
   for (int i = 0; i < n; i++) b->host_bytes += (long long)avail[(size_t)i];
   b->nimages = n;
   b->max_nsub = max_nsub;
-  HOK(hipEventRecord(b->ev_up, up));                            // (jga_huff_wait_upload: the last piece is on its way)
-  b->round0_queued = 1;
+  b->round0_queued = HJ_PIECE_ROUNDS;
+  b->npieces = np;
   if (b->trace) {
     fprintf(stderr, "  prepare (host clean-up, %d threads, %d pieces): %.2f ms\n", nt, np,
      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
@@ -831,6 +885,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   b->unstuffed_on_device = 0;
   b->host_bytes = 0;
   b->round0_queued = 0;
+  b->npieces = 0;
   const auto t_p0 = std::chrono::steady_clock::now();
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
@@ -996,6 +1051,10 @@ JGA_EXPORT void jga_huff_set_blocking_waits(jga_huff_batch *b, int on) { b->bloc
 JGA_EXPORT void jga_huff_set_device_shared(jga_huff_batch *b, int on) { b->device_shared = on != 0; }
 // Wait until the last prepare()'s upload has arrived (its kernels, if it queued any, may still run).
 JGA_EXPORT int jga_huff_wait_upload(jga_huff_batch *b) {
+  for (int k = 0; k < b->npieces; k++) {      // (an upload in pieces: every piece's own event)
+    HOK(b->blocking_waits ? jga_event_wait_sleeping(b->ev_piece[k]) : hipEventSynchronize(b->ev_piece[k]));
+  }
+  if (b->npieces) return EXIT_SUCCESS;
   HOK(b->blocking_waits ? jga_event_wait_sleeping(b->ev_up) : hipEventSynchronize(b->ev_up));
   return EXIT_SUCCESS;
 }
@@ -1194,12 +1253,12 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   if (b->round0_queued) {
     // prepare() has queued every piece's start states and first round behind that piece's upload: go on
     // from round 1 (the images' verdicts — what the on-device clean-up found, or nothing — are set here)
+    round = b->round0_queued;
     b->round0_queued = 0;
     if (b->unstuffed_on_device) {
       HOK(hipMemcpyAsync(b->d_errors, b->d_blob + b->off_perr, 4*(size_t)b->nimages, hipMemcpyDeviceToDevice, st));
     }
     else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
-    round = 1;
   }
   // reset: states back to the guesses, "never ran"
   // (on-device unstuffing has already had its say about every image: early end, RSTn counters)

@@ -81,9 +81,10 @@ const char *jga_version(void) { return "jpeg_gpu_amd 0.1 (gfx950)"; }
  * v1 "cpu.cfs_quota_us" + "cpu.cfs_period_us" (-1 = unlimited).  Returns CPUs' worth of run time,
  * 0 when the directory sets no limit or cannot be read. */
 static double cgroup_dir_quota(const char *dir) {
-  char path[512];
+  char path[512 + 32];                 /* (dir is at most 512 bytes: room for the longest file name) */
   double quota = 0, period = 0;
   FILE *f;
+  if (strlen(dir) >= 512) return 0.0;
   snprintf(path, sizeof(path), "%s/cpu.max", dir);
   f = fopen(path, "r");
   if (f) {

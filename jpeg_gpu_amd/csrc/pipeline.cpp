@@ -540,7 +540,10 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     if (cap > full) full = (int)cap;
   }
   // (with the clean-up on the device the batch holds the raw scans AND the clean streams)
-  const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pl->offload_cleanup);
+  // (a short job's batches, uploaded in pieces, leave the clean-up to the device whatever the core count: what the
+  // run waits for is the host's pass over the bytes before the first piece can go — a copy, or nothing at all
+  // for files that are pinned or in the input cache, against an unstuffing pass four times as long)
+  const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && (pl->offload_cleanup || pieces > 1));
   const long long total_full = (total/m*full + total/4)*(on_device ? 2 : 1);
   if (on_device) total *= 2;
   if (!l.hb || m > l.hb_images || total > l.hb_scan) {
@@ -839,7 +842,7 @@ void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<
     const bool short_mode = pp.short_job == 2 && px > 0 && pixels[key] <= (long long)batch*frame;
     if (short_mode) {
       const long long count = pixels[key]/px;
-      cap = pixels[key] >= 8*frame && count >= 4 ? (made == 0 ? (count*3 + 4)/5 : count) : count;
+      cap = count;                                  // ONE batch (its upload in pieces)
     }
     if ((long long)groups[it->second].size() >= cap) { open.erase(it); made++; }
   }
@@ -1009,8 +1012,6 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     pl->run_t0 = std::chrono::steady_clock::now();
     const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 48;
     const int nl = (int)pl->lanes.size();
-    int per = pl->cfg.nthreads/nl;
-    if (per < 1) per = 1;
     std::vector<std::vector<jga_job *>> groups;
     std::vector<int> pieces;
     {
@@ -1022,6 +1023,10 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
         for (int i : plan[k]) groups[k].push_back(&jobs[i]);
       }
     }
+    // host threads of a lane's prepare: the run's share per lane that has a group to work on
+    const int busy = (int)groups.size() < nl ? ((int)groups.size() > 0 ? (int)groups.size() : 1) : nl;
+    int per = pl->cfg.nthreads/busy;
+    if (per < 1) per = 1;
     if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), pl->since_run_start_ms());
     {
       std::lock_guard<std::mutex> lk(pl->run_mutex);

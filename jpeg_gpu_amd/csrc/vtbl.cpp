@@ -125,7 +125,7 @@ plugin_settings current_settings() {
   std::lock_guard<std::mutex> lk(g_settings_mutex);
   plugin_settings s = g_settings;
   if (const char *e = jga_tune("JGA_PLUGIN_ENTROPY")) s.host_entropy = strcmp(e, "host") == 0;
-  if (const char *e = jga_tune("JGA_PLUGIN_REGISTER")) s.register_buffers = strcmp(e, "1") == 0;
+  if (const char *e = jga_tune("JGA_PLUGIN_REGISTER")) s.register_buffers = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0;
   if (const char *e = jga_tune("JGA_PLUGIN_COPY_TEAM")) s.copy_team = atoi(e) == 0 ? -1 : 0;
   if (const char *e = jga_tune("JGA_PLUGIN_BAND_COPY")) s.band_copy = atoi(e) == 0 ? -1 : 0;
   return s;
@@ -136,7 +136,7 @@ plugin_settings current_settings() {
 // decoder context lives (the harness does; a caller that frees and re-allocates its image
 // between frames would leave a stale registration behind).  Default: the staged copy.
 bool registered(hipjpeg_ctx *c, void *p, size_t bytes) {
-  if (!c->opt.register_buffers || !p || !bytes) return false;
+  if (c->opt.register_buffers <= 0 || !p || !bytes) return false;
   int free_slot = -1;
   for (int i = 0; i < 6; i++) {
     if (c->reg[i].ptr == p && c->reg[i].bytes >= bytes) return true;
@@ -155,6 +155,28 @@ bool registered(hipjpeg_ctx *c, void *p, size_t bytes) {
   c->reg[free_slot].bytes = bytes;
   return true;
 }
+
+// A caller's buffer registered for the length of ONE decode_image call (round 4): hipHostRegister takes
+// 40-60 us for a 3-12 MB buffer on this stack and hipHostUnregister 1 us (tools/register_probe.py) — less
+// than a host pass over the same bytes by an order of magnitude — and a registration that does not outlive
+// the call needs no promise from the caller: the buffer is alive while the call runs.  The stream is drained
+// before the buffer is let go.  A buffer that cannot be registered (already registered by its owner, ...)
+// takes the staged route.
+struct transient_registration {
+  hipStream_t stream = nullptr;
+  void *ptr = nullptr;
+  bool take(hipStream_t st, void *p, size_t bytes) {
+    if (ptr || !p || !bytes) return false;
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+    stream = st; ptr = p;
+    return true;
+  }
+  ~transient_registration() {
+    if (!ptr) return;
+    (void)hipStreamSynchronize(stream);
+    (void)hipHostUnregister(ptr);
+  }
+};
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return jga_fail("hipjpeg: HIP error %d (%s) at %s", (int)e_, \
@@ -349,6 +371,9 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       return EXIT_FAILURE;
     }
     int on_gpu = !c->opt.host_entropy;
+    // (declared before anything is queued: destroyed — stream drained, buffers let go — on every way out)
+    transient_registration tr_file, tr_out[NPLANES_MAX];
+    const bool per_call = c->opt.register_buffers == 0;      // (1: for the life of the context; -1: never, staged copies)
     if (on_gpu) {
       jga_geom g2;
       if (!c->hb || c->size + 4096ll > c->hb_scan) {
@@ -362,7 +387,8 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       // device cleans the scan up — the host's pass over the entropy-coded bytes takes one core
       // 0.2 ms for a 4K file, the four launches of the device's ~0.1 ms whatever the size: a 4K frame
       // 1.15 -> 1.08 ms, 8K 3.5 -> 2.7, a 1080p frame is better off with the host's)
-      const bool file_pinned = c->size >= (3 << 19) && registered(c, const_cast<unsigned char *>(c->buf), (size_t)c->size);
+      const bool file_pinned = c->size >= (3 << 19) && (registered(c, const_cast<unsigned char *>(c->buf), (size_t)c->size)
+       || (per_call && tr_file.take(c->stream, const_cast<unsigned char *>(c->buf), (size_t)c->size)));
       jga_huff_set_device_unstuff(c->hb, file_pinned);
       jga_huff_set_inputs_pinned(c->hb, file_pinned);
       if (jga_huff_prepare(c->hb, &c->buf, &c->size, 1, &g2, c->stream) != EXIT_SUCCESS) {
@@ -394,7 +420,8 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     // D2H straight into the caller's buffers when they can be registered, else through
     // the pinned staging buffer
     if (rgb) {
-      if (registered(c, img->pixels, (size_t)out_bytes)) {
+      if (registered(c, img->pixels, (size_t)out_bytes)
+       || (per_call && out_bytes >= (1 << 20) && tr_out[0].take(c->stream, img->pixels, (size_t)out_bytes))) {
         HIP_OK(hipMemcpyAsync(img->pixels, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
       }
@@ -406,8 +433,9 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     else {
       bool direct = true;
       for (i = 0; i < img->nplanes; i++) {
-        direct = direct && registered(c, img->plane[i].data,
-         (size_t)img->plane[i].ystride*img->plane[i].height);
+        const size_t pb = (size_t)img->plane[i].ystride*img->plane[i].height;
+        direct = direct && (registered(c, img->plane[i].data, pb)
+         || (per_call && out_bytes >= (1 << 20) && tr_out[i].take(c->stream, img->plane[i].data, pb)));
       }
       if (direct) {
         for (i = 0; i < img->nplanes; i++) {
@@ -451,7 +479,7 @@ extern "C" JGA_EXPORT int jga_plugin_configure(const jga_plugin_config *cfg) {
      "library: %d) - use jga_plugin_config_init()", cfg ? cfg->struct_size : 0, (int)sizeof(jga_plugin_config));
   }
   std::lock_guard<std::mutex> lk(g_settings_mutex);
-  g_settings.register_buffers = cfg->register_buffers != 0;
+  g_settings.register_buffers = cfg->register_buffers < 0 ? -1 : cfg->register_buffers > 0 ? 1 : 0;
   g_settings.host_entropy = cfg->host_entropy != 0;
   g_settings.copy_team = cfg->copy_team < 0 ? -1 : 0;
   g_settings.band_copy = cfg->band_copy < 0 ? -1 : 0;

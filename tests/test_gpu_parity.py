@@ -457,9 +457,12 @@ def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
     try:
         jobs = run(pl, list(range(10)))
         assert pl.counters()["registered"] == 0 and all(j.host_bytes == j.size for j in jobs)
-        run(pl, list(range(10)))
+        run(pl, list(range(10)))                     # second sight: registered while there is room (buffers a running
+        c = pl.counters()                            # group holds are never evicted: the others are copied)
+        assert 2 <= c["registered"] <= 3 and c["registered_MB"] <= 1
+        run(pl, [7, 8, 9])                           # ... and idle ones make room, least recently used first
         c = pl.counters()
-        assert c["registered"] >= 2 and c["evicted"] >= 1 and c["registered_MB"] <= 1
+        assert c["evicted"] >= 1 and c["registered_MB"] <= 1
         pl.register_input(arrs[0])                                              # explicit: at once, whatever the sight count
         jobs = run(pl, [0])
         assert jobs[0].host_bytes == 0

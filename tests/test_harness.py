@@ -161,7 +161,7 @@ def test_plugin_entropy_stage_choice(gpu, orc, jpg, entropy):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"JGA_STAGED": "0"}, {"JGA_HUFF_WRITE_GMEM": "0"},
                                  {"JGA_HUFF_SPARSE_FROM": "99"}, {"JGA_HUFF_ITERS": "1,1,3"},
-                                 {"JGA_HUFF_FLUSH": "1"}, {"JPEG_GPU_HIP_REGISTER": "0"},
+                                 {"JGA_HUFF_FLUSH": "1"}, {"JPEG_GPU_HIP_REGISTER": "0"}, {"JPEG_GPU_HIP_REGISTER": "-1"},
                                  {"JGA_HUFF_SUB": "32"}, {"JGA_HUFF_SUB": "64"},
                                  {"JGA_HUFF_LITE": "0"}, {"JGA_HUFF_LITE": "1", "JGA_HUFF_ITERS": "1,1,2"},
                                  {"JGA_HUFF_LITE": "120"}, {"JGA_HUFF_PACKS": "0"},
@@ -195,9 +195,12 @@ def test_registered_buffers_big_file(gpu, orc, jpg, ri):
     assert len(data) >= 3 << 19
     _, rgb = orc.decode_rgb(data)
     want = "%08x" % zlib.adler32(rgb.tobytes())
-    for env in ({"JPEG_GPU_HIP_REGISTER": "1"}, {"JPEG_GPU_HIP_REGISTER": "0"}):
+    # 1: buffers registered for the life of the decoder context; 0: for the length of each decode_image
+    # call (the plugin's default: safe for any caller); -1: never, copies staged through pinned buffers
+    for env in ({"JPEG_GPU_HIP_REGISTER": "1"}, {"JPEG_GPU_HIP_REGISTER": "0"}, {"JPEG_GPU_HIP_REGISTER": "-1"}):
         out = run("-o", "rgb", "--frames", "3", "--check", path, env=env).stdout.strip().split("\n")
         assert out[-1].endswith(want), (env, ri)
     out = run("-o", "yuv", "--frames", "2", "--check", path, env={"JPEG_GPU_HIP_REGISTER": "1"}).stdout.strip().split("\n")
-    assert out[-1].split()[-1] == run("-o", "yuv", "--frames", "2", "--check", path,
-                                      env={"JPEG_GPU_HIP_REGISTER": "0"}).stdout.strip().split("\n")[-1].split()[-1]
+    for mode in ("0", "-1"):
+        assert out[-1].split()[-1] == run("-o", "yuv", "--frames", "2", "--check", path,
+                                          env={"JPEG_GPU_HIP_REGISTER": mode}).stdout.strip().split("\n")[-1].split()[-1]
