@@ -39,6 +39,9 @@
 #include "pack_params.h"
 
 #define PK_BLOCK 256                 /* 4 waves, one block per lane */
+#ifndef PK_HOMOGENEOUS
+#define PK_HOMOGENEOUS 0             /* 1: a wave takes one MCU slot of 64 consecutive MCUs; 0: 64 blocks in scan order */
+#endif
 #define PK_BLK_STRIDE 33             /* dwords per lane's block buffer: 32 + its destination */
 #ifndef PK_CHUNK
 #define PK_CHUNK 16                  /* words per trip: 8 or 16 */
@@ -83,7 +86,23 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
   // where this lane's block starts in the stream and where it goes in the planes
   uint32_t k = limit, dst = ~0u;                             // dst: 128-byte slot of the image's planes; ~0: no block
   {
+#if PK_HOMOGENEOUS
+    // A/B (round 4, NOT the default): a wave's trips run as long as its LONGEST block, and luma blocks are
+    // systematically longer than chroma ones (the bench's files: 33.8 words against 8.4) — with the blocks dealt
+    // out in scan order every wave holds both kinds and takes the luma trip count.  Here `nslots` consecutive
+    // waves share 64 consecutive MCUs and wave w of them takes MCU slot w of each: a wave holds ONE kind of block
+    // (modelled on the bench's files: 636 -> 495 loop instructions per 64 blocks).  [MI355X] SLOWER: 0.379-0.387 ms
+    // against 0.354-0.359 (profiles/r4_pack_homogeneous_ab.txt) — neighbouring lanes' words then lie 300 bytes
+    // apart instead of 50, and what the trips save the scattered reads cost twice over: the kernel is not bound by
+    // its instruction count alone.
+    const uint32_t wave_id = (blockIdx.x*PK_BLOCK + threadIdx.x) >> 6;
+    const uint32_t sg = (uint32_t)(((uint64_t)wave_id*P.div_nslots.mul) >> P.div_nslots.shift);
+    const uint32_t slot_w = wave_id - sg*nslots, mcu_w = sg*64u + lane;
+    const bool mine = mcu_w < nhmb*(uint32_t)P.nvmb;
+    const uint32_t b = mine ? mcu_w*nslots + slot_w : total;
+#else
     const uint32_t b = blockIdx.x*PK_BLOCK + threadIdx.x;
+#endif
     if (b < total) {
       const uint32_t mcu = (uint32_t)(((uint64_t)b*P.div_nslots.mul) >> P.div_nslots.shift);
       const uint32_t slot = b - mcu*nslots;
@@ -182,7 +201,12 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
 }
 
 extern "C" int jga_launch_unpack(const jga_pack_params *P, void *stream) {
+#if PK_HOMOGENEOUS
+  const int waves = ((P->nhmb*P->nvmb + 63)/64)*P->nslots;      // nslots waves per 64 MCUs
+  const int blocks = waves*64;
+#else
   const int blocks = P->nhmb*P->nvmb*P->nslots;
+#endif
   dim3 grid((blocks + PK_BLOCK - 1)/PK_BLOCK, P->nimages), block(PK_BLOCK);
   hipLaunchKernelGGL(jga_unpack_kernel, grid, block, 0, (hipStream_t)stream, *P);
   return (int)hipGetLastError();
