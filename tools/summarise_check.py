@@ -1,4 +1,4 @@
-"""gpurun_out/<tag>/ (tools/r2_check.sh, tools/r3_check.sh) -> profiles/<name>_rocprof_summary.md,
+"""gpurun_out/<tag>/ (tools/archive/r2_check.sh, tools/archive/r3_check.sh, tools/r4_check.sh) -> profiles/<name>_rocprof_summary.md,
 profiles/<name>_bench.json, profiles/pmc_latest.json (+ round 3: <name>_configs_bench.txt,
 <name>_huffman_kernels.txt, <name>_huffman_pmc.md, <name>_harness_fps.txt).
 Usage: python tools/summarise_check.py r3c r3"""
