@@ -7,8 +7,32 @@ tag = sys.argv[1]
 name = sys.argv[2] if len(sys.argv) > 2 else tag
 src = os.path.join("gpurun_out", tag)
 bench = json.load(open(os.path.join(src, "bench.json")))
-out = ["# rocprofv3 summary, %s" % name, "",
-       "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 12 --warmup 3 --no-cpu --no-e2e "
+rf = bench["roofline"]
+out = ["# rocprofv3 summary, %s" % name, ""]
+roof = glob.glob(os.path.join(src, "roof", "**", "roof_kernel_stats.csv"), recursive=True)
+if roof:
+    # round 4: the roofline leg ALONE, so that roofline.frac can be recomputed from this file
+    out += ["## the roofline leg alone", "",
+            "Command: `rocprofv3 --kernel-trace --stats -- python tools/kbench.py --child 3840 2160 420 48` — 2 x 20 launches of the fused "
+            "dequantise + IDCT + upsample + RGB kernel (and of the YUV kernel) on 48 resident 3840x2160 4:2:0 frames, nothing else on the device.", "",
+            "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+    for r in csv.DictReader(open(roof[0])):
+        if "jga_" in r["Name"]:
+            out.append("| %s | %s | %.1f | %.1f | %.1f |" % (r["Name"][:80], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3))
+            if "jga_idct_rgb_kernel<1, 1, true>" in r["Name"]:
+                a_us = float(r["AverageNs"])/1e3
+                alg = rf["algorithmic_bytes_per_launch"]
+                out_roof = ("`jga_idct_rgb_kernel<1,1,true>`: %d algorithmic bytes per launch (48 x (194 400 blocks x 128 B + 3840 x 2160 x 3 B)) / %.1f us = "
+                            "**%.0f GB/s = %.3f of 8 TB/s** by rocprofv3's clock; bench.py's HIP events over 50 launches of the same build, un-profiled run: "
+                            "%.1f us -> %.0f GB/s = %.4f (`roofline.frac`)." % (alg, a_us, alg/a_us/1e3, alg/a_us/1e3/8000, rf["kernel_ms_per_launch"]*1e3, rf["achieved"], rf["frac"]))
+    out += ["", out_roof, ""]
+    dc = rf.get("device_copy")
+    if dc:
+        out += ["Copy ceiling of the same run (`roofline.device_copy`): hipMemcpyDtoDAsync of %d bytes each way, %d repetitions, warmed: %.4f ms = "
+                "%.0f GB/s read + %.0f GB/s written = %.0f GB/s (torch copy_: %s GB/s)." % (dc["bytes_each_way"], dc["reps"], dc["ms"], dc["read_GBps"],
+                    dc["write_GBps"], rf["device_copy_GBps"], dc.get("torch_copy_GBps")), ""]
+out += ["## a short bench run", "",
+       "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 12 --warmup 3 --batch 128 --no-cpu --no-e2e "
        "--no-pack --no-other --no-gpu-entropy` (tools/r2_check.sh / r3_check.sh; round 3 adds `--no-configs "
        "--no-measure-traffic`): the end-to-end pipeline legs (12 steps of 128 files through 8 lanes in groups "
        "of 32, pageable then pinned files, plus set-up and warm-up batches) followed by the roofline leg "
@@ -23,7 +47,6 @@ for fn in glob.glob(os.path.join(src, "**", "stats_kernel_stats.csv"), recursive
             float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3, r["Percentage"]))
         if "jga_idct_rgb_kernel<1, 1, true>" in r["Name"]:
             avg = (float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, int(r["Calls"]))
-rf = bench["roofline"]
 out += ["", "The dominant kernel by time in this command is `jga_idct_rgb_kernel<1,1,true>` (the roofline leg's "
         "launches + one per pipeline batch, the latter sharing the GPU with other lanes' kernels).",
         "rocprof: avg %.1f us over %d calls (min %.1f); bench.py's HIP events over its 50 timed launches, un-profiled "
@@ -58,6 +81,6 @@ if "configs" in bench:
         for k, v in bench["configs"].items():
             f.write("%s %s\n" % (k, json.dumps(v)))
 for fn, to in (("huffman_kernels.txt", "%s_huffman_kernels.txt"), ("huffman_pmc.txt", "%s_huffman_pmc.md"),
-               ("harness_fps.txt", "%s_harness_fps.txt")):
+               ("harness_fps.txt", "%s_harness_fps.txt"), ("plugin_latency.txt", "%s_plugin_latency.txt")):
     if os.path.exists(os.path.join(src, fn)):
         shutil.copy(os.path.join(src, fn), os.path.join("profiles", to % name))
