@@ -374,6 +374,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     // (declared before anything is queued: destroyed — stream drained, buffers let go — on every way out)
     transient_registration tr_file, tr_out[NPLANES_MAX];
     const bool per_call = c->opt.register_buffers == 0;      // (1: for the life of the context; -1: never, staged copies)
+    const bool direct_pageable = c->opt.register_buffers == -2;   // (experiment: the runtime's own handling of unregistered memory)
     if (on_gpu) {
       jga_geom g2;
       if (!c->hb || c->size + 4096ll > c->hb_scan) {
@@ -388,7 +389,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       // 0.2 ms for a 4K file, the four launches of the device's ~0.1 ms whatever the size: a 4K frame
       // 1.15 -> 1.08 ms, 8K 3.5 -> 2.7, a 1080p frame is better off with the host's)
       const bool file_pinned = c->size >= (3 << 19) && (registered(c, const_cast<unsigned char *>(c->buf), (size_t)c->size)
-       || (per_call && tr_file.take(c->stream, const_cast<unsigned char *>(c->buf), (size_t)c->size)));
+       || (per_call && tr_file.take(c->stream, const_cast<unsigned char *>(c->buf), (size_t)c->size)) || direct_pageable);
       jga_huff_set_device_unstuff(c->hb, file_pinned);
       jga_huff_set_inputs_pinned(c->hb, file_pinned);
       if (jga_huff_prepare(c->hb, &c->buf, &c->size, 1, &g2, c->stream) != EXIT_SUCCESS) {
@@ -421,7 +422,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     // the pinned staging buffer
     if (rgb) {
       if (registered(c, img->pixels, (size_t)out_bytes)
-       || (per_call && out_bytes >= (1 << 20) && tr_out[0].take(c->stream, img->pixels, (size_t)out_bytes))) {
+       || (per_call && out_bytes >= (1 << 20) && tr_out[0].take(c->stream, img->pixels, (size_t)out_bytes)) || direct_pageable) {
         HIP_OK(hipMemcpyAsync(img->pixels, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
       }
@@ -435,7 +436,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       for (i = 0; i < img->nplanes; i++) {
         const size_t pb = (size_t)img->plane[i].ystride*img->plane[i].height;
         direct = direct && (registered(c, img->plane[i].data, pb)
-         || (per_call && out_bytes >= (1 << 20) && tr_out[i].take(c->stream, img->plane[i].data, pb)));
+         || (per_call && out_bytes >= (1 << 20) && tr_out[i].take(c->stream, img->plane[i].data, pb)) || direct_pageable);
       }
       if (direct) {
         for (i = 0; i < img->nplanes; i++) {
@@ -479,7 +480,7 @@ extern "C" JGA_EXPORT int jga_plugin_configure(const jga_plugin_config *cfg) {
      "library: %d) - use jga_plugin_config_init()", cfg ? cfg->struct_size : 0, (int)sizeof(jga_plugin_config));
   }
   std::lock_guard<std::mutex> lk(g_settings_mutex);
-  g_settings.register_buffers = cfg->register_buffers < 0 ? -1 : cfg->register_buffers > 0 ? 1 : 0;
+  g_settings.register_buffers = cfg->register_buffers < -2 ? -1 : cfg->register_buffers > 0 ? 1 : cfg->register_buffers;
   g_settings.host_entropy = cfg->host_entropy != 0;
   g_settings.copy_team = cfg->copy_team < 0 ? -1 : 0;
   g_settings.band_copy = cfg->band_copy < 0 ? -1 : 0;

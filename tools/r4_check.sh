@@ -12,8 +12,9 @@ if [ -z "$SKIP_TESTS" ]; then
 fi
 ( time timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; tail -3 $OUT/bench.time
 tail -3 $OUT/bench.err
-# the roofline leg alone: 2 x 20 launches of the fused RGB kernel (and of the YUV kernel) on 48 resident 4K frames
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/roof -o roof -f csv -- python tools/kbench.py --child 3840 2160 420 48 > $OUT/roof.log 2>&1
+# the roofline leg alone, as bench.py runs it: 0.5 s of untimed launches of the fused RGB kernel on 48 resident 4K
+# frames, then 50 launches between two HIP events (the LAST 50 launches of the trace)
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/roof -o roof -f csv -- python tools/kbench.py --roofline-leg 3840 2160 420 48 > $OUT/roof.log 2>&1
 echo "roofline leg rc=$?"
 PB="python bench.py --steps 12 --warmup 3 --batch 128 --no-cpu --no-e2e --no-pack --no-other --no-gpu-entropy --no-configs --no-measure-traffic --scale-proxy 0"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT -o stats -f csv -- $PB > $OUT/bench_under_rocprof.json 2> $OUT/stats.err

@@ -9,27 +9,35 @@ src = os.path.join("gpurun_out", tag)
 bench = json.load(open(os.path.join(src, "bench.json")))
 rf = bench["roofline"]
 out = ["# rocprofv3 summary, %s" % name, ""]
-roof = glob.glob(os.path.join(src, "roof", "**", "roof_kernel_stats.csv"), recursive=True)
+roof = glob.glob(os.path.join(src, "roof", "**", "roof_kernel_trace.csv"), recursive=True)
 if roof:
     # round 4: the roofline leg ALONE, so that roofline.frac can be recomputed from this file
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(roof[0]))
+         if "jga_idct_rgb_kernel" in r["Kernel_Name"]]
+    last = d[-50:]
+    alg = rf["algorithmic_bytes_per_launch"]
+    own = ""
+    try:
+        own = [l for l in open(os.path.join(src, "roof.log")) if l.startswith("RESULT ")][0][7:].strip()
+    except Exception:
+        pass
+    stat = lambda v: "%d | %.1f | %.1f | %.1f" % (len(v), sum(v) / len(v), min(v), max(v))
     out += ["## the roofline leg alone", "",
-            "Command: `rocprofv3 --kernel-trace --stats -- python tools/kbench.py --child 3840 2160 420 48` — 2 x 20 launches of the fused "
-            "dequantise + IDCT + upsample + RGB kernel (and of the YUV kernel) on 48 resident 3840x2160 4:2:0 frames, nothing else on the device.", "",
-            "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
-    for r in csv.DictReader(open(roof[0])):
-        if "jga_" in r["Name"]:
-            out.append("| %s | %s | %.1f | %.1f | %.1f |" % (r["Name"][:80], r["Calls"], float(r["AverageNs"])/1e3, float(r["MinNs"])/1e3, float(r["MaxNs"])/1e3))
-            if "jga_idct_rgb_kernel<1, 1, true>" in r["Name"]:
-                a_us = float(r["AverageNs"])/1e3
-                alg = rf["algorithmic_bytes_per_launch"]
-                out_roof = ("`jga_idct_rgb_kernel<1,1,true>`: %d algorithmic bytes per launch (48 x (194 400 blocks x 128 B + 3840 x 2160 x 3 B)) / %.1f us = "
-                            "**%.0f GB/s = %.3f of 8 TB/s** by rocprofv3's clock; bench.py's HIP events over 50 launches of the same build, un-profiled run: "
-                            "%.1f us -> %.0f GB/s = %.4f (`roofline.frac`)." % (alg, a_us, alg/a_us/1e3, alg/a_us/1e3/8000, rf["kernel_ms_per_launch"]*1e3, rf["achieved"], rf["frac"]))
-    out += ["", out_roof, ""]
+            "Command: `rocprofv3 --kernel-trace --stats -- python tools/kbench.py --roofline-leg 3840 2160 420 48` - bench.py's roofline leg as a "
+            "program of its own: the fused dequantise + IDCT + upsample + RGB kernel on 48 resident 3840x2160 4:2:0 frames, 0.5 s of untimed "
+            "launches (the clocks settle), 5 more, then 50 launches between two HIP events; nothing else on the device.", "",
+            "| `jga_idct_rgb_kernel<1,1,true>` | calls | avg us | min us | max us |", "|---|---|---|---|---|",
+            "| the 50 timed launches (the last 50 of the trace) | " + stat(last) + " |",
+            "| every launch of the process (warm-up included) | " + stat(d) + " |", "",
+            "%d algorithmic bytes per launch (48 x (194 400 blocks x 128 B + 3840 x 2160 x 3 B)) / %.1f us = **%.0f GB/s = %.4f of 8 TB/s** by "
+            "rocprofv3's clock over the timed launches; the program's own HIP events around the same 50 launches: %s; bench.py's HIP events over "
+            "its 50 launches, un-profiled run of the same build: %.1f us -> %.0f GB/s = %.4f (`roofline.frac`)." % (
+                alg, sum(last) / len(last), alg / (sum(last) / len(last)) / 1e3, alg / (sum(last) / len(last)) / 1e3 / 8000, own or "n/a",
+                rf["kernel_ms_per_launch"] * 1e3, rf["achieved"], rf["frac"]), ""]
     dc = rf.get("device_copy")
     if dc:
-        out += ["Copy ceiling of the same run (`roofline.device_copy`): hipMemcpyDtoDAsync of %d bytes each way, %d repetitions, warmed: %.4f ms = "
-                "%.0f GB/s read + %.0f GB/s written = %.0f GB/s (torch copy_: %s GB/s)." % (dc["bytes_each_way"], dc["reps"], dc["ms"], dc["read_GBps"],
+        out += ["Copy ceiling of the same bench run (`roofline.device_copy`): hipMemcpyDtoDAsync of %d bytes each way, %d repetitions, warmed: %.4f ms = "
+                "%.0f GB/s read + %.0f GB/s written = %.0f GB/s (torch copy_ of the same tensors: %s GB/s)." % (dc["bytes_each_way"], dc["reps"], dc["ms"], dc["read_GBps"],
                     dc["write_GBps"], rf["device_copy_GBps"], dc.get("torch_copy_GBps")), ""]
 out += ["## a short bench run", "",
        "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 12 --warmup 3 --batch 128 --no-cpu --no-e2e "
