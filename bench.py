@@ -537,7 +537,7 @@ def main():
     def headline_run(pinned, **kw):
         src = pcyc if pinned else cyc
         mk = lambda n, o, **k2: lib.Pipeline.make_jobs(src(n, o), pinned=pinned, **k2)
-        if not pinned and args.input_cache_MB > 0:
+        if not pinned and args.input_cache_MB != 0:
             kw.setdefault("input_cache_mb", args.input_cache_MB)
         pl = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False,
                           transport=2, batch=G, depth=args.lanes, **kw)
@@ -552,7 +552,7 @@ def main():
         if warm_jobs is not None:
             pl.run_jobs(warm_jobs)                                   # W untimed steps
         kept.buf.zero_()
-        if not pinned and kw.get("input_cache_mb"):
+        if not pinned and kw.get("input_cache_mb", 0) > 0:
             # whatever the warm-up left registered is dropped: every file's FIRST sight — its
             # hipHostRegister — happens inside the timed region
             for v in timed_jobs._keep[0]:

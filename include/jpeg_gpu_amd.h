@@ -397,7 +397,11 @@ typedef struct jga_pipeline_config {
    *     is copied as before.  Only used where the scan clean-up runs on the device (unstuff 2, or 0 with
    *     few cores): a host that cleans up reads every byte anyway.  CONTRACT: a buffer handed in again
    *     at the same address and size must still be the same live allocation, or have been dropped with
-   *     jga_pipeline_forget_input() before it was freed; jga_pipeline_destroy() unregisters everything. */
+   *     jga_pipeline_forget_input() before it was freed; jga_pipeline_destroy() unregisters everything.
+   *     input_cache_mb = 0 (default), and buffers a cache does not hold: no contract — the upload's copies name the
+   *     callers' ordinary buffers and the runtime pins what they touch (slower than the cache: the pinning is
+   *     redone per copy; what the plugin does with a lone frame's buffers).  input_cache_mb < 0: every file that
+   *     is not `pinned` is copied into the group's pinned blob by a host core (rounds 2-3). */
   int input_cache_mb;
   int input_cache_sight;
   /* --- GPU entropy stage of the lanes' batches (jga_huff_set_option): 0 = default */
@@ -424,7 +428,7 @@ typedef struct jga_job {
                                 * does (copy_back then writes the pixels straight into it: no staging
                                 * buffer, no host memcpy) — jga_host_malloc_pinned / jga_host_register */
   long long host_bytes;        /* out: bytes of this file a host core read (copied or cleaned up) on the way to
-                                * the device; 0 when the scan was DMA'd where it lies */
+                                * the device; 0 when the copy engine read the scan where it lies */
 } jga_job;
 
 /* Zero the configuration (every 0 is a documented default) and stamp it with this header's
@@ -551,20 +555,18 @@ int jga_huff_set_option(jga_huff_batch *b, int option, int value);
  *     are allocated; what JGA_PLUGIN_* environment variables used to say. */
 typedef struct jga_plugin_config {
   int struct_size;             /* sizeof(jga_plugin_config) of the caller's header */
-  int register_buffers;        /* 1: the caller keeps its image and file buffers alive and in place for as long
-                                * as a decoder context lives (the reference's main loop does,
-                                * src/jpeg_gpu.c:612-613, 1231-1237): they are registered with the device once,
-                                * pixels are copied straight into them, big files DMA'd where they lie.
-                                * 0 (default, safe for any caller): the same, but each buffer is registered for the
-                                * length of ONE decode_image call and let go before it returns (hipHostRegister
-                                * takes ~50 us per buffer, a host pass over a 4K frame's pixels ~1 ms).
-                                * -1: never — copies staged through the context's pinned buffers */
+  int register_buffers;        /* how the caller's image and file buffers meet the device:
+                                *  0 (default, any caller): the copies name the caller's ordinary memory and the
+                                *    runtime pins what they touch (and caches that) — pixels arrive at link speed,
+                                *    big files are DMA'd where they lie, no host core passes over either;
+                                *  1: the plugin registers the buffers for the life of the decoder context
+                                *    (hipHostRegister) — for callers that keep image and file in place for that long
+                                *    (the reference's main loop does, src/jpeg_gpu.c:612-613, 1231-1237);
+                                * -1: copies staged through the context's pinned buffers (rounds 2-3's default) */
   int host_entropy;            /* 1: Huffman decoding on the host (csrc/entropy.c) for YUV / RGB too */
   int copy_team;               /* staged copy back of frames of 12 MB and more: 0 = two helper threads move the
                                 * pieces (default), -1 = the calling thread alone */
-  int band_copy;               /* RGB frames of 24 MB and more with restart intervals: 0 = bands of MCU rows are
-                                * decoded and copied back one after the other (the copy of one hides the decode of
-                                * the next), -1 = whole frame at once */
+  int reserved_;               /* zero */
 } jga_plugin_config;
 #define jga_plugin_config_init(cfg) do { memset((cfg), 0, sizeof(jga_plugin_config)); \
   (cfg)->struct_size = (int)sizeof(jga_plugin_config); } while (0)

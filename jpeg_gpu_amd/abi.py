@@ -102,7 +102,7 @@ class jga_job(C.Structure):
 
 class jga_plugin_config(C.Structure):
     _fields_ = [("struct_size", C.c_int), ("register_buffers", C.c_int), ("host_entropy", C.c_int),
-                ("copy_team", C.c_int), ("band_copy", C.c_int)]
+                ("copy_team", C.c_int), ("reserved_", C.c_int)]
 
 
 JGA_HUFF_OPT_SUB_BYTES, JGA_HUFF_OPT_ASSIST_AFTER, JGA_HUFF_OPT_SPECULATE, JGA_HUFF_OPT_PIECES, \

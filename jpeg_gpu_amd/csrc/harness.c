@@ -334,8 +334,8 @@ int main(int argc, char *argv[]) {
   int c;
   memset(&info, 0, sizeof(info));
   /* this program keeps one image for the life of each decoder context, so the plugin may
-   * register its buffers once and copy results straight into them (JPEG_GPU_HIP_REGISTER=0: as a caller
-   * that makes no such promise — buffers registered per call; -1: staged copies only) */
+   * register its buffers once and copy results straight into them (JPEG_GPU_HIP_REGISTER=0: the plugin's
+   * default for callers that make no such promise — copies on ordinary memory; -1: staged copies) */
   {
     jga_plugin_config pc;
     const char *e = getenv("JPEG_GPU_HIP_REGISTER"), *h = getenv("JPEG_GPU_HIP_ENTROPY");

@@ -55,7 +55,7 @@ struct hipjpeg_ctx {
   struct { void *ptr; size_t bytes; } reg[6];
   hipEvent_t ev_piece[8];     // copy_back_staged
   struct copy_team *team;     // ... and its two helpers, started by the first big frame
-  struct { int register_buffers, host_entropy, copy_team, band_copy; } opt;   // jga_plugin_configure, as of decode_alloc
+  struct { int register_buffers, host_entropy, copy_team; } opt;   // jga_plugin_configure, as of decode_alloc
 };
 
 // Two helper threads that move pieces of a frame from the pinned staging buffer into the caller's
@@ -118,16 +118,15 @@ struct copy_team {
 
 // The plugin's settings (jga_plugin_configure): process-wide, copied into a context when it is
 // allocated.  Builds made with -DJGA_TUNING also listen to the JGA_PLUGIN_* variables of rounds 2-3.
-struct plugin_settings { int register_buffers, host_entropy, copy_team, band_copy; };
+struct plugin_settings { int register_buffers, host_entropy, copy_team; };
 std::mutex g_settings_mutex;
-plugin_settings g_settings = {0, 0, 0, 0};
+plugin_settings g_settings = {0, 0, 0};
 plugin_settings current_settings() {
   std::lock_guard<std::mutex> lk(g_settings_mutex);
   plugin_settings s = g_settings;
   if (const char *e = jga_tune("JGA_PLUGIN_ENTROPY")) s.host_entropy = strcmp(e, "host") == 0;
   if (const char *e = jga_tune("JGA_PLUGIN_REGISTER")) s.register_buffers = atoi(e) < 0 ? -1 : atoi(e) > 0 ? 1 : 0;
   if (const char *e = jga_tune("JGA_PLUGIN_COPY_TEAM")) s.copy_team = atoi(e) == 0 ? -1 : 0;
-  if (const char *e = jga_tune("JGA_PLUGIN_BAND_COPY")) s.band_copy = atoi(e) == 0 ? -1 : 0;
   return s;
 }
 
@@ -156,28 +155,21 @@ bool registered(hipjpeg_ctx *c, void *p, size_t bytes) {
   return true;
 }
 
-// A caller's buffer registered for the length of ONE decode_image call (round 4): hipHostRegister takes
-// 40-60 us for a 3-12 MB buffer on this stack and hipHostUnregister 1 us (tools/register_probe.py) — less
-// than a host pass over the same bytes by an order of magnitude — and a registration that does not outlive
-// the call needs no promise from the caller: the buffer is alive while the call runs.  The stream is drained
-// before the buffer is let go.  A buffer that cannot be registered (already registered by its owner, ...)
-// takes the staged route.
-struct transient_registration {
-  hipStream_t stream = nullptr;
-  void *ptr = nullptr;
-  bool take(hipStream_t st, void *p, size_t bytes) {
-    if (ptr || !p || !bytes) return false;
-    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
-    stream = st; ptr = p;
-    return true;
-  }
-  ~transient_registration() {
-    if (!ptr) return;
-    (void)hipStreamSynchronize(stream);
-    (void)hipHostUnregister(ptr);
-  }
-};
-
+// How the caller's buffers meet the device (jga_plugin_config.register_buffers; round 4 measured all four ways,
+// profiles/r4_host_side_steps.md §2):
+//    0  (default) the copies name the caller's ORDINARY memory and the runtime does the rest — it pins what a copy
+//       touches and keeps that cached, so a frame's pixels arrive at link speed without any promise from the caller
+//       and without a pass of a host core over them: one 4K frame 1.08 ms, the 8K frame of config 5 2.71 ms, the same
+//       as with registered buffers, and the caller's own later copies of those buffers run at link speed too
+//       (harness, 4K -o rgb: 657 FPS; rounds 2-3's staged default: 527-540)
+//    1  buffers registered by the plugin for the life of the decoder context (hipHostRegister): the same times; for
+//       callers that keep image and file in place (the reference's main loop does) and want no first-frame pinning
+//   -1  copies staged through the context's pinned buffers, the pieces moved into the caller's memory by host threads
+//       (rounds 2-3's default): 0.75 / 1.49 / 3.96 ms for a 1080p / 4K / 8K frame
+// Tried and dropped: registering each buffer for the length of ONE decode_image call (hipHostRegister 40-60 us,
+// hipHostUnregister 1 us: tools/register_probe.py) — the fastest decode_image in isolation, but the release throws
+// away the runtime's cached pinning, so a caller that then copies the same buffer itself (the reference's
+// glTexSubImage2D; the harness's upload) pays for it: 4K -o rgb 326 FPS against 540 staged.
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return jga_fail("hipjpeg: HIP error %d (%s) at %s", (int)e_, \
   hipGetErrorString(e_), #call); } while (0)
@@ -289,7 +281,7 @@ jpeg_decode_ctx *hipjpeg_alloc(jpeg_info *info) {
     c->buf = info->buf;
     c->size = info->size;
     c->opt.register_buffers = s.register_buffers; c->opt.host_entropy = s.host_entropy;
-    c->opt.copy_team = s.copy_team; c->opt.band_copy = s.band_copy;
+    c->opt.copy_team = s.copy_team;
   }
   return (jpeg_decode_ctx *)c;
 }
@@ -371,10 +363,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       return EXIT_FAILURE;
     }
     int on_gpu = !c->opt.host_entropy;
-    // (declared before anything is queued: destroyed — stream drained, buffers let go — on every way out)
-    transient_registration tr_file, tr_out[NPLANES_MAX];
-    const bool per_call = c->opt.register_buffers == 0;      // (1: for the life of the context; -1: never, staged copies)
-    const bool direct_pageable = c->opt.register_buffers == -2;   // (experiment: the runtime's own handling of unregistered memory)
+    const bool direct = c->opt.register_buffers == 0;         // (1: registered for the life of the context; -1: staged copies)
     if (on_gpu) {
       jga_geom g2;
       if (!c->hb || c->size + 4096ll > c->hb_scan) {
@@ -388,8 +377,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       // device cleans the scan up — the host's pass over the entropy-coded bytes takes one core
       // 0.2 ms for a 4K file, the four launches of the device's ~0.1 ms whatever the size: a 4K frame
       // 1.15 -> 1.08 ms, 8K 3.5 -> 2.7, a 1080p frame is better off with the host's)
-      const bool file_pinned = c->size >= (3 << 19) && (registered(c, const_cast<unsigned char *>(c->buf), (size_t)c->size)
-       || (per_call && tr_file.take(c->stream, const_cast<unsigned char *>(c->buf), (size_t)c->size)) || direct_pageable);
+      const bool file_pinned = c->size >= (3 << 19) && (direct || registered(c, const_cast<unsigned char *>(c->buf), (size_t)c->size));
       jga_huff_set_device_unstuff(c->hb, file_pinned);
       jga_huff_set_inputs_pinned(c->hb, file_pinned);
       if (jga_huff_prepare(c->hb, &c->buf, &c->size, 1, &g2, c->stream) != EXIT_SUCCESS) {
@@ -421,8 +409,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     // D2H straight into the caller's buffers when they can be registered, else through
     // the pinned staging buffer
     if (rgb) {
-      if (registered(c, img->pixels, (size_t)out_bytes)
-       || (per_call && out_bytes >= (1 << 20) && tr_out[0].take(c->stream, img->pixels, (size_t)out_bytes)) || direct_pageable) {
+      if (direct || registered(c, img->pixels, (size_t)out_bytes)) {
         HIP_OK(hipMemcpyAsync(img->pixels, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_OK(hipStreamSynchronize(c->stream));
       }
@@ -432,13 +419,11 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       }
     }
     else {
-      bool direct = true;
+      bool in_place = true;
       for (i = 0; i < img->nplanes; i++) {
-        const size_t pb = (size_t)img->plane[i].ystride*img->plane[i].height;
-        direct = direct && (registered(c, img->plane[i].data, pb)
-         || (per_call && out_bytes >= (1 << 20) && tr_out[i].take(c->stream, img->plane[i].data, pb)) || direct_pageable);
+        in_place = in_place && (direct || registered(c, img->plane[i].data, (size_t)img->plane[i].ystride*img->plane[i].height));
       }
-      if (direct) {
+      if (in_place) {
         for (i = 0; i < img->nplanes; i++) {
           HIP_OK(hipMemcpyAsync(img->plane[i].data, c->d_out + g->plane[i].data_off,
            (size_t)img->plane[i].ystride*img->plane[i].height, hipMemcpyDeviceToHost, c->stream));
@@ -480,10 +465,9 @@ extern "C" JGA_EXPORT int jga_plugin_configure(const jga_plugin_config *cfg) {
      "library: %d) - use jga_plugin_config_init()", cfg ? cfg->struct_size : 0, (int)sizeof(jga_plugin_config));
   }
   std::lock_guard<std::mutex> lk(g_settings_mutex);
-  g_settings.register_buffers = cfg->register_buffers < -2 ? -1 : cfg->register_buffers > 0 ? 1 : cfg->register_buffers;
+  g_settings.register_buffers = cfg->register_buffers < 0 ? -1 : cfg->register_buffers > 0 ? 1 : 0;
   g_settings.host_entropy = cfg->host_entropy != 0;
   g_settings.copy_team = cfg->copy_team < 0 ? -1 : 0;
-  g_settings.band_copy = cfg->band_copy < 0 ? -1 : 0;
   return EXIT_SUCCESS;
 }
 
