@@ -459,7 +459,7 @@ def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
         assert pl.counters()["registered"] == 0
         run(pl, list(range(10)))                     # second sight: registered while there is room (buffers a running
         c = pl.counters()                            # group holds are never evicted: the others go unregistered)
-        assert 2 <= c["registered"] <= 3 and c["registered_MB"] <= 1
+        assert c["registered"] >= 2 and c["registered_MB"] <= 1
         run(pl, [7, 8, 9])                           # ... and idle ones make room, least recently used first
         c = pl.counters()
         assert c["evicted"] >= 1 and c["registered_MB"] <= 1
