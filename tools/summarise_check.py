@@ -41,8 +41,8 @@ if roof:
                     dc["write_GBps"], rf["device_copy_GBps"], dc.get("torch_copy_GBps")), ""]
 out += ["## a short bench run", "",
        "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 12 --warmup 3 --batch 128 --no-cpu --no-e2e "
-       "--no-pack --no-other --no-gpu-entropy` (tools/r2_check.sh / r3_check.sh; round 3 adds `--no-configs "
-       "--no-measure-traffic`): the end-to-end pipeline legs (12 steps of 128 files through 8 lanes in groups "
+       "--no-pack --no-other --no-gpu-entropy --no-configs --no-measure-traffic --scale-proxy 0` (tools/r4_check.sh; rounds 2-3: "
+       "tools/archive/r2_check.sh, r3_check.sh without `--batch`): the end-to-end pipeline legs (12 steps of 128 files through 8 lanes in groups "
        "of 32, pageable then pinned files, plus set-up and warm-up batches) followed by the roofline leg "
        "(launches of the fused kernel on 48 resident images).  Under the pipeline several groups' kernels "
        "share the device, so their averages are longer than alone (hj_* alone: <name>_huffman_kernels.txt).", "",
