@@ -83,6 +83,7 @@ struct input_cache {
   unsigned long long tick = 0;
   int sight = 1;
   static constexpr size_t MIN_BYTES = 64u << 10;     // (below this a copy is cheaper than a registration can ever be)
+  static constexpr size_t MAX_TRACKED = 4096;        // addresses whose sights are being counted
   std::atomic<long long> n_registered{0}, n_evicted{0}, us_register{0}, n_in_place{0}, n_copied{0}, host_bytes{0};
   bool enabled() const { return cap > 0; }
   // make room for `bytes` by unregistering idle entries, oldest first (lock held)
@@ -118,6 +119,13 @@ struct input_cache {
         held -= it->second.bytes;
         map.erase(it);
         it = map.end();
+      }
+      // (addresses seen once and never again — a caller that decodes every file out of a fresh buffer — must not
+      // pile up: the sight counts of buffers that are not registered are dropped when there are too many)
+      if (it == map.end() && map.size() >= MAX_TRACKED) {
+        for (auto jt = map.begin(); jt != map.end(); ) {
+          if (!jt->second.registered && !jt->second.busy) jt = map.erase(jt); else ++jt;
+        }
       }
       entry &e = it != map.end() ? it->second : map[p];
       e.last = ++tick;
@@ -756,7 +764,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   for (int i = 0; i < m; i++) {
     jobv[i]->width = g.width; jobv[i]->height = g.height; jobv[i]->nplanes = g.nplanes;
     jobv[i]->h2d_bytes = up;
-    jobv[i]->host_bytes = in_place[(size_t)i] ? 0 : jobv[i]->size;
+    jobv[i]->host_bytes = in_place[(size_t)i] && !host_entropy ? 0 : jobv[i]->size;
     (in_place[(size_t)i] ? pl->inputs.n_in_place : pl->inputs.n_copied)++;
     pl->inputs.host_bytes += jobv[i]->host_bytes;
     jobv[i]->status = (damaged && jga_huff_image_error(l.hb, i) != 0) ? EXIT_FAILURE : EXIT_SUCCESS;
@@ -796,13 +804,12 @@ uint64_t geometry_key(const unsigned char *p, int size) {
 // files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
 // entropy stage and block decode of different groups overlap: about groups_per_lane groups
 // per lane, none below min_group_eq frame equivalents.
-// short_job = 2 (jga_pipeline_config): a geometry whose jobs would all fit ONE full group is not cut into
-// small groups — eight 16-file decodes keep the device busy 3.2 ms where one 128-file batch takes 1.8, each
-// paying the launches' latencies anew — but into two batches (the first 60 % of the files, then the rest:
-// the second one's tail after the last byte has landed is what the run waits for, so it is the shorter)
-// whose uploads arrive in pieces of ~12 MB: a piece's scan clean-up, start states and first synchronisation
-// round start when ITS bytes are there (jga_huff_set_option JGA_HUFF_OPT_PIECES).  `pieces[k]` = pieces
-// of group k's upload (0: one upload).
+// short_job = 2 (jga_pipeline_config; an experiment, measured slower: DESIGN.md §6): a geometry whose jobs would
+// all fit ONE full group is not cut into small groups — eight 16-file decodes keep the device busy 3.2 ms where
+// one 128-file batch takes 1.8, each paying the launches' latencies anew — but kept as one batch whose upload
+// arrives in pieces of ~12 MB: a piece's scan clean-up, start states and first synchronisation rounds start when
+// ITS bytes are there (jga_huff_set_option JGA_HUFF_OPT_PIECES).  `pieces[k]` = pieces of group k's upload
+// (0: one upload).
 struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; int short_job; };
 void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups,
  std::vector<int> *pieces = nullptr) {
@@ -855,13 +862,11 @@ void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<
     pieces->assign(groups.size(), 0);
     for (size_t k = 0; k < groups.size(); k++) {
       const uint64_t key = groups[k].empty() ? 0 : keys[(size_t)groups[k][0]];
-      const long long px = (long long)((key >> 48) & 0xffff)*(long long)((key >> 32) & 0xffff);
       if (pp.short_job != 2 || !key || pixels[key] > (long long)batch*frame) continue;
       long long bytes = 0;
       for (int i : groups[k]) bytes += jobs[i].size;
       const long long p = (bytes + (6ll << 20))/(12ll << 20);
       (*pieces)[k] = (int)(p < 2 ? (bytes >= (8ll << 20) ? 2 : 0) : p > 8 ? 8 : p);
-      (void)px;
     }
   }
 }
