@@ -769,6 +769,10 @@ def main():
                         "%d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
             # (the library's rule, csrc/pipeline.cpp: the smaller of the CPU grant and nthreads)
             "scan_cleanup": cleanup_route,
+            # (pageable files: with the clean-up on the device they go through the pipeline's input cache —
+            # registered at first sight inside the timed region, DMA'd where they lie afterwards; on the host
+            # every byte is read by a core anyway and nothing is registered: `host_cost`)
+            "input_cache_mb": args.input_cache_MB,
             "batch_per_gpu": PB, "pipeline_group": G, "distinct_images_per_gpu": len(jpegs),
             "images_timed_per_gpu": K * PB, "images_verified": page["verified"],
             "images_verified_pinned_ingest": pinn["verified"],
