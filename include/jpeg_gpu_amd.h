@@ -496,7 +496,9 @@ int jga_huff_last_assisted(const jga_huff_batch *b);
 /* After a jga_huff_decode that returned EXIT_FAILURE because of damaged DATA: how many images
  * of the batch were affected (0: the failure was something else), and image i's verdict (0 ok,
  * bit 0 "entropy data ended early" / inconsistent stream, bit 1 coefficient index outside the
- * block).  The planes of the other images are complete and correct. */
+ * block).  The planes of the other images are complete and correct; a damaged image's planes are
+ * UNDEFINED — whatever its lanes reached, over what the buffer held before (the decode clears nothing) —
+ * and must not be handed on (jga_pipeline_run zeroes the output of such a job). */
 int jga_huff_image_errors(const jga_huff_batch *b);
 int jga_huff_image_error(const jga_huff_batch *b, int i);
 const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
