@@ -546,8 +546,11 @@ enum {
   JGA_HUFF_OPT_SUB_BYTES = 1,      /* subsequence length: 32, 64, 128, 256, 512; 0 = by batch */
   JGA_HUFF_OPT_ASSIST_AFTER = 2,   /* rounds before the host walks unsettled stretches (default 12) */
   JGA_HUFF_OPT_SPECULATE = 3,      /* 0 / 1 = the tail is queued behind the first rounds, -1 = never */
-  JGA_HUFF_OPT_PIECES = 4,         /* prepare() uploads the batch in this many pieces and decode() starts the
-                                    * first round of each as it lands (0 / 1 = one upload) */
+  JGA_HUFF_OPT_PIECES = 4,         /* prepare() uploads the batch in this many pieces (2..16; 0 / 1 = one upload) on copy
+                                    * streams of the batch's own and queues, behind each piece's arrival, its scan
+                                    * clean-up, start states and first six synchronisation rounds; the next decode —
+                                    * on the SAME stream prepare() was given — goes on from there.  An experiment:
+                                    * same planes, measured slower on short jobs */
   JGA_HUFF_OPT_TRACE = 5           /* 1: what prepare() and decode() spent where, on stderr */
 };
 int jga_huff_set_option(jga_huff_batch *b, int option, int value);
