@@ -2,9 +2,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 (timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_baseline_configs.py -m gpu -q -x -k "pipeline or config4 or short_job or input_cache" 2>&1 | tail -3) > gpurun_out/r4s20.txt
-timeout 600 python tools/shard_sweep.py 128 "" "link_slots=-2" "link_slots=3" "link_slots=1" >> gpurun_out/r4s20.txt 2>&1
-timeout 600 python tools/shard_sweep.py 1024 "" "link_slots=-2" "link_slots=3" "link_slots=1" >> gpurun_out/r4s20.txt 2>&1
-for ls in 0 -2 0 -2; do echo -n "4K headline, link_slots=$ls: "; timeout 300 python - <<PY
+timeout 600 python tools/shard_sweep.py 128 "" "link_slots=-3" >> gpurun_out/r4s20.txt 2>&1
+timeout 600 python tools/shard_sweep.py 1024 "" "link_slots=-3" >> gpurun_out/r4s20.txt 2>&1
+for ls in 0 -3 0 -3; do echo -n "4K headline, link_slots=$ls: "; timeout 300 python - <<PY
 import sys, time
 sys.path.insert(0, ".")
 import torch
