@@ -494,7 +494,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     for (int i = 0; i < n; i++) sizes_v[(size_t)i] = prep[i].avail;
     const std::vector<int> cut = cut_pieces(sizes_v, b->pieces < 16 ? b->pieces : 16);
     const int np = (int)cut.size() - 1;
-    if (pieces_begin(b, np, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (pieces_begin(b, np, st) != EXIT_SUCCESS) { b->nimages = 0; return EXIT_FAILURE; }
     std::vector<int> piece_of((size_t)n);
     std::vector<std::atomic<int>> left((size_t)np);
     for (int k = 0; k < np; k++) {
