@@ -141,3 +141,29 @@ def test_product_reads_no_tuning_variable_from_the_environment():
             if n:
                 hits[f] = n
     assert hits == {"layout.c": 3, "libjpeg_vtbl.c": 1}, hits       # JGA_QUIET, JGA_CPU_BUDGET, jga_tune; JGA_LIBJPEG
+
+
+def test_tuning_variables_move_the_tuning_build_only(tmp_path):
+    """JGA_PIPE_MIN_GROUP (one of rounds 2-3's A/B variables) changes the plan jga_pipeline_plan_cfg makes in
+    libjpeg_gpu_amd_tuning.so and nothing at all in the product library (host logic: no GPU needed)."""
+    import sys
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import numpy as np
+from jpeg_gpu_amd import lib, synth
+d = bytearray(synth.synthetic_jpeg(16, 16, "420", quality=50, seed=1))
+i = d.index(b"\xff\xc0"); d[i + 5:i + 9] = bytes([1080 >> 8, 1080 & 255, 1920 >> 8, 1920 & 255])
+jobs = lib.Pipeline.make_jobs([bytes(d)] * 128)
+g = (C.c_int * 128)()
+c = lib.Pipeline.config(transport=2, depth=8, batch=32)
+print(lib.L.jga_pipeline_plan_cfg(C.byref(c), jobs, 128, g))
+""" % ROOT
+    out = {}
+    for name in ("libjpeg_gpu_amd.so", "libjpeg_gpu_amd_tuning.so"):
+        env = dict(os.environ, JGA_LIB_PATH=os.path.join(PKG, name), JGA_PIPE_MIN_GROUP="8")
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out[name] = int(r.stdout.strip().split()[-1])
+    assert out == {"libjpeg_gpu_amd.so": 8, "libjpeg_gpu_amd_tuning.so": 4}
