@@ -246,6 +246,31 @@ int jga_entropy_decode_pack(const unsigned char *buf, int size,
  const jga_geom *g, short *pack, long long pack_cap, int *index,
  long long *nwords, long long *plane_words);
 
+/* --- one frame in bands of MCU rows that decode independently (restart intervals:
+ *     reference src/xjpeg.c:593-629, DC predictors reset 612-618, DRI 412-420).  A frame whose
+ *     restart intervals tile its MCU rows (interval = a row of MCUs, or any length of which a whole
+ *     number fills some number of rows) is cut where intervals begin on a row boundary;
+ *     jga_band_file() writes one band as a baseline JPEG file of its own (the frame's marker
+ *     segments, SOF0 height = the band's rows, its entropy-coded bytes with the RSTn counters
+ *     renumbered from 0, EOI), which every decode entry point here — and the reference's
+ *     xjpeg_decode_image() — takes like any other file.  Its pixels are rows [y0, y0 + rows) of
+ *     the frame's, bit for bit.  One process per GPU decodes band `rank` of `world`; no collective.
+ *     A frame without restart markers is one band.  Host code only. ---- */
+typedef struct jga_band {
+  int index, count;            /* band `index` of `count` */
+  int mcu_row0, mcu_rows;      /* the MCU rows of the frame it covers */
+  int y0, rows;                /* = pixel rows [y0, y0 + rows) of the frame */
+  int first_interval;          /* number of its first restart interval in the frame */
+  int reserved_;
+  long scan_off, scan_bytes;   /* its entropy-coded bytes in the frame's file (no marker before or after) */
+} jga_band;
+/* bands[0 .. count): returns how many were made (fewer than `count` when the frame has fewer
+ * rows of MCUs that can stand alone), or < 0 (jga_last_error()). */
+int jga_band_plan(const unsigned char *file, long size, int count, jga_band *bands);
+/* The band as a file: returns its length (out == NULL: the length `out` must hold), or < 0. */
+long jga_band_file(const unsigned char *file, long size, const jga_band *band,
+ unsigned char *out, long cap);
+
 /* --- device stage: dequantise + row IDCT + column IDCT + level shift/clamp
  *     (+ chroma upsample + YCbCr->RGB) on coefficient planes RESIDENT IN HBM.
  *     Replaces the three GLSL passes res/horz_quant_yuv.fs.glsl:81-99,

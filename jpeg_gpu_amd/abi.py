@@ -105,6 +105,12 @@ class jga_plugin_config(C.Structure):
                 ("copy_team", C.c_int), ("reserved_", C.c_int)]
 
 
+class jga_band(C.Structure):
+    _fields_ = [("index", C.c_int), ("count", C.c_int), ("mcu_row0", C.c_int), ("mcu_rows", C.c_int),
+                ("y0", C.c_int), ("rows", C.c_int), ("first_interval", C.c_int), ("reserved_", C.c_int),
+                ("scan_off", C.c_long), ("scan_bytes", C.c_long)]
+
+
 JGA_HUFF_OPT_SUB_BYTES, JGA_HUFF_OPT_ASSIST_AFTER, JGA_HUFF_OPT_SPECULATE, JGA_HUFF_OPT_PIECES, \
     JGA_HUFF_OPT_TRACE = 1, 2, 3, 4, 5
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("JGA_LIB_PATH") or os.path.join(_HERE, "libjpeg_gpu_am
 EXPORTED = [
     "HIPJPEG_DECODE_CTX_VTBL", "JGA_LIBJPEG_DECODE_CTX_VTBL", "jga_libjpeg_available", "jga_version", "jga_last_error", "jga_image_init",
     "jga_image_zero", "jga_image_clear", "jga_geom_from_header", "jga_block_offset",
-    "jga_parse_header", "jga_entropy_decode", "jga_entropy_decode_pack",
+    "jga_parse_header", "jga_band_plan", "jga_band_file", "jga_entropy_decode", "jga_entropy_decode_pack",
     "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_idct_rgb_batch_dc", "jga_idct_yuv_batch_dc", "jga_huff_decode_split", "jga_kernel_name",
     "jga_index_count", "jga_unpack_batch", "jga_yuv_rgb_batch",
     "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
@@ -66,6 +66,9 @@ L.jga_block_offset.argtypes = [_G, _i, _i, _i]
 L.jga_block_offset.restype = _ll
 L.jga_parse_header.argtypes = [C.c_char_p, _i, C.POINTER(abi.jpeg_header)]
 L.jga_entropy_decode.argtypes = [C.c_char_p, _i, _G, _vp, _i]
+L.jga_band_plan.argtypes = [C.c_char_p, C.c_long, _i, C.POINTER(abi.jga_band)]
+L.jga_band_file.argtypes = [C.c_char_p, C.c_long, C.POINTER(abi.jga_band), _vp, C.c_long]
+L.jga_band_file.restype = C.c_long
 L.jga_entropy_decode_pack.argtypes = [C.c_char_p, _i, _G, _vp, _ll, _vp,
                                       C.POINTER(_ll), C.POINTER(_ll)]
 L.jga_idct_rgb_batch.argtypes = [_G, _i, _vp, _ll, _vp, _i, _vp, _ll, _vp]
@@ -177,6 +180,30 @@ def parse_header(data):
     h = abi.jpeg_header()
     check(L.jga_parse_header(bytes(data), len(data), C.byref(h)))
     return h
+
+
+def band_plan(data, count):
+    """The frame `data` in up to `count` bands of MCU rows that decode independently
+    (include/jpeg_gpu_amd.h: jga_band_plan): a list of abi.jga_band."""
+    data = bytes(data)
+    bands = (abi.jga_band * count)()
+    n = L.jga_band_plan(data, len(data), count, bands)
+    if n < 0:
+        raise JgaError(L.jga_last_error().decode())
+    return [bands[i] for i in range(n)]
+
+
+def band_file(data, band):
+    """Band `band` of the frame as a JPEG file of its own (jga_band_file)."""
+    data = bytes(data)
+    n = L.jga_band_file(data, len(data), C.byref(band), None, 0)
+    if n < 0:
+        raise JgaError(L.jga_last_error().decode())
+    out = C.create_string_buffer(n)
+    n = L.jga_band_file(data, len(data), C.byref(band), out, n)
+    if n < 0:
+        raise JgaError(L.jga_last_error().decode())
+    return out.raw[:n]
 
 
 def geom_from_header(h):

@@ -17,6 +17,22 @@ def shard_items(items, rank, world):
     return [items[i] for i in r]
 
 
+def band_of_rank(jpeg, rank, world):
+    """ONE frame across `world` GPUs (SURVEY.md §8e's note; include/jpeg_gpu_amd.h: jga_band_plan):
+    the band of MCU rows rank `rank` decodes, as (y0, rows, file) — a baseline JPEG file of its
+    own that any decode entry point takes; its pixels are rows [y0, y0 + rows) of the frame.  A
+    frame with fewer independent rows of MCUs than ranks (no restart markers: one) leaves the
+    last ranks without work: (0, 0, None).  No collective: the bands stay where they are decoded."""
+    from . import lib
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank/world %r/%r" % (rank, world))
+    bands = lib.band_plan(jpeg, world)
+    if rank >= len(bands):
+        return 0, 0, None
+    b = bands[rank]
+    return b.y0, b.rows, lib.band_file(jpeg, b)
+
+
 def aggregate_throughput(local_units, local_seconds, dist=None, device=None):
     """Whole-job units/s: sum of units over ranks / max of time over ranks.
 

@@ -189,6 +189,27 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
                             one_frame=_device_only(lib, files, 1, 2 if quick else 5)),
              "bit_exact_vs_oracle": ok,
              "cpu": cpu_rates(files, w, h, cpu_frames)}
+        if ri:
+            # (SURVEY §8e's note) the same frame in 8 bands of MCU rows, one per GPU: what ONE of them does —
+            # finds its band (host: a pass over the file for the restart markers), writes it as a file of
+            # its own and decodes that; band 3 of 8 here.  No collective: the rows stay on their GPUs
+            t0 = time.perf_counter()
+            for _ in range(3):
+                y0, rows, bf = shard.band_of_rank(files[0], 3, 8)
+            cut = (time.perf_counter() - t0) / 3
+            whole_rgb = orc.decode_rgb(files[0])[1] if not quick else None
+            blat = _pipeline_latency(lib, abi, bf, nthreads)
+            e["band_3_of_8"] = {"rows": [y0, rows], "file_bytes": len(bf), "host_cut_ms": round(cut * 1e3, 3),
+                                "to_rgb_hbm": {"latency_ms": round(blat * 1e3, 3)},
+                                "to_host_pixels": _plugin(lib, abi, bf, 3 if quick else 10),
+                                "device": {"one_frame": _device_only(lib, [bf], 1, 2 if quick else 5)}}
+            if whole_rgb is not None:
+                with lib.Decoder(bf) as d:
+                    d.read_header()
+                    d.init_image()
+                    d.decode(abi.JPEG_DECODE_RGB)
+                    e["band_3_of_8"]["bit_exact_vs_oracle_rows_of_the_frame"] = bool(
+                        (d.pixels() == whole_rgb[y0:y0 + rows]).all())
         out[key] = e
         say("configs: %s done in %.1f s" % (key, time.perf_counter() - t_cfg))
 
