@@ -8,9 +8,10 @@ N=${1:-3000}; SEED=${2:-1}
 F="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
 gcc -std=gnu11 $F -c $C/entropy.c -o $W/entropy.o
 gcc -std=gnu11 $F -c $C/layout.c -o $W/layout.o
+gcc -std=gnu11 $F -c $C/band.c -o $W/band.o
 g++ -std=c++17 -mavx2 $F -I$C -c $C/huff_prepare.cpp -o $W/huff_prepare.o
 g++ -std=c++17 $F -I$C -c $ROOT/tools/asan_driver.cpp -o $W/drv.o
-g++ -fsanitize=address,undefined $W/drv.o $W/entropy.o $W/layout.o $W/huff_prepare.o -o $W/drv
+g++ -fsanitize=address,undefined $W/drv.o $W/entropy.o $W/layout.o $W/band.o $W/huff_prepare.o -o $W/drv
 mkdir -p $W/corpus
 python3 - "$ROOT" "$W/corpus" "$N" "$SEED" <<'PY'
 import sys
