@@ -355,13 +355,24 @@ int jga_scan_describe(const unsigned char *buf, int size, jga_scan_desc *d) {
 
 /* ---- bit reader --------------------------------------------------------- */
 
+/* The scan is read one restart interval at a time from a CLEAN copy: the bytes up to the next
+ * marker with the stuffed zeros (FF 00) and fill bytes (FF FF ..) taken out (load_interval), 280
+ * zero bytes behind them.  The per-symbol path then refills its window without looking at what
+ * it loads — no "is there an FF among the next eight bytes" test, no marker state — and running
+ * off the data is found by arithmetic afterwards (bits consumed against bits there were).  The
+ * copy costs a pass of memchr + memcpy over runs of ~256 bytes, 2 % of what the decode takes. */
 typedef struct bitreader {
-  uint64_t bits;       /* MSB-aligned window; only the top nbits are promised */
+  uint64_t bits;       /* MSB-aligned window; the top nbits are accounted for, those below are
+                          look-ahead (the same stream bits the next refill ORs in again) */
   int nbits;
-  const uint8_t *p, *end;
-  int marker;          /* marker byte that stopped the refill, 0 = none */
-  long zeros;          /* pad bytes fed after the data ran out */
+  const uint8_t *p;    /* next byte of the clean interval to load */
+  const uint8_t *base, *lim;   /* the clean interval; zeros behind it */
+  /* where the interval came from */
+  const uint8_t *raw, *raw_end;      /* raw: the marker that ended it (or raw_end) */
+  int marker;          /* that marker's second byte, 0 = the buffer ended without one */
+  uint8_t *clean;      /* the copy's buffer (raw_end - raw0 + CLEAN_PAD bytes) */
 } bitreader;
+#define CLEAN_PAD 280  /* a block takes at most 64 x 31 bits = 248 bytes, a refill reads 8 */
 
 static inline uint64_t load_be64(const uint8_t *p) {
   uint64_t w;
@@ -369,42 +380,45 @@ static inline uint64_t load_be64(const uint8_t *p) {
   return __builtin_bswap64(w);
 }
 
-static void refill_slow(bitreader *br) {
-  br->bits &= br->nbits ? ~(uint64_t)0 << (64 - br->nbits) : 0;
-  while (br->nbits <= 56) {
-    unsigned b;
-    if (br->marker || br->p >= br->end) {
-      if (!br->marker) br->marker = 0xD9;          /* ran off the buffer */
-      br->nbits += 8;
-      br->zeros++;
-      continue;
-    }
-    b = *br->p;
-    if (b == 0xFF) {
-      unsigned b2 = br->p + 1 < br->end ? br->p[1] : 0xD9;
-      if (b2 == 0x00) br->p += 2;                  /* stuffed zero */
-      else if (b2 == 0xFF) { br->p++; continue; }  /* fill byte */
-      else { br->marker = (int)b2; continue; }     /* stay on the FF */
-    }
-    else br->p++;
-    br->bits |= (uint64_t)b << (56 - br->nbits);
-    br->nbits += 8;
-  }
+/* Bits of the interval consumed so far exceed the bits it has: the decode ran into the padding. */
+static inline int ran_past_end(const bitreader *br) {
+  return 8*(br->p - br->base) - br->nbits > 8*(br->lim - br->base);
 }
 
-/* After this at least 57 bits are available (real or padding). */
-static inline void refill(bitreader *br) {
-  if (br->p + 8 <= br->end && !br->marker) {
-    uint64_t w = load_be64(br->p);
-    uint64_t x = ~w;
-    if (!((x - 0x0101010101010101ULL) & ~x & 0x8080808080808080ULL)) {
-      br->bits |= w >> br->nbits;
-      br->p += (63 - br->nbits) >> 3;
-      br->nbits |= 56;
-      return;
-    }
+/* Clean copy of the entropy-coded bytes from `from` up to the next marker.  The rules are T.81
+ * B.1.1.5 / F.1.2.3 as the reference's reader applies them (src/xjpeg.c:151-186): FF 00 is a data
+ * byte FF, FF FF.. is fill before a marker (or before more data), FF xx anything else is a
+ * marker — the interval ends ON its FF.  A lone FF as the buffer's last byte counts as the end
+ * of the image. */
+static void load_interval(bitreader *br, const uint8_t *from) {
+  const uint8_t *p = from, *end = br->raw_end;
+  uint8_t *o = br->clean;
+  br->marker = 0;
+  while (p < end) {
+    const uint8_t *q = (const uint8_t *)memchr(p, 0xFF, (size_t)(end - p));
+    if (!q) q = end;
+    memcpy(o, p, (size_t)(q - p));
+    o += q - p;
+    p = q;
+    if (p >= end) break;
+    if (p + 1 >= end) { br->marker = 0xD9; break; }          /* FF, then nothing */
+    if (p[1] == 0x00) { *o++ = 0xFF; p += 2; }
+    else if (p[1] == 0xFF) p++;
+    else { br->marker = p[1]; break; }
   }
-  refill_slow(br);
+  memset(o, 0, CLEAN_PAD);
+  br->raw = p;
+  br->base = br->p = br->clean;
+  br->lim = o;
+  br->bits = 0;
+  br->nbits = 0;
+}
+
+/* After this at least 56 bits are accounted for (real or padding); at most 63. */
+static inline void refill(bitreader *br) {
+  br->bits |= load_be64(br->p) >> br->nbits;
+  br->p += (63 - br->nbits) >> 3;
+  br->nbits |= 56;
 }
 
 #define PEEK(br, n) ((unsigned)((br)->bits >> (64 - (n))))
@@ -453,7 +467,9 @@ static inline int extend_bits(unsigned v, int s) {
 static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
  const unsigned short *q, short *pred, short *blk, scan_out *so, int stage) {
   int s, k;
-  refill(br);                                      /* >= 57 bits: DC code + magnitude <= 27 */
+  /* (a block reads at most 248 + 8 bytes past this: inside the padding) */
+  if (br->p > br->lim + 8) return jga_fail("Error, entropy data ended early.");
+  refill(br);                                      /* >= 56 bits: DC code + magnitude <= 31 */
   s = huff_symbol(br, dc);
   if (s < 0 || s > 15) return jga_fail("Error invalid DC code.");
   if (s) {
@@ -468,75 +484,71 @@ static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
     memset(blk, 0, 64*sizeof(short));
     blk[0] = stage == JGA_STAGE_DCT ? (short)(*pred*q[0]) : *pred;
   }
+  /* Two symbols per refill: it leaves >= 56 bits, a symbol found in the table takes at most
+     FAST_BITS + 15 = 25 and any symbol at most 31 — so the second one has its 25 whatever the
+     first was, and a long code (rare) refills for itself. */
   for (k = 1; k < 64;) {
-    unsigned e;
-    int rs, r, v;
-    if (br->nbits < 32) refill(br);                /* a symbol takes at most 16 + 15 bits */
-    e = ac->fast[PEEK(br, FAST_BITS)];
-    if (__builtin_expect(e != 0, 1)) {
-      /* code and magnitude leave the window in ONE shift (the next look-up waits for nothing
-         else); the value is read from the bits as they were */
-      const uint64_t w = br->bits << ((e >> 8) & 255);
-      rs = (int)(e >> 16);
-      r = rs >> 4;
-      s = rs & 15;
-      SKIP(br, e & 255);
-      v = s ? extend_bits((unsigned)(w >> (64 - s)), s) : 0;
-    }
-    else {
-      rs = huff_symbol(br, ac);
-      if (rs < 0) return jga_fail("Error invalid AC code.");
-      r = rs >> 4;
-      s = rs & 15;
-      v = 0;
-      if (s) {
-        v = extend_bits(PEEK(br, s), s);
-        SKIP(br, s);
+    int half;
+    refill(br);
+    for (half = 0; half < 2 && k < 64; half++) {
+      unsigned e;
+      int rs, r, v;
+      e = ac->fast[PEEK(br, FAST_BITS)];
+      if (__builtin_expect(e != 0, 1)) {
+        /* code and magnitude leave the window in ONE shift (the next look-up waits for nothing
+           else); the value is read from the bits as they were */
+        const uint64_t w = br->bits << ((e >> 8) & 255);
+        rs = (int)(e >> 16);
+        r = rs >> 4;
+        s = rs & 15;
+        SKIP(br, e & 255);
+        v = s ? extend_bits((unsigned)(w >> (64 - s)), s) : 0;
       }
-    }
-    if (__builtin_expect(s == 0, 0)) {
-      if (rs == 0) {                               /* EOB */
-        if (stage == JGA_STAGE_PACK) so->pack[so->nwords++] = 0;
-        break;
+      else {
+        refill(br);
+        rs = huff_symbol(br, ac);
+        if (rs < 0) return jga_fail("Error invalid AC code.");
+        r = rs >> 4;
+        s = rs & 15;
+        v = 0;
+        if (s) {
+          v = extend_bits(PEEK(br, s), s);
+          SKIP(br, s);
+        }
       }
-      v = 0;                                       /* ZRL (or any run without a value): r + 1 zeros, xjpeg.c:507-508 */
+      if (__builtin_expect(s == 0, 0)) {
+        if (rs == 0) {                               /* EOB */
+          if (stage == JGA_STAGE_PACK) so->pack[so->nwords++] = 0;
+          return EXIT_SUCCESS;
+        }
+        v = 0;                                       /* ZRL (or any run without a value): r + 1 zeros, xjpeg.c:507-508 */
+      }
+      k += r;
+      if (k > 63) return jga_fail("Error indexing outside block.");
+      if (stage == JGA_STAGE_PACK) {
+        so->pack[so->nwords++] = (short)((r << 12) | (v & 0xfff));
+      }
+      else if (s) {
+        const int n = DEZZ[k];
+        blk[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v;
+      }
+      k++;
     }
-    k += r;
-    if (k > 63) return jga_fail("Error indexing outside block.");
-    if (stage == JGA_STAGE_PACK) {
-      so->pack[so->nwords++] = (short)((r << 12) | (v & 0xfff));
-    }
-    else if (s) {
-      const int n = DEZZ[k];
-      blk[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v;
-    }
-    k++;
   }
   return EXIT_SUCCESS;
 }
 
 static int next_restart(bitreader *br, int expect) {
-  if (br->zeros*8 > br->nbits) return jga_fail("Error, entropy data ended early.");
-  if (!br->marker) {
-    /* tolerate stray bytes before the marker */
-    while (br->p + 1 < br->end
-     && !(br->p[0] == 0xFF && br->p[1] != 0x00 && br->p[1] != 0xFF)) {
-      br->p++;
-    }
-    if (br->p + 1 >= br->end) return jga_fail("Error, expected to find marker.");
-    br->marker = br->p[1];
-  }
+  if (ran_past_end(br)) return jga_fail("Error, entropy data ended early.");
+  /* (bytes of the interval the decode did not need are tolerated, as stray bytes before the marker) */
+  if (!br->marker) return jga_fail("Error, expected to find marker.");
   if (br->marker != 0xD0 + (expect & 7)) {
     if (br->marker >= 0xD0 && br->marker <= 0xD7) {
       return jga_fail("Error invalid RST counter in marker.");
     }
     return jga_fail("Error, unknown marker found in scan.");
   }
-  br->p += 2;
-  br->bits = 0;
-  br->nbits = 0;
-  br->marker = 0;
-  br->zeros = 0;
+  load_interval(br, br->raw + 2);
   return EXIT_SUCCESS;
 }
 
@@ -553,59 +565,83 @@ static int check_geom(const parser *ps, const jga_geom *g) {
   return EXIT_SUCCESS;
 }
 
+#define MCU_SLOTS_MAX 48          /* 4 x 4 blocks of each of three components */
+typedef struct mcu_slot {
+  const htab *dc, *ac;
+  const unsigned short *q;
+  int comp, sbx, sby, step;
+  long long at;                    /* offset of the slot's block in the planes (PACK: in the index) */
+} mcu_slot;
+
 static int decode_scan(parser *ps, const jga_geom *g, scan_out *so,
- const int stage) {
+ const int stage, uint8_t *clean) {
   bitreader br;
   short pred[3] = {0, 0, 0};
   short scratch[64];
-  int mbx, mby, i, sbx, sby;
+  int mbx, mby, i, sbx, sby, nslots = 0;
   long mcus = 0, total = (long)g->nhmb*g->nvmb;
-  int rst = 0;
+  int rst = 0, to_restart;
   long long index_base[3];
+  mcu_slot slots[MCU_SLOTS_MAX];
   memset(&br, 0, sizeof(br));
-  br.p = ps->buf + ps->pos;
-  br.end = ps->buf + ps->size;
+  br.clean = clean;
+  br.raw_end = ps->buf + ps->size;
+  load_interval(&br, ps->buf + ps->pos);
   index_base[0] = 0;
   for (i = 1; i < 3; i++) {
     index_base[i] = index_base[i - 1]
      + (long long)(g->plane[i - 1].hblocks << g->plane[i - 1].xdec)
      *g->plane[i - 1].cstride;
   }
-  for (mby = 0; mby < g->nvmb; mby++) {
-    for (mbx = 0; mbx < g->nhmb; mbx++) {
-      for (i = 0; i < ps->ncomps; i++) {
-        const comp_info *c = &ps->comp[i];
-        const htab *dc = &ps->dc[c->td], *ac = &ps->ac[c->ta];
-        const unsigned short *q = ps->quant[c->tq].tbl;
-        for (sby = 0; sby < c->vs; sby++) {
-          for (sbx = 0; sbx < c->hs; sbx++) {
-            int bx = mbx*c->hs + sbx, by = mby*c->vs + sby;
-            short *blk = scratch;
-            if (stage == JGA_STAGE_PACK) {
-              so->index[index_base[i] + (long long)by*g->plane[i].hblocks + bx] =
-               (int)so->nwords;
-            }
-            else blk = so->coef + jga_block_offset(g, i, bx, by);
-            {
-              const long long w0 = so->nwords;
-              if (decode_block(&br, dc, ac, q, &pred[i], blk, so, stage)
-               != EXIT_SUCCESS) {
-                return EXIT_FAILURE;
-              }
-              so->plane_words[i] += so->nwords - w0;
-            }
-          }
-        }
-      }
-      mcus++;
-      if (ps->restart_interval && mcus % ps->restart_interval == 0
-       && mcus < total) {
-        if (next_restart(&br, rst++) != EXIT_SUCCESS) return EXIT_FAILURE;
-        pred[0] = pred[1] = pred[2] = 0;
+  /* the blocks of an MCU in scan order (xjpeg.c:461-472), each with its tables; where a slot's
+     block lies is worked out once per row of MCUs and stepped from MCU to MCU */
+  for (i = 0; i < ps->ncomps; i++) {
+    const comp_info *c = &ps->comp[i];
+    for (sby = 0; sby < c->vs; sby++) {
+      for (sbx = 0; sbx < c->hs; sbx++) {
+        if (nslots >= MCU_SLOTS_MAX) return jga_fail("Unsupported sampling: more than %d blocks per MCU", MCU_SLOTS_MAX);
+        slots[nslots].dc = &ps->dc[c->td];
+        slots[nslots].ac = &ps->ac[c->ta];
+        slots[nslots].q = ps->quant[c->tq].tbl;
+        slots[nslots].comp = i;
+        slots[nslots].sbx = sbx;
+        slots[nslots].sby = sby;
+        nslots++;
       }
     }
   }
-  if (br.zeros*8 > br.nbits) return jga_fail("Error, entropy data ended early.");
+  to_restart = ps->restart_interval;
+  for (mby = 0; mby < g->nvmb; mby++) {
+    for (i = 0; i < nslots; i++) {
+      const comp_info *c = &ps->comp[slots[i].comp];
+      const int by = mby*c->vs + slots[i].sby;
+      slots[i].at = stage == JGA_STAGE_PACK
+       ? index_base[slots[i].comp] + (long long)by*g->plane[slots[i].comp].hblocks + slots[i].sbx
+       : jga_block_offset(g, slots[i].comp, slots[i].sbx, by);
+      slots[i].step = stage == JGA_STAGE_PACK ? c->hs : c->hs*64;
+    }
+    for (mbx = 0; mbx < g->nhmb; mbx++) {
+      for (i = 0; i < nslots; i++) {
+        mcu_slot *sl = &slots[i];
+        short *blk = scratch;
+        const long long w0 = so->nwords;
+        if (stage == JGA_STAGE_PACK) so->index[sl->at] = (int)so->nwords;
+        else blk = so->coef + sl->at;
+        sl->at += sl->step;
+        if (decode_block(&br, sl->dc, sl->ac, sl->q, &pred[sl->comp], blk, so, stage) != EXIT_SUCCESS) {
+          return EXIT_FAILURE;
+        }
+        if (stage == JGA_STAGE_PACK) so->plane_words[sl->comp] += so->nwords - w0;
+      }
+      mcus++;
+      if (ps->restart_interval && --to_restart == 0 && mcus < total) {
+        if (next_restart(&br, rst++) != EXIT_SUCCESS) return EXIT_FAILURE;
+        pred[0] = pred[1] = pred[2] = 0;
+        to_restart = ps->restart_interval;
+      }
+    }
+  }
+  if (ran_past_end(&br)) return jga_fail("Error, entropy data ended early.");
   return EXIT_SUCCESS;
 }
 
@@ -617,12 +653,16 @@ static int run_decode(const unsigned char *buf, int size, const jga_geom *g,
   rc = parse_to_scan(ps, buf, size);
   if (rc == EXIT_SUCCESS) rc = check_geom(ps, g);
   if (rc == EXIT_SUCCESS) {
+    /* room for the clean copy of the longest interval there can be: everything behind SOS */
+    uint8_t *clean = (uint8_t *)malloc((size_t)(ps->size - ps->pos) + CLEAN_PAD);
+    if (!clean) rc = jga_fail("Out of memory");
     /* literal stage arguments so each loop is specialised */
-    switch (so->stage) {
-      case JGA_STAGE_PACK : rc = decode_scan(ps, g, so, JGA_STAGE_PACK); break;
-      case JGA_STAGE_QUANT : rc = decode_scan(ps, g, so, JGA_STAGE_QUANT); break;
-      default : rc = decode_scan(ps, g, so, JGA_STAGE_DCT); break;
+    else switch (so->stage) {
+      case JGA_STAGE_PACK : rc = decode_scan(ps, g, so, JGA_STAGE_PACK, clean); break;
+      case JGA_STAGE_QUANT : rc = decode_scan(ps, g, so, JGA_STAGE_QUANT, clean); break;
+      default : rc = decode_scan(ps, g, so, JGA_STAGE_DCT, clean); break;
     }
+    free(clean);
   }
   free(ps);
   return rc;
