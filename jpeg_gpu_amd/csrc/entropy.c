@@ -54,7 +54,7 @@ typedef struct parser {
 
 /* zig-zag position -> natural index (T.81 Fig. A.6); a constant, so the parsing threads of
  * the pipeline and of jga_huff_prepare share it without initialisation order */
-static const int DEZZ[64] = {
+static const uint8_t DEZZ[64] = {
    0,  1,  8, 16,  9,  2,  3, 10,
   17, 24, 32, 25, 18, 11,  4,  5,
   12, 19, 26, 33, 40, 48, 41, 34,
@@ -374,14 +374,14 @@ typedef struct bitreader {
 } bitreader;
 #define CLEAN_PAD 280  /* a block takes at most 64 x 31 bits = 248 bytes, a refill reads 8 */
 
-static inline uint64_t load_be64(const uint8_t *p) {
+static inline __attribute__((always_inline)) uint64_t load_be64(const uint8_t *p) {
   uint64_t w;
   memcpy(&w, p, 8);
   return __builtin_bswap64(w);
 }
 
 /* Bits of the interval consumed so far exceed the bits it has: the decode ran into the padding. */
-static inline int ran_past_end(const bitreader *br) {
+static inline __attribute__((always_inline)) int ran_past_end(const bitreader *br) {
   return 8*(br->p - br->base) - br->nbits > 8*(br->lim - br->base);
 }
 
@@ -415,7 +415,7 @@ static void load_interval(bitreader *br, const uint8_t *from) {
 }
 
 /* After this at least 56 bits are accounted for (real or padding); at most 63. */
-static inline void refill(bitreader *br) {
+static inline __attribute__((always_inline)) void refill(bitreader *br) {
   br->bits |= load_be64(br->p) >> br->nbits;
   br->p += (63 - br->nbits) >> 3;
   br->nbits |= 56;
@@ -425,7 +425,7 @@ static inline void refill(bitreader *br) {
 #define SKIP(br, n) ((br)->bits <<= (n), (br)->nbits -= (n))
 
 /* Decode one Huffman symbol; needs >= 16 bits in the window. */
-static inline int huff_symbol(bitreader *br, const htab *h) {
+static inline __attribute__((always_inline)) int huff_symbol(bitreader *br, const htab *h) {
   unsigned e = h->fast[PEEK(br, FAST_BITS)];
   unsigned code;
   int len;
@@ -454,7 +454,7 @@ typedef struct scan_out {
 
 /* Sign extension of an s-bit magnitude (T.81 F.2.2.1 EXTEND), without a branch: values whose
  * top bit is clear are negative, v - (2^s - 1). */
-static inline int extend_bits(unsigned v, int s) {
+static inline __attribute__((always_inline)) int extend_bits(unsigned v, int s) {
   return (int)v + (int)(((v >> (s - 1)) - 1u) & (unsigned)(1 - (1 << s)));
 }
 
@@ -464,7 +464,7 @@ static inline int extend_bits(unsigned v, int s) {
  * window.  The branches left are the ones that go the same way almost every time (window
  * low, code longer than FAST_BITS, end of block): the earlier version chose between a
  * combined code+value table and this path on every symbol, a coin toss on busy images. */
-static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
+static inline __attribute__((always_inline)) int decode_block(bitreader *br, const htab *dc, const htab *ac,
  const unsigned short *q, short *pred, short *blk, scan_out *so, int stage) {
   int s, k;
   /* (a block reads at most 248 + 8 bytes past this: inside the padding) */
@@ -487,54 +487,58 @@ static inline int decode_block(bitreader *br, const htab *dc, const htab *ac,
   /* Two symbols per refill: it leaves >= 56 bits, a symbol found in the table takes at most
      FAST_BITS + 15 = 25 and any symbol at most 31 — so the second one has its 25 whatever the
      first was, and a long code (rare) refills for itself. */
+#define AC_SYMBOL() do { \
+    unsigned e; \
+    int rs, r, v; \
+    e = ac->fast[PEEK(br, FAST_BITS)]; \
+    if (__builtin_expect(e != 0, 1)) { \
+      /* code and magnitude leave the window in ONE shift (the next look-up waits for nothing \
+         else); the value is read from the bits as they were */ \
+      const uint64_t w = br->bits << ((e >> 8) & 255); \
+      rs = (int)(e >> 16); \
+      r = rs >> 4; \
+      s = rs & 15; \
+      SKIP(br, e & 255); \
+      /* (EXTEND from the window itself: its top bit is the magnitude's first, 1 = positive) */ \
+      v = s ? (int)(w >> (64 - s)) + ((int)~((int64_t)w >> 63) & (1 - (1 << s))) : 0; \
+    } \
+    else { \
+      refill(br); \
+      rs = huff_symbol(br, ac); \
+      if (rs < 0) return jga_fail("Error invalid AC code."); \
+      r = rs >> 4; \
+      s = rs & 15; \
+      v = 0; \
+      if (s) { \
+        v = extend_bits(PEEK(br, s), s); \
+        SKIP(br, s); \
+      } \
+    } \
+    if (__builtin_expect(s == 0, 0)) { \
+      if (rs == 0) {                               /* EOB */ \
+        if (stage == JGA_STAGE_PACK) so->pack[so->nwords++] = 0; \
+        return EXIT_SUCCESS; \
+      } \
+      v = 0;                                       /* ZRL (or any run without a value): r + 1 zeros, xjpeg.c:507-508 */ \
+    } \
+    k += r; \
+    if (k > 63) return jga_fail("Error indexing outside block."); \
+    if (stage == JGA_STAGE_PACK) { \
+      so->pack[so->nwords++] = (short)((r << 12) | (v & 0xfff)); \
+    } \
+    else if (s) { \
+      const int n = DEZZ[k]; \
+      blk[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v; \
+    } \
+    k++; \
+  } while (0)
   for (k = 1; k < 64;) {
-    int half;
     refill(br);
-    for (half = 0; half < 2 && k < 64; half++) {
-      unsigned e;
-      int rs, r, v;
-      e = ac->fast[PEEK(br, FAST_BITS)];
-      if (__builtin_expect(e != 0, 1)) {
-        /* code and magnitude leave the window in ONE shift (the next look-up waits for nothing
-           else); the value is read from the bits as they were */
-        const uint64_t w = br->bits << ((e >> 8) & 255);
-        rs = (int)(e >> 16);
-        r = rs >> 4;
-        s = rs & 15;
-        SKIP(br, e & 255);
-        v = s ? extend_bits((unsigned)(w >> (64 - s)), s) : 0;
-      }
-      else {
-        refill(br);
-        rs = huff_symbol(br, ac);
-        if (rs < 0) return jga_fail("Error invalid AC code.");
-        r = rs >> 4;
-        s = rs & 15;
-        v = 0;
-        if (s) {
-          v = extend_bits(PEEK(br, s), s);
-          SKIP(br, s);
-        }
-      }
-      if (__builtin_expect(s == 0, 0)) {
-        if (rs == 0) {                               /* EOB */
-          if (stage == JGA_STAGE_PACK) so->pack[so->nwords++] = 0;
-          return EXIT_SUCCESS;
-        }
-        v = 0;                                       /* ZRL (or any run without a value): r + 1 zeros, xjpeg.c:507-508 */
-      }
-      k += r;
-      if (k > 63) return jga_fail("Error indexing outside block.");
-      if (stage == JGA_STAGE_PACK) {
-        so->pack[so->nwords++] = (short)((r << 12) | (v & 0xfff));
-      }
-      else if (s) {
-        const int n = DEZZ[k];
-        blk[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v;
-      }
-      k++;
-    }
+    AC_SYMBOL();
+    if (k >= 64) break;
+    AC_SYMBOL();
   }
+#undef AC_SYMBOL
   return EXIT_SUCCESS;
 }
 
@@ -573,7 +577,7 @@ typedef struct mcu_slot {
   long long at;                    /* offset of the slot's block in the planes (PACK: in the index) */
 } mcu_slot;
 
-static int decode_scan(parser *ps, const jga_geom *g, scan_out *so,
+static inline __attribute__((always_inline)) int decode_scan(parser *ps, const jga_geom *g, scan_out *so,
  const int stage, uint8_t *clean) {
   bitreader br;
   short pred[3] = {0, 0, 0};
@@ -645,6 +649,20 @@ static int decode_scan(parser *ps, const jga_geom *g, scan_out *so,
   return EXIT_SUCCESS;
 }
 
+/* The scan loop once per stage (a literal stage: the per-symbol path holds no stage test) and once
+ * more per stage for CPUs with BMI2 — shifts by a register that need not be %cl, which the
+ * per-symbol path is made of (a third fewer instructions). */
+#define SCAN_VARIANT(name, attr, stage) \
+  attr static int name(parser *ps, const jga_geom *g, scan_out *so, uint8_t *clean) { \
+    return decode_scan(ps, g, so, stage, clean); \
+  }
+SCAN_VARIANT(scan_pack, , JGA_STAGE_PACK)
+SCAN_VARIANT(scan_quant, , JGA_STAGE_QUANT)
+SCAN_VARIANT(scan_dct, , JGA_STAGE_DCT)
+SCAN_VARIANT(scan_pack_bmi2, __attribute__((target("bmi,bmi2"))), JGA_STAGE_PACK)
+SCAN_VARIANT(scan_quant_bmi2, __attribute__((target("bmi,bmi2"))), JGA_STAGE_QUANT)
+SCAN_VARIANT(scan_dct_bmi2, __attribute__((target("bmi,bmi2"))), JGA_STAGE_DCT)
+
 static int run_decode(const unsigned char *buf, int size, const jga_geom *g,
  scan_out *so) {
   parser *ps = (parser *)malloc(sizeof(parser));
@@ -656,11 +674,17 @@ static int run_decode(const unsigned char *buf, int size, const jga_geom *g,
     /* room for the clean copy of the longest interval there can be: everything behind SOS */
     uint8_t *clean = (uint8_t *)malloc((size_t)(ps->size - ps->pos) + CLEAN_PAD);
     if (!clean) rc = jga_fail("Out of memory");
-    /* literal stage arguments so each loop is specialised */
+#ifndef JGA_ENTROPY_NO_BMI2     /* (defined by the differential fuzz to run the plain variants on a CPU that has BMI2) */
+    else if (__builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi")) switch (so->stage) {
+      case JGA_STAGE_PACK : rc = scan_pack_bmi2(ps, g, so, clean); break;
+      case JGA_STAGE_QUANT : rc = scan_quant_bmi2(ps, g, so, clean); break;
+      default : rc = scan_dct_bmi2(ps, g, so, clean); break;
+    }
+#endif
     else switch (so->stage) {
-      case JGA_STAGE_PACK : rc = decode_scan(ps, g, so, JGA_STAGE_PACK, clean); break;
-      case JGA_STAGE_QUANT : rc = decode_scan(ps, g, so, JGA_STAGE_QUANT, clean); break;
-      default : rc = decode_scan(ps, g, so, JGA_STAGE_DCT, clean); break;
+      case JGA_STAGE_PACK : rc = scan_pack(ps, g, so, clean); break;
+      case JGA_STAGE_QUANT : rc = scan_quant(ps, g, so, clean); break;
+      default : rc = scan_dct(ps, g, so, clean); break;
     }
     free(clean);
   }

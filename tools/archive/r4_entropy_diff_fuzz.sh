@@ -1,12 +1,12 @@
 #!/bin/bash
 # Differential fuzz of the host entropy stage across a rewrite: csrc/entropy.c of commit $1 against the tree's, on
 # randomly damaged files — the same accept / reject decision, and for accepted files the same QUANT planes, DCT
-# planes and PACK words + index.  Usage: tools/archive/r4_entropy_diff_fuzz.sh <old commit> [nfiles] [seed]
+# planes and PACK words + index.  NEWFLAGS=-DJGA_ENTROPY_NO_BMI2 runs the variants for CPUs without BMI2.  Usage: tools/archive/r4_entropy_diff_fuzz.sh <old commit> [nfiles] [seed]
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd); C=$ROOT/jpeg_gpu_amd/csrc; W=$(mktemp -d)
 git -C $ROOT show $1:jpeg_gpu_amd/csrc/entropy.c > $W/entropy_old.c
 gcc -std=gnu11 -O2 -fPIC -shared -I$C $W/entropy_old.c $C/layout.c -o $W/old.so 2>/dev/null
-gcc -std=gnu11 -O2 -fPIC -shared -I$C $C/entropy.c $C/layout.c -o $W/new.so 2>/dev/null
+gcc -std=gnu11 -O2 -fPIC -shared $NEWFLAGS -I$C $C/entropy.c $C/layout.c -o $W/new.so 2>/dev/null
 JGA_QUIET=1 PYTHONPATH=$ROOT python3 - $W ${2:-3000} ${3:-1} <<'PY'
 import ctypes as C, sys, numpy as np
 from jpeg_gpu_amd import lib, synth, abi
