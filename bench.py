@@ -724,14 +724,18 @@ def main():
         # Huffman threads also block on their slot's event: ~3 per granted CPU measured best
         # (profiles/r2_t0_sweep.txt: 32-48 threads on a 16-CPU grant, fewer AND more are slower)
         nthr = min(my_cpus, 3 * budget) if quota else max(1, min(my_cpus, 96))
-        n0 = max(96, 4 * nthr)
+        # (long enough that the cgroup's burst allowance is spent: 192 images read 13-16 Gpixel/s with
+        #  21-26 CPUs busy on a 16-CPU grant, 768 the sustained 10-11: profiles/r4_north_star_probe.txt)
+        n0 = max(384, 16 * nthr)
         pl0 = lib.Pipeline(device=gpu, nthreads=nthr, out=abi.JPEG_DECODE_RGB,
                            copy_back=False, transport=0)
         j_warm, j_run = lib.Pipeline.make_jobs(cyc(2 * nthr)), lib.Pipeline.make_jobs(cyc(n0, 3))
         pl0.run_jobs(j_warm)
         fence()
+        c0 = sum(os.times()[:2])
         t0 = time.perf_counter()
         rc0 = pl0.run_jobs(j_run)
+        cpu_ns = sum(os.times()[:2]) - c0
         fence()
         r0, t_ns = comm.throughput(n0 * W * H, time.perf_counter() - t0)
         pl0.close()
@@ -739,6 +743,7 @@ def main():
             "value": round(r0 / 1e6, 1), "unit": "Mpixel/s", "images_per_gpu": n0,
             "host_threads_per_gpu": nthr, "ok": rc0 == 0,
             "h2d_bytes_per_image": int(g.coef_shorts * 2),
+            "host_cpu_ms_per_image": round(cpu_ns / n0 * 1e3, 2), "cpus_busy": round(cpu_ns / t_ns, 1),
             "note": "north_star's design: Huffman on the host (csrc/entropy.c), dense coefficient "
                     "planes over PCIe, fused kernel; aggregated over ranks like `value`"}
 
@@ -874,7 +879,7 @@ def main():
             nt = nthreads if transport == 2 else nthr
             p2 = lib.Pipeline(device=gpu, nthreads=nt, out=abi.JPEG_DECODE_RGB,
                               copy_back=copy_back, transport=transport, batch=G, depth=args.lanes)
-            n = 24 * G if transport == 2 else max(96, 4 * nthr)
+            n = 24 * G if transport == 2 else max(384, 16 * nthr)
             if copy_back:
                 n = min(n, 288)                   # 25 MB of host pixels per image
             outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in range(n)] if copy_back else None

@@ -631,10 +631,10 @@ static inline __attribute__((always_inline)) int decode_scan(parser *ps, const j
         const long long w0 = so->nwords;
         if (stage == JGA_STAGE_PACK) so->index[sl->at] = (int)so->nwords;
         else blk = so->coef + sl->at;
-        sl->at += sl->step;
         if (decode_block(&br, sl->dc, sl->ac, sl->q, &pred[sl->comp], blk, so, stage) != EXIT_SUCCESS) {
           return EXIT_FAILURE;
         }
+        sl->at += sl->step;
         if (stage == JGA_STAGE_PACK) so->plane_words[sl->comp] += so->nwords - w0;
       }
       mcus++;
