@@ -458,14 +458,82 @@ static inline __attribute__((always_inline)) int extend_bits(unsigned v, int s) 
   return (int)v + (int)(((v >> (s - 1)) - 1u) & (unsigned)(1 - (1 << s)));
 }
 
-/* One block.  `blk` receives 64 natural-order shorts (QUANT/DCT stages).
+/* ---- two AC symbols per look-up ---------------------------------------------------------------
+ * At ~5 bits per symbol (code + magnitude) the ten bits the code table is indexed with usually
+ * hold TWO whole symbols — 66 % of the consecutive pairs of the bench's q90 frames, 54 % at q50.
+ * The pair table gives, for the same ten bits, everything both leave behind:
+ *     bits  0.. 7  tot   bits the symbols take (0: the first one does not fit — one-symbol path)
+ *     bits  8..15  need  how far the zig-zag index moves (every run + 1), + 1 for an EOB: the step
+ *                        is taken iff k + need <= 64 — an EOB is a symbol of THIS block only
+ *                        while k < 64 (behind coefficient 63 the next bits are a DC code)
+ *     bits 16..23  at1   where the first value goes relative to k   (64: nowhere — ZRL, EOB)
+ *     bits 24..31  at2   the second one's                            (64: none)
+ *     bits 32..47  v1, bits 48..62 v2 (15 bits, sign extended)       bit 63: the last symbol is an EOB
+ * built by decoding the ten bits symbol by symbol (build_pairs), so a step through it is, for
+ * any input, what two steps of the one-symbol path would have done — as long as the block has
+ * room for both (k + need <= 64: in a valid stream nearly always; otherwise the one-symbol path goes
+ * on and reports what it finds where it finds it).  Values are stored without a test: a block
+ * is put together in a local buffer whose slot 64 takes the stores that go nowhere (DEZZX maps
+ * every position >= 64 there), and leaves as 128 bytes at its end. */
+#define PAIR_EOB ((uint64_t)1 << 63)
+static const uint8_t DEZZX[136] = {
+   0,  1,  8, 16,  9,  2,  3, 10, 17, 24, 32, 25, 18, 11,  4,  5,
+  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13,  6,  7, 14, 21, 28,
+  35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+  58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+  64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64,
+  64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64,
+  64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64,
+  64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64,
+  64, 64, 64, 64, 64, 64, 64, 64
+};
+
+static void build_pairs(const htab *ac, uint64_t *pair) {
+  unsigned idx;
+  for (idx = 0; idx < (1u << FAST_BITS); idx++) {
+    const unsigned e1 = ac->fast[idx];
+    const int tot1 = (int)(e1 & 255), len1 = (int)((e1 >> 8) & 255);
+    const int rs1 = (int)(e1 >> 16), r1 = rs1 >> 4, s1 = rs1 & 15;
+    uint64_t x;
+    int v1 = 0, v2 = 0, adv, at1 = 64, at2 = 64, tot = tot1, eob = 0;
+    pair[idx] = 0;
+    if (!e1 || tot1 > FAST_BITS) continue;             /* a longer code, or magnitude bits beyond the index */
+    if (s1) v1 = extend_bits((idx >> (FAST_BITS - tot1)) & ((1u << s1) - 1u), s1);
+    (void)len1;
+    if (rs1 == 0) { eob = 1; adv = 0; }
+    else {
+      const unsigned idx2 = (idx << tot1) & ((1u << FAST_BITS) - 1u);     /* what follows, zeros behind it */
+      const unsigned e2 = ac->fast[idx2];
+      const int tot2 = (int)(e2 & 255), rs2 = (int)(e2 >> 16), r2 = rs2 >> 4, s2 = rs2 & 15;
+      adv = r1 + 1;
+      if (s1) at1 = r1;
+      if (e2 && tot1 + tot2 <= FAST_BITS) {              /* the second symbol lies inside the index too */
+        tot += tot2;
+        if (rs2 == 0) eob = 1;
+        else {
+          if (s2) {
+            v2 = extend_bits((idx2 >> (FAST_BITS - tot2)) & ((1u << s2) - 1u), s2);
+            at2 = adv + r2;
+          }
+          adv += r2 + 1;
+        }
+      }
+    }
+    x = (uint64_t)tot | (uint64_t)(adv + eob) << 8 | (uint64_t)at1 << 16 | (uint64_t)at2 << 24
+     | (uint64_t)(uint16_t)v1 << 32 | (uint64_t)((uint16_t)v2 & 0x7fffu) << 48;
+    pair[idx] = eob ? x | PAIR_EOB : x;
+  }
+}
+
+/* One block.  `blk` receives 64 natural-order shorts (QUANT/DCT stages); `lb` is the caller's
+ * zeroed 72-short staging block (zero again on return), `q` has 65 entries (the last one 0).
  * One path per symbol whatever its length: a table look-up for the code (codes of up to
  * FAST_BITS bits — nearly all — in one step), then the magnitude bits straight from the
  * window.  The branches left are the ones that go the same way almost every time (window
  * low, code longer than FAST_BITS, end of block): the earlier version chose between a
  * combined code+value table and this path on every symbol, a coin toss on busy images. */
 static inline __attribute__((always_inline)) int decode_block(bitreader *br, const htab *dc, const htab *ac,
- const unsigned short *q, short *pred, short *blk, scan_out *so, int stage) {
+ const uint64_t *pair, const unsigned short *q, short *pred, short *blk, short *lb, scan_out *so, int stage) {
   int s, k;
   /* (a block reads at most 248 + 8 bytes past this: inside the padding) */
   if (br->p > br->lim + 8) return jga_fail("Error, entropy data ended early.");
@@ -480,16 +548,27 @@ static inline __attribute__((always_inline)) int decode_block(bitreader *br, con
     if (so->nwords + 64 > so->pack_cap) return jga_fail("Error PACK buffer too small.");   /* a block is at most 1 + 63 words */
     so->pack[so->nwords++] = (short)(*pred & 0xfff);
   }
-  else {
-    memset(blk, 0, 64*sizeof(short));
-    blk[0] = stage == JGA_STAGE_DCT ? (short)(*pred*q[0]) : *pred;
-  }
-  /* Two symbols per refill: it leaves >= 56 bits, a symbol found in the table takes at most
-     FAST_BITS + 15 = 25 and any symbol at most 31 — so the second one has its 25 whatever the
+  else lb[0] = stage == JGA_STAGE_DCT ? (short)(*pred*q[0]) : *pred;
+  /* Two steps per refill: it leaves >= 56 bits, a step through a table takes at most
+     FAST_BITS + 15 = 25 and any symbol at most 31 — so the second step has its 25 whatever the
      first was, and a long code (rare) refills for itself. */
-#define AC_SYMBOL() do { \
+#define AC_STEP() do { \
     unsigned e; \
     int rs, r, v; \
+    if (stage != JGA_STAGE_PACK) { \
+      const uint64_t x = pair[PEEK(br, FAST_BITS)]; \
+      const int need = (int)((x >> 8) & 255); \
+      if (__builtin_expect((x & 255) != 0 && k + need <= 64, 1)) { \
+        const int n1 = DEZZX[k + (int)((x >> 16) & 255)], n2 = DEZZX[k + (int)((x >> 24) & 255)]; \
+        const int v1 = (int16_t)(x >> 32), v2 = (int16_t)((int64_t)(x << 1) >> 49); \
+        lb[n1] = stage == JGA_STAGE_DCT ? (short)((short)v1*q[n1]) : (short)v1; \
+        lb[n2] = stage == JGA_STAGE_DCT ? (short)((short)v2*q[n2]) : (short)v2; \
+        SKIP(br, x & 255); \
+        if (x & PAIR_EOB) goto block_done; \
+        k += need; \
+        break; \
+      } \
+    } \
     e = ac->fast[PEEK(br, FAST_BITS)]; \
     if (__builtin_expect(e != 0, 1)) { \
       /* code and magnitude leave the window in ONE shift (the next look-up waits for nothing \
@@ -517,7 +596,7 @@ static inline __attribute__((always_inline)) int decode_block(bitreader *br, con
     if (__builtin_expect(s == 0, 0)) { \
       if (rs == 0) {                               /* EOB */ \
         if (stage == JGA_STAGE_PACK) so->pack[so->nwords++] = 0; \
-        return EXIT_SUCCESS; \
+        goto block_done; \
       } \
       v = 0;                                       /* ZRL (or any run without a value): r + 1 zeros, xjpeg.c:507-508 */ \
     } \
@@ -528,17 +607,22 @@ static inline __attribute__((always_inline)) int decode_block(bitreader *br, con
     } \
     else if (s) { \
       const int n = DEZZ[k]; \
-      blk[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v; \
+      lb[n] = stage == JGA_STAGE_DCT ? (short)((short)v*q[n]) : (short)v; \
     } \
     k++; \
   } while (0)
   for (k = 1; k < 64;) {
     refill(br);
-    AC_SYMBOL();
+    AC_STEP();
     if (k >= 64) break;
-    AC_SYMBOL();
+    AC_STEP();
   }
-#undef AC_SYMBOL
+block_done:
+#undef AC_STEP
+  if (stage != JGA_STAGE_PACK) {
+    memcpy(blk, lb, 64*sizeof(short));
+    memset(lb, 0, 64*sizeof(short));
+  }
   return EXIT_SUCCESS;
 }
 
@@ -572,7 +656,8 @@ static int check_geom(const parser *ps, const jga_geom *g) {
 #define MCU_SLOTS_MAX 48          /* 4 x 4 blocks of each of three components */
 typedef struct mcu_slot {
   const htab *dc, *ac;
-  const unsigned short *q;
+  const uint64_t *pair;            /* the AC table's pair table (QUANT / DCT stages) */
+  const unsigned short *q;         /* 65 entries, the last one 0 */
   int comp, sbx, sby, step;
   long long at;                    /* offset of the slot's block in the planes (PACK: in the index) */
 } mcu_slot;
@@ -581,7 +666,10 @@ static inline __attribute__((always_inline)) int decode_scan(parser *ps, const j
  const int stage, uint8_t *clean) {
   bitreader br;
   short pred[3] = {0, 0, 0};
-  short scratch[64];
+  short lb[72] __attribute__((aligned(32)));      /* the block being put together (+ slot 64: stores that go nowhere) */
+  unsigned short qx[3][72];
+  uint64_t pairs[4][1 << FAST_BITS];               /* built for the AC tables the scan uses */
+  int pairs_built[4] = {0, 0, 0, 0};
   int mbx, mby, i, sbx, sby, nslots = 0;
   long mcus = 0, total = (long)g->nhmb*g->nvmb;
   int rst = 0, to_restart;
@@ -599,14 +687,22 @@ static inline __attribute__((always_inline)) int decode_scan(parser *ps, const j
   }
   /* the blocks of an MCU in scan order (xjpeg.c:461-472), each with its tables; where a slot's
      block lies is worked out once per row of MCUs and stepped from MCU to MCU */
+  memset(lb, 0, sizeof(lb));
   for (i = 0; i < ps->ncomps; i++) {
     const comp_info *c = &ps->comp[i];
+    memcpy(qx[i], ps->quant[c->tq].tbl, 64*sizeof(unsigned short));
+    memset(qx[i] + 64, 0, 8*sizeof(unsigned short));
+    if (stage != JGA_STAGE_PACK && !pairs_built[c->ta]) {
+      build_pairs(&ps->ac[c->ta], pairs[c->ta]);
+      pairs_built[c->ta] = 1;
+    }
     for (sby = 0; sby < c->vs; sby++) {
       for (sbx = 0; sbx < c->hs; sbx++) {
         if (nslots >= MCU_SLOTS_MAX) return jga_fail("Unsupported sampling: more than %d blocks per MCU", MCU_SLOTS_MAX);
         slots[nslots].dc = &ps->dc[c->td];
         slots[nslots].ac = &ps->ac[c->ta];
-        slots[nslots].q = ps->quant[c->tq].tbl;
+        slots[nslots].pair = pairs[c->ta];
+        slots[nslots].q = qx[i];
         slots[nslots].comp = i;
         slots[nslots].sbx = sbx;
         slots[nslots].sby = sby;
@@ -627,11 +723,11 @@ static inline __attribute__((always_inline)) int decode_scan(parser *ps, const j
     for (mbx = 0; mbx < g->nhmb; mbx++) {
       for (i = 0; i < nslots; i++) {
         mcu_slot *sl = &slots[i];
-        short *blk = scratch;
+        short *blk = lb;
         const long long w0 = so->nwords;
         if (stage == JGA_STAGE_PACK) so->index[sl->at] = (int)so->nwords;
         else blk = so->coef + sl->at;
-        if (decode_block(&br, sl->dc, sl->ac, sl->q, &pred[sl->comp], blk, so, stage) != EXIT_SUCCESS) {
+        if (decode_block(&br, sl->dc, sl->ac, sl->pair, sl->q, &pred[sl->comp], blk, lb, so, stage) != EXIT_SUCCESS) {
           return EXIT_FAILURE;
         }
         sl->at += sl->step;
