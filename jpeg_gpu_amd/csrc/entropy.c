@@ -490,6 +490,43 @@ static const uint8_t DEZZX[136] = {
    0,  0,  0,  0,  0,  0,  0,  0
 };
 
+/* The same for the PACK stage (xjpeg.c:484-496, 513-519): what the symbols leave behind there is
+ * one RLE word each, run << 12 | value & 0xfff, an EOB the word 0:
+ *     bits 0..7 tot, 8..15 need (as above), 16..23 words (1 or 2), 32..47 word 1, 48..63 word 2
+ * (one word: it is word 2 as well, so that both can be stored without a test). */
+static void build_pack_pairs(const htab *ac, uint64_t *pair) {
+  unsigned idx;
+  for (idx = 0; idx < (1u << FAST_BITS); idx++) {
+    const unsigned e1 = ac->fast[idx];
+    const int tot1 = (int)(e1 & 255), rs1 = (int)(e1 >> 16), r1 = rs1 >> 4, s1 = rs1 & 15;
+    int v1 = 0, need, tot = tot1, words = 1, eob = 0;
+    unsigned w1, w2;
+    pair[idx] = 0;
+    if (!e1 || tot1 > FAST_BITS) continue;
+    if (s1) v1 = extend_bits((idx >> (FAST_BITS - tot1)) & ((1u << s1) - 1u), s1);
+    if (rs1 == 0) { eob = 1; need = 1; w1 = w2 = 0; }
+    else {
+      const unsigned idx2 = (idx << tot1) & ((1u << FAST_BITS) - 1u);
+      const unsigned e2 = ac->fast[idx2];
+      const int tot2 = (int)(e2 & 255), rs2 = (int)(e2 >> 16), r2 = rs2 >> 4, s2 = rs2 & 15;
+      need = r1 + 1;
+      w1 = w2 = (unsigned)((r1 << 12) | (v1 & 0xfff)) & 0xffffu;
+      if (e2 && tot1 + tot2 <= FAST_BITS) {
+        tot += tot2;
+        words = 2;
+        if (rs2 == 0) { eob = 1; need++; w2 = 0; }
+        else {
+          const int v2 = s2 ? extend_bits((idx2 >> (FAST_BITS - tot2)) & ((1u << s2) - 1u), s2) : 0;
+          need += r2 + 1;
+          w2 = (unsigned)((r2 << 12) | (v2 & 0xfff)) & 0xffffu;
+        }
+      }
+    }
+    pair[idx] = (uint64_t)tot | (uint64_t)need << 8 | (uint64_t)words << 16 | (uint64_t)eob << 24
+     | (uint64_t)w1 << 32 | (uint64_t)w2 << 48;
+  }
+}
+
 static void build_pairs(const htab *ac, uint64_t *pair) {
   unsigned idx;
   for (idx = 0; idx < (1u << FAST_BITS); idx++) {
@@ -556,7 +593,21 @@ static inline __attribute__((always_inline)) int decode_block(bitreader *br, con
 #define AC_STEP() do { \
     unsigned e; \
     int rs, r, v; \
-    if (stage != JGA_STAGE_PACK) { \
+    if (stage == JGA_STAGE_PACK) { \
+      const uint64_t x = pair[PEEK(br, FAST_BITS)]; \
+      const int need = (int)((x >> 8) & 255); \
+      if (__builtin_expect((x & 255) != 0 && k + need <= 64, 1)) { \
+        const int words = (int)((x >> 16) & 255); \
+        so->pack[so->nwords] = (short)(x >> 32); \
+        so->pack[so->nwords + words - 1] = (short)(x >> 48); \
+        so->nwords += words; \
+        SKIP(br, x & 255); \
+        if (x & (1u << 24)) goto block_done; \
+        k += need; \
+        break; \
+      } \
+    } \
+    else { \
       const uint64_t x = pair[PEEK(br, FAST_BITS)]; \
       const int need = (int)((x >> 8) & 255); \
       if (__builtin_expect((x & 255) != 0 && k + need <= 64, 1)) { \
@@ -690,8 +741,9 @@ static inline __attribute__((always_inline)) int decode_scan(parser *ps, const j
     const comp_info *c = &ps->comp[i];
     memcpy(qx[i], ps->quant[c->tq].tbl, 64*sizeof(unsigned short));
     memset(qx[i] + 64, 0, 8*sizeof(unsigned short));
-    if (stage != JGA_STAGE_PACK && !pairs_built[c->ta]) {
-      build_pairs(&ps->ac[c->ta], pairs[c->ta]);
+    if (!pairs_built[c->ta]) {
+      if (stage == JGA_STAGE_PACK) build_pack_pairs(&ps->ac[c->ta], pairs[c->ta]);
+      else build_pairs(&ps->ac[c->ta], pairs[c->ta]);
       pairs_built[c->ta] = 1;
     }
     for (sby = 0; sby < c->vs; sby++) {
