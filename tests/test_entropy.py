@@ -159,3 +159,53 @@ def test_irregular_huffman_tables(lib, orc, synth):
     if oracle.Reference.available():
         assert np.array_equal(oracle.Reference().decode(data, oracle.QUANT)[1],
                               lib.entropy_decode(data, g))
+
+
+@pytest.mark.parametrize("sampling", ["420", "444", "grey"])
+def test_two_symbols_per_lookup_edges(lib, orc, synth, sampling):
+    """The host stage takes two short AC symbols per table look-up (csrc/entropy.c: build_pairs).  Levels made
+    for that path's edges: blocks that run to coefficient 63 with no EOB (the bits behind them are the next
+    block's DC code — an "EOB" found there is not one), runs of +-1 (three-bit symbols: every step a pair),
+    an EOB as first and as second symbol of a step, a ZRL inside a pair, magnitudes too long for the table
+    beside short ones; QUANT, DCT and PACK against the oracle."""
+    import oracle
+    w, h = 96, 80
+    n = synth.coef_shorts(w, h, sampling)
+    rng = np.random.default_rng(7)
+    lv = np.zeros(n, np.int16).reshape(-1, 64)
+    for i, b in enumerate(lv):
+        kind = i % 8
+        b[0] = rng.integers(-60, 61)
+        if kind == 0:
+            b[1:] = rng.choice([-1, 1], 63)                         # full block of +-1: ends at 63, no EOB
+        elif kind == 1:
+            b[1:] = rng.choice([-1, 1], 63); b[40:] = 0             # pairs, then an EOB
+        elif kind == 2:
+            pass                                                    # DC only: the EOB is a step's first symbol
+        elif kind == 3:
+            b[1] = 1                                                # value, EOB: the EOB is the second
+        elif kind == 4:
+            b[1:] = rng.choice([-2, -1, 1, 2, 3], 63); b[63] = 1    # ends at 63 on a short symbol
+        elif kind == 5:
+            b[1] = 1; b[18] = -1; b[35] = 1; b[63] = -1             # ZRLs between short symbols
+        elif kind == 6:
+            b[1:] = rng.integers(-1023, 1024, 63)                   # long magnitudes: the one-symbol path
+        else:
+            b[1:32] = rng.choice([-1, 0, 0, 1, 300], 31)            # a mixture
+    data = synth.encode_levels(lv.reshape(-1), w, h, sampling, restart_interval=5)
+    _, g = lib.geom_of(data)
+    got = lib.entropy_decode(data, g, False).reshape(-1, 64)
+    assert (got == lv).all() or _only_unused_slots_differ(lib, g, got, lv)
+    assert (lib.entropy_decode(data, g, False) == orc.decode(data, oracle.QUANT)[1]).all()
+    assert (lib.entropy_decode(data, g, True) == orc.decode(data, oracle.DCT)[1]).all()
+    pack, idx, per = lib.entropy_decode_pack(data, g)
+    assert sum(per) == len(pack)
+    if oracle.Reference.available():                                # the compiled reference's own words and index
+        words, index = oracle.Reference().decode(data, oracle.PACK)[1]
+        assert np.array_equal(pack, words) and np.array_equal(idx, index)
+    # every block's words expanded (res/horz_pack_yuv.fs.glsl:94-127, oracle.c) = its QUANT block
+    quant = lib.entropy_decode(data, g, False)
+    got = np.zeros_like(quant)
+    for ipos, off in lib.block_slots(g):
+        got[off[:, None] + np.arange(64)] = orc.unpack_blocks(pack, idx[ipos])
+    assert np.array_equal(got, quant)
