@@ -365,6 +365,9 @@ int jga_time_idct_batch(const jga_geom *g, int nimages, const short *d_coef,
 /* `reps` device-to-device copies (hipMemcpyDtoDAsync) of `bytes`, HIP events on `stream` around them: the copy
  * ceiling the bench prints beside the kernels' rates; average milliseconds per copy in *ms. */
 int jga_time_device_copy(void *d_dst, const void *d_src, size_t bytes, int reps, void *stream, float *ms);
+/* The same volume moved by a kernel of this library that does nothing else (csrc/copy_kernel.hip: `grid` workgroups
+ * of 256 lanes, 16 bytes per lane per trip, non-temporal stores); bytes a multiple of 16. */
+int jga_time_kernel_copy(void *d_dst, const void *d_src, size_t bytes, int grid, int reps, void *stream, float *ms);
 
 /* --- pipelined batch decoder (build addition; SURVEY.md §8b "batch/async
  *     entry"): N host entropy threads -> pinned ring -> H2D on a copy stream

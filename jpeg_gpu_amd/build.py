@@ -23,7 +23,7 @@ OBJ = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
 C_SOURCES = ["layout.c", "entropy.c", "libjpeg_vtbl.c", "band.c"]
-HIP_SOURCES = ["idct_kernels.hip", "huff_kernels.hip", "pack_kernels.hip", "unstuff_kernels.hip"]   # device code: hipcc
+HIP_SOURCES = ["idct_kernels.hip", "huff_kernels.hip", "pack_kernels.hip", "unstuff_kernels.hip", "copy_kernel.hip"]   # device code: hipcc
 CXX_SOURCES = ["device_api.cpp", "vtbl.cpp", "pipeline.cpp", "huff_prepare.cpp",
                "huff_api.cpp"]                           # host only: g++ + HIP API
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")

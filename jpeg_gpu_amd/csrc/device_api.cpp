@@ -345,6 +345,29 @@ JGA_EXPORT int jga_time_device_copy(void *d_dst, const void *d_src, size_t bytes
   return EXIT_SUCCESS;
 }
 
+// The same volume moved by a kernel of this library (copy_kernel.hip): `grid` workgroups of 256 lanes,
+// 16 bytes per lane per trip.  bytes a multiple of 16.
+extern "C" int jga_launch_stream_copy(void *dst, const void *src, size_t bytes, int grid, void *stream);
+JGA_EXPORT int jga_time_kernel_copy(void *d_dst, const void *d_src, size_t bytes, int grid, int reps, void *stream, float *ms) {
+  hipEvent_t e0, e1;
+  float t = 0.0f;
+  if (reps < 1) reps = 1;
+  if (grid < 1 || (bytes & 15)) return jga_fail("jga_time_kernel_copy: bad arguments");
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
+  for (int i = 0; i < reps; i++) {
+    if (jga_launch_stream_copy(d_dst, d_src, bytes, grid, stream) != 0) return jga_fail("copy kernel launch failed");
+  }
+  HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (ms) *ms = t/(float)reps;
+  return EXIT_SUCCESS;
+}
+
 // ---- thin device-memory helpers -------------------------------------------
 
 JGA_EXPORT void *jga_device_malloc(size_t bytes) {

@@ -27,7 +27,7 @@ EXPORTED = [
     "jga_host_register", "jga_host_unregister",
     "jga_pipeline_plan_cfg", "jga_pipeline_register_input", "jga_pipeline_forget_input", "jga_pipeline_counters",
     "jga_huff_set_input_flags", "jga_huff_host_bytes", "jga_huff_set_option", "jga_plugin_configure",
-    "jga_time_device_copy",
+    "jga_time_device_copy", "jga_time_kernel_copy",
 ]
 
 
@@ -116,6 +116,7 @@ L.jga_huff_host_bytes.restype = _ll
 L.jga_huff_set_option.argtypes = [_vp, _i, _i]
 L.jga_plugin_configure.argtypes = [C.POINTER(abi.jga_plugin_config)]
 L.jga_time_device_copy.argtypes = [_vp, _vp, C.c_size_t, _i, _vp, C.POINTER(C.c_float)]
+L.jga_time_kernel_copy.argtypes = [_vp, _vp, C.c_size_t, _i, _i, _vp, C.POINTER(C.c_float)]
 
 L.jga_huff_create.argtypes = [_i, _ll]
 L.jga_huff_create.restype = _vp

@@ -37,8 +37,9 @@ if roof:
     dc = rf.get("device_copy")
     if dc:
         out += ["Copy ceiling of the same bench run (`roofline.device_copy`): hipMemcpyDtoDAsync of %d bytes each way, %d repetitions, warmed: %.4f ms = "
-                "%.0f GB/s read + %.0f GB/s written = %.0f GB/s (torch copy_ of the same tensors: %s GB/s)." % (dc["bytes_each_way"], dc["reps"], dc["ms"], dc["read_GBps"],
-                    dc["write_GBps"], rf["device_copy_GBps"], dc.get("torch_copy_GBps")), ""]
+                "%.0f GB/s read + %.0f GB/s written = %.0f GB/s; a copy kernel of this library on the same buffers (csrc/copy_kernel.hip, by grid size): %s GB/s; "
+                "torch copy_ of the same volume: %s GB/s.  `roofline.device_copy_GBps` = the best of them = %.0f." % (dc["bytes_each_way"], dc["reps"], dc["ms"], dc["read_GBps"],
+                    dc["write_GBps"], dc["read_GBps"] + dc["write_GBps"], dc.get("kernel_copy_GBps_by_grid"), dc.get("torch_copy_GBps"), rf["device_copy_GBps"]), ""]
 out += ["## a short bench run", "",
        "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 12 --warmup 3 --batch 128 --no-cpu --no-e2e "
        "--no-pack --no-other --no-gpu-entropy --no-configs --no-measure-traffic --scale-proxy 0` (tools/r4_check.sh; rounds 2-3: "
