@@ -170,8 +170,30 @@ def test_two_symbols_per_lookup_edges(lib, orc, synth, sampling):
     beside short ones; QUANT, DCT and PACK against the oracle."""
     import oracle
     w, h = 96, 80
+    lv = pair_edge_levels(synth, w, h, sampling)
+    data = synth.encode_levels(lv.reshape(-1), w, h, sampling, restart_interval=5)
+    _, g = lib.geom_of(data)
+    got = lib.entropy_decode(data, g, False).reshape(-1, 64)
+    assert (got == lv).all() or _only_unused_slots_differ(lib, g, got, lv)
+    assert (lib.entropy_decode(data, g, False) == orc.decode(data, oracle.QUANT)[1]).all()
+    assert (lib.entropy_decode(data, g, True) == orc.decode(data, oracle.DCT)[1]).all()
+    pack, idx, per = lib.entropy_decode_pack(data, g)
+    assert sum(per) == len(pack)
+    if oracle.Reference.available():                                # the compiled reference's own words and index
+        words, index = oracle.Reference().decode(data, oracle.PACK)[1]
+        assert np.array_equal(pack, words) and np.array_equal(idx, index)
+    # every block's words expanded (res/horz_pack_yuv.fs.glsl:94-127, oracle.c) = its QUANT block
+    quant = lib.entropy_decode(data, g, False)
+    got = np.zeros_like(quant)
+    for ipos, off in lib.block_slots(g):
+        got[off[:, None] + np.arange(64)] = orc.unpack_blocks(pack, idx[ipos])
+    assert np.array_equal(got, quant)
+
+
+def pair_edge_levels(synth, w, h, sampling, seed=7):
+    """Levels for the edges of "several symbols per table look-up" (host stage: build_pairs; GPU stage: packs)."""
     n = synth.coef_shorts(w, h, sampling)
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(seed)
     lv = np.zeros(n, np.int16).reshape(-1, 64)
     for i, b in enumerate(lv):
         kind = i % 8
@@ -192,20 +214,4 @@ def test_two_symbols_per_lookup_edges(lib, orc, synth, sampling):
             b[1:] = rng.integers(-1023, 1024, 63)                   # long magnitudes: the one-symbol path
         else:
             b[1:32] = rng.choice([-1, 0, 0, 1, 300], 31)            # a mixture
-    data = synth.encode_levels(lv.reshape(-1), w, h, sampling, restart_interval=5)
-    _, g = lib.geom_of(data)
-    got = lib.entropy_decode(data, g, False).reshape(-1, 64)
-    assert (got == lv).all() or _only_unused_slots_differ(lib, g, got, lv)
-    assert (lib.entropy_decode(data, g, False) == orc.decode(data, oracle.QUANT)[1]).all()
-    assert (lib.entropy_decode(data, g, True) == orc.decode(data, oracle.DCT)[1]).all()
-    pack, idx, per = lib.entropy_decode_pack(data, g)
-    assert sum(per) == len(pack)
-    if oracle.Reference.available():                                # the compiled reference's own words and index
-        words, index = oracle.Reference().decode(data, oracle.PACK)[1]
-        assert np.array_equal(pack, words) and np.array_equal(idx, index)
-    # every block's words expanded (res/horz_pack_yuv.fs.glsl:94-127, oracle.c) = its QUANT block
-    quant = lib.entropy_decode(data, g, False)
-    got = np.zeros_like(quant)
-    for ipos, off in lib.block_slots(g):
-        got[off[:, None] + np.arange(64)] = orc.unpack_blocks(pack, idx[ipos])
-    assert np.array_equal(got, quant)
+    return lv

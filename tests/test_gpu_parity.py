@@ -723,6 +723,37 @@ def test_gpu_huffman_block_finished_with_the_next_intervals_bits_is_an_early_end
         gpu.gpu_entropy_decode([d])
 
 
+@pytest.mark.parametrize("sampling", ["420", "444", "grey"])
+@pytest.mark.parametrize("ri", [0, 5])
+def test_gpu_huffman_several_symbols_per_lookup_edges(gpu, orc, synth, sampling, ri):
+    """Both entropy stages take several short AC symbols per table look-up (GPU: the packs of the
+    synchronisation runs, csrc/huff_common.h; host: csrc/entropy.c build_pairs).  Levels made for the edges —
+    blocks that run to coefficient 63 with no EOB (what follows is the next block's DC code), EOBs first and
+    second in a step, ZRLs, long magnitudes (tests/test_entropy.py: pair_edge_levels): GPU planes = host planes
+    = the oracle's, and through the pipeline the pixels are the oracle's."""
+    import oracle
+    from test_entropy import pair_edge_levels
+    from jpeg_gpu_amd import abi
+    w, h = 416, 240                                        # enough scan for several subsequences per segment
+    lv = pair_edge_levels(synth, w, h, sampling, seed=19)
+    data = synth.encode_levels(lv.reshape(-1), w, h, sampling, restart_interval=ri)
+    _, g = gpu.geom_of(data)
+    want = orc.decode(data, oracle.QUANT)[1]
+    assert np.array_equal(gpu.entropy_decode(data, g, False), want)
+    _, coefs, _ = gpu.gpu_entropy_decode([data, data])
+    assert np.array_equal(coefs[0], want) and np.array_equal(coefs[1], want)
+    rgb = orc.decode_rgb(data)[1]
+    for transport in (2, 0, 1):
+        out = np.zeros(rgb.size, np.uint8)
+        pl = gpu.Pipeline(device=0, nthreads=2, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=transport, batch=2, depth=1)
+        try:
+            rc, jobs = pl.run([data], host_outs=[out])
+            assert rc == 0 and jobs[0].status == 0
+        finally:
+            pl.close()
+        assert np.array_equal(out, rgb.ravel()), transport
+
+
 def test_gpu_huffman_golden_jpegs(gpu, golden_jpegs):
     """Pillow-made files (optimised tables, DRI) + ours, against the reference's QUANT planes."""
     for name in golden_jpegs.names:
