@@ -64,6 +64,7 @@ static int walk(const unsigned char *f, long size, band_walk *w) {
  * (or fill) inside entropy-coded data, where one byte in 256 is a stuffed FF 00 — or -1.  The
  * stuffed ones are dropped 32 bytes at a time: the pass over an 8K frame's 12 MB is bound by
  * reading them (0.5 ms), not by 48 000 calls of memchr (1.7 ms). */
+#if defined(__x86_64__)
 __attribute__((target("avx2"))) static long next_marker_avx2(const unsigned char *f, long pos, long size) {
   typedef long long v4 __attribute__((vector_size(32), aligned(1)));
   typedef char v32 __attribute__((vector_size(32)));
@@ -81,8 +82,11 @@ __attribute__((target("avx2"))) static long next_marker_avx2(const unsigned char
   for (; pos + 1 < size; pos++) if (f[pos] == 0xFF && f[pos + 1] != 0x00) return pos;
   return -1;
 }
+#endif
 static long next_marker(const unsigned char *f, long pos, long size) {
+#if defined(__x86_64__)
   if (__builtin_cpu_supports("avx2")) return next_marker_avx2(f, pos, size);
+#endif
   while (pos + 1 < size) {
     const unsigned char *p = (const unsigned char *)memchr(f + pos, 0xFF, (size_t)(size - 1 - pos));
     if (!p) return -1;

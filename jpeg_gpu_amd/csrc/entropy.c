@@ -805,9 +805,12 @@ static inline __attribute__((always_inline)) int decode_scan(parser *ps, const j
 SCAN_VARIANT(scan_pack, , JGA_STAGE_PACK)
 SCAN_VARIANT(scan_quant, , JGA_STAGE_QUANT)
 SCAN_VARIANT(scan_dct, , JGA_STAGE_DCT)
+#if defined(__x86_64__) && !defined(JGA_ENTROPY_NO_BMI2)   /* (NO_BMI2: the differential fuzz runs the plain variants on a CPU that has BMI2) */
+#define JGA_ENTROPY_BMI2 (1)
 SCAN_VARIANT(scan_pack_bmi2, __attribute__((target("bmi,bmi2"))), JGA_STAGE_PACK)
 SCAN_VARIANT(scan_quant_bmi2, __attribute__((target("bmi,bmi2"))), JGA_STAGE_QUANT)
 SCAN_VARIANT(scan_dct_bmi2, __attribute__((target("bmi,bmi2"))), JGA_STAGE_DCT)
+#endif
 
 static int run_decode(const unsigned char *buf, int size, const jga_geom *g,
  scan_out *so) {
@@ -820,7 +823,7 @@ static int run_decode(const unsigned char *buf, int size, const jga_geom *g,
     /* room for the clean copy of the longest interval there can be: everything behind SOS */
     uint8_t *clean = (uint8_t *)malloc((size_t)(ps->size - ps->pos) + CLEAN_PAD);
     if (!clean) rc = jga_fail("Out of memory");
-#ifndef JGA_ENTROPY_NO_BMI2     /* (defined by the differential fuzz to run the plain variants on a CPU that has BMI2) */
+#ifdef JGA_ENTROPY_BMI2
     else if (__builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi")) switch (so->stage) {
       case JGA_STAGE_PACK : rc = scan_pack_bmi2(ps, g, so, clean); break;
       case JGA_STAGE_QUANT : rc = scan_quant_bmi2(ps, g, so, clean); break;
