@@ -401,45 +401,31 @@ typedef struct jga_pipeline_config {
                                 * whose jobs are all `pinned` are uploaded by DMA straight from the
                                 * callers' buffers; else on the host: one core unstuffs ~12 GB/s, as
                                 * fast as it could copy), 1 = host, 2 = GPU (jga_huff_set_device_unstuff) */
-  /* --- scheduling of transport 2 (what rounds 1-3 read from JGA_PIPE_* environment variables; the
-   *     environment is only consulted by builds made with -DJGA_TUNING).  0 = the default named. */
-  int link_slots;              /* uploads that may cross the link side by side: 0 = 2 (a single blob of 64 MB or
-                                * more takes both), -1 = no turns (every lane uploads when it is ready) */
-  int device_slots;            /* full-size groups whose kernels may be queued at a time: 0 = 3 */
-  int groups_per_lane;         /* a job too short for a steady state is cut into about this many groups per
-                                * lane: 0 = 4 ... */
-  int min_group;               /* ... none under this many 4K-frame equivalents: 0 = 4 */
-  int ramp_first;              /* a long job's first groups rise in size from lane to lane: 0 = yes, -1 = all equal */
   int spin_waits;              /* 0: lanes waiting for the device poll and sleep (csrc/host_wait.h), 1: they
                                 * spin in the runtime's waits (a core each; the lowest latency) */
-  int offload_at;              /* unstuff = 0: the clean-up runs on the device when the host side can count on this
-                                * many cores or fewer: 0 = 8 */
-  int copy_streams;            /* uploads of all lanes go through this many shared copy streams, round robin:
-                                * 0 = none (each lane's own stream; measured better with link_slots) */
   int trace;                   /* 1: a timeline of every run on stderr */
-  /* --- ingest of caller-owned PAGEABLE buffers without a host copy (round 4).  input_cache_mb > 0: the
-   *     pipeline keeps up to that many MB of callers' JPEG buffers registered with the device
-   *     (hipHostRegister), keyed by (address, size), least recently used out first.  A buffer seen for the
-   *     input_cache_sight-th time (0 = 1: at first sight) is registered — inside the run that sees it —
-   *     and from then on its scan is DMA'd where it lies, exactly like a `pinned` job's; until then it
-   *     is copied as before.  Only used where the scan clean-up runs on the device (unstuff 2, or 0 with
-   *     few cores): a host that cleans up reads every byte anyway.  CONTRACT: a buffer handed in again
-   *     at the same address and size must still be the same live allocation, or have been dropped with
-   *     jga_pipeline_forget_input() before it was freed; jga_pipeline_destroy() unregisters everything.
-   *     input_cache_mb = 0 (default), and buffers a cache does not hold: no contract — the upload's copies name the
-   *     callers' ordinary buffers and the runtime pins what they touch (slower than the cache: the pinning is
-   *     redone per copy; what the plugin does with a lone frame's buffers).  input_cache_mb < 0: every file that
-   *     is not `pinned` is copied into the group's pinned blob by a host core (rounds 2-3). */
+  /* (How transport 2 schedules its lanes — groups per lane, turns on the link and on the device, the ramp of a long
+   *  job's first groups — is not configuration: every other value of those fields measured slower or the same in
+   *  rounds 3-4, profiles/r4_host_side_steps.md.  Builds made with -DJGA_TUNING still read them from JGA_PIPE_*
+   *  environment variables, csrc/jga_tune.h.) */
+  /* --- ingest of caller-owned PAGEABLE buffers without a host copy.  The pipeline keeps up to input_cache_mb MB of
+   *     callers' JPEG buffers registered with the device (hipHostRegister), keyed by address, least recently used
+   *     out first.  A buffer seen for the input_cache_sight-th time (0 = 1: at first sight) is registered — inside
+   *     the run that sees it: 14 us for a 0.77 MB file where copying it costs a core 17 — and from then on the
+   *     device reads its scan where it lies, exactly like a `pinned` job's; until then it is copied as before.
+   *     Only used where the scan clean-up runs on the device (unstuff 2, 0 with few cores, and short runs): a host
+   *     that cleans up reads every byte anyway.
+   *     A registration is only ever used for the file it was made for: every entry carries a FINGERPRINT of its
+   *     buffer (size, the bytes of the first and last 64, a few words of the scan) that the host re-reads at every
+   *     sight; a buffer that was freed and handed out again at the same address with other contents — whose old
+   *     pages the device would still see — fails the check, loses its registration and is registered afresh.
+   *     jga_pipeline_forget_input() drops an entry at once (a caller that re-uses ingest buffers and wants the
+   *     pages unpinned); jga_pipeline_destroy() unregisters everything.
+   *     input_cache_mb = 0 (default): 512 MB.  -1: no cache — the upload's copies name the callers' ordinary buffers
+   *     and the runtime pins what they touch (the pinning is redone per copy).  -2: no cache, and every file that is
+   *     not `pinned` is copied into the group's pinned blob by a host core (rounds 2-3). */
   int input_cache_mb;
   int input_cache_sight;
-  /* --- GPU entropy stage of the lanes' batches (jga_huff_set_option): 0 = default */
-  int huff_sub_bytes;          /* subsequence length 32/64/128/256/512; 0 = by batch (hj_choose_sub_log2) */
-  int huff_assist_after;       /* rounds before the host walks stretches that never fall into step: 0 = 12 */
-  int huff_speculate;          /* the decode's tail is queued behind the first burst of rounds: 0 = yes, -1 = no */
-  int short_job;               /* how a job of at most short_job_frames 4K-frame equivalents is run: 0 = auto,
-                                * 1 = cut into groups like any other, 2 = as few batches as possible whose
-                                * uploads arrive in pieces (the first synchronisation round of a piece starts
-                                * when its bytes have landed) */
   int reserved_[6];            /* zero */
 } jga_pipeline_config;
 
@@ -511,6 +497,15 @@ int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
  * strided 2-byte pass over the planes that puts them in place. */
 int jga_huff_decode_split(jga_huff_batch *b, short *d_coef, long long coef_stride,
  short *d_dc, long long dc_stride, void *stream);
+/* jga_huff_decode_split in two halves, for a caller that wants ONE host wait per decode: _begin queues the decode
+ * on `stream` and returns; the caller queues what consumes the planes (jga_idct_*_batch_dc, copies of its output)
+ * on the same stream; _end waits for the stream, finishes the decode if its first burst of synchronisation rounds
+ * had not settled it, and sets *valid_behind to 1 if the work queued in between saw the final planes and DC values,
+ * 0 if it has to be queued again (streams that need more rounds than were queued up front: rare).  Returns and
+ * verdicts as jga_huff_decode_split. */
+int jga_huff_decode_split_begin(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ short *d_dc, long long dc_stride, void *stream);
+int jga_huff_decode_split_end(jga_huff_batch *b, int *valid_behind);
 /* Per-image outcome of the last jga_huff_prepare (also after it failed): 0 usable, 1 not
  * (damaged or unsupported file), 2 a valid file the device format cannot hold — Huffman
  * tables with too many long-code groups, or a frame beyond the kernels' 32-bit bit
@@ -530,6 +525,9 @@ int jga_huff_last_assisted(const jga_huff_batch *b);
 int jga_huff_image_errors(const jga_huff_batch *b);
 int jga_huff_image_error(const jga_huff_batch *b, int i);
 const unsigned short *jga_huff_qtabs(const jga_huff_batch *b);
+/* The same tables in device memory (they travel with prepare()'s upload): valid for work queued on prepare()'s
+ * stream after it, until the next prepare(); NULL if nothing is prepared. */
+const unsigned short *jga_huff_qtabs_device(const jga_huff_batch *b);
 /* Where the scan's byte-level clean-up happens (stuffed zeros, fill bytes, RSTn markers ->
  * restart segments; T.81 B.1.1.5, the reference's bit reader src/xjpeg.c:113-127, 593-629):
  * 0 = on the host inside jga_huff_prepare (one core unstuffs ~12 GB/s), 1 = on the GPU — prepare
@@ -562,9 +560,9 @@ int  jga_huff_wait_upload(jga_huff_batch *b);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */
 void jga_huff_set_threads(jga_huff_batch *b, int nthreads);
 /* Per-image version of jga_huff_set_inputs_pinned for the NEXT prepare(): flags[i] != 0 says image i's
- * buffer is pinned / registered (DMA'd where it lies when the clean-up runs on the device), 0 that it is
- * ordinary memory (copied into the batch's pinned blob).  NULL: back to the all-or-nothing setting.  The
- * array is read during prepare() only. */
+ * scan is read where it lies by a copy call naming the buffer (pinned / registered memory; or ordinary memory, which
+ * the runtime pins per copy) when the clean-up runs on the device, 0 that a host core copies it into the batch's
+ * pinned blob.  NULL: back to the all-or-nothing setting.  The array is read during prepare() only. */
 void jga_huff_set_input_flags(jga_huff_batch *b, const unsigned char *flags, int n);
 /* Bytes of the callers' files the last prepare() read on the host (0 = all DMA'd in place). */
 long long jga_huff_host_bytes(const jga_huff_batch *b);
@@ -574,12 +572,7 @@ enum {
   JGA_HUFF_OPT_SUB_BYTES = 1,      /* subsequence length: 32, 64, 128, 256, 512; 0 = by batch */
   JGA_HUFF_OPT_ASSIST_AFTER = 2,   /* rounds before the host walks unsettled stretches (default 12) */
   JGA_HUFF_OPT_SPECULATE = 3,      /* 0 / 1 = the tail is queued behind the first rounds, -1 = never */
-  JGA_HUFF_OPT_PIECES = 4,         /* prepare() uploads the batch in this many pieces (2..16; 0 / 1 = one upload) on copy
-                                    * streams of the batch's own and queues, behind each piece's arrival, its scan
-                                    * clean-up, start states and first six synchronisation rounds; the next decode —
-                                    * on the SAME stream prepare() was given — goes on from there.  An experiment:
-                                    * same planes, measured slower on short jobs */
-  JGA_HUFF_OPT_TRACE = 5           /* 1: what prepare() and decode() spent where, on stderr */
+  JGA_HUFF_OPT_TRACE = 4           /* 1: what prepare() and decode() spent where, on stderr */
 };
 int jga_huff_set_option(jga_huff_batch *b, int option, int value);
 

@@ -84,13 +84,8 @@ class jga_pipeline_config(C.Structure):
                 ("out", C.c_int), ("copy_back", C.c_int),
                 ("max_coef_shorts", C.c_longlong), ("max_out_bytes", C.c_longlong),
                 ("transport", C.c_int), ("batch", C.c_int), ("unstuff", C.c_int),
-                # round 4: scheduling knobs (0 = default), input cache, entropy-stage options
-                ("link_slots", C.c_int), ("device_slots", C.c_int), ("groups_per_lane", C.c_int),
-                ("min_group", C.c_int), ("ramp_first", C.c_int), ("spin_waits", C.c_int),
-                ("offload_at", C.c_int), ("copy_streams", C.c_int), ("trace", C.c_int),
-                ("input_cache_mb", C.c_int), ("input_cache_sight", C.c_int),
-                ("huff_sub_bytes", C.c_int), ("huff_assist_after", C.c_int), ("huff_speculate", C.c_int),
-                ("short_job", C.c_int), ("reserved_", C.c_int * 6)]
+                ("spin_waits", C.c_int), ("trace", C.c_int),
+                ("input_cache_mb", C.c_int), ("input_cache_sight", C.c_int), ("reserved_", C.c_int * 6)]
 
 
 class jga_job(C.Structure):
@@ -111,8 +106,7 @@ class jga_band(C.Structure):
                 ("scan_off", C.c_long), ("scan_bytes", C.c_long)]
 
 
-JGA_HUFF_OPT_SUB_BYTES, JGA_HUFF_OPT_ASSIST_AFTER, JGA_HUFF_OPT_SPECULATE, JGA_HUFF_OPT_PIECES, \
-    JGA_HUFF_OPT_TRACE = 1, 2, 3, 4, 5
+JGA_HUFF_OPT_SUB_BYTES, JGA_HUFF_OPT_ASSIST_AFTER, JGA_HUFF_OPT_SPECULATE, JGA_HUFF_OPT_TRACE = 1, 2, 3, 4
 
 
 # SURVEY.md §8b ABI numbers (x86-64 SysV)

@@ -177,9 +177,22 @@ JGA_EXPORT long jga_band_file(const unsigned char *file, long size, const jga_ba
   long need, o, pos, end;
   int next = 0;
   if (!file || !band) return -jga_fail("jga_band_file: bad arguments");
+  if (size > 0x7fffffffL) return -jga_fail("jga_band_file: file too large");
+  /* (the same gate as jga_band_plan: a band is only ever cut out of a file the header parser accepts) */
+  {
+    jpeg_header h;
+    if (jga_parse_header(file, (int)size, &h) != EXIT_SUCCESS) return -EXIT_FAILURE;
+  }
   if (walk(file, size, &w) != EXIT_SUCCESS) return -EXIT_FAILURE;
+  /* no SOF0 seen: sof_height_off would still be 0 and the height would land on the SOI bytes */
+  if (w.hmax < 1 || w.vmax < 1 || w.sof_height_off < 4) return -jga_fail("jga_band_file: no frame header");
   if (band->scan_off < w.scan0 || band->scan_bytes < 0 || band->scan_off + band->scan_bytes > size
    || band->rows < 1 || band->rows > 65535) return -jga_fail("jga_band_file: band outside the file");
+  /* a band of THIS file begins at the scan's first byte or right behind an RSTn, and is no taller than the frame
+   * (a jga_band planned on another file can pass the range test above by accident) */
+  if (band->scan_off > w.scan0 && !(file[band->scan_off - 2] == 0xFF && file[band->scan_off - 1] >= 0xD0
+   && file[band->scan_off - 1] <= 0xD7)) return -jga_fail("jga_band_file: the band does not start at a restart marker of this file");
+  if (band->y0 < 0 || (long)band->y0 + band->rows > w.height) return -jga_fail("jga_band_file: band outside the frame");
   need = w.scan0 + band->scan_bytes + 2;
   if (!out) return need;
   if (cap < need) return -jga_fail("jga_band_file: %ld bytes needed, %ld given", need, cap);

@@ -13,6 +13,22 @@
 #define HIP_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
   return jga_fail("HIP error %d (%s) at %s", (int)e_, hipGetErrorString(e_), #call); } while (0)
 
+// Two timing events that are destroyed on every way out of the function that holds them (the timing entry points
+// below are called in loops by the bench: an early return must not leak a pair per call).
+namespace {
+struct event_pair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t create() {
+    hipError_t e = hipEventCreate(&e0);
+    return e != hipSuccess ? e : hipEventCreate(&e1);
+  }
+  ~event_pair() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+}  // namespace
+
 static jga_divisor make_divisor(uint32_t d) {
   jga_divisor r;
   uint32_t s = 0;
@@ -304,12 +320,12 @@ JGA_EXPORT int jga_time_idct_batch(const jga_geom *g, int nimages,
  const short *d_coef, long long coef_stride, const unsigned short *d_qtab,
  int dequant_on_device, unsigned char *d_out, long long out_stride, int rgb,
  int reps, void *stream, float *ms) {
-  hipEvent_t e0, e1;
+  event_pair ev;
   int i, rc = EXIT_SUCCESS;
   float t = 0.0f;
   if (reps < 1) reps = 1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(ev.create());
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
   for (i = 0; i < reps && rc == EXIT_SUCCESS; i++) {
     rc = rgb ? jga_idct_rgb_batch(g, nimages, d_coef, coef_stride, d_qtab,
@@ -320,8 +336,6 @@ JGA_EXPORT int jga_time_idct_batch(const jga_geom *g, int nimages,
   HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
   HIP_TRY(hipEventSynchronize(e1));
   HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (ms) *ms = t/(float)reps;
   return rc;
 }
@@ -329,18 +343,16 @@ JGA_EXPORT int jga_time_idct_batch(const jga_geom *g, int nimages,
 // The copy ceiling beside the kernels' rates ("state the measured copy ceiling next to the spec"):
 // `reps` hipMemcpyDtoDAsync of `bytes` between two device buffers, HIP events on `stream` around them.
 JGA_EXPORT int jga_time_device_copy(void *d_dst, const void *d_src, size_t bytes, int reps, void *stream, float *ms) {
-  hipEvent_t e0, e1;
+  event_pair ev;
   float t = 0.0f;
   if (reps < 1) reps = 1;
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(ev.create());
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
   for (int i = 0; i < reps; i++) HIP_TRY(hipMemcpyDtoDAsync(d_dst, const_cast<void *>(d_src), bytes, (hipStream_t)stream));
   HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
   HIP_TRY(hipEventSynchronize(e1));
   HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (ms) *ms = t/(float)reps;
   return EXIT_SUCCESS;
 }
@@ -349,12 +361,12 @@ JGA_EXPORT int jga_time_device_copy(void *d_dst, const void *d_src, size_t bytes
 // 16 bytes per lane per trip.  bytes a multiple of 16.
 extern "C" int jga_launch_stream_copy(void *dst, const void *src, size_t bytes, int grid, void *stream);
 JGA_EXPORT int jga_time_kernel_copy(void *d_dst, const void *d_src, size_t bytes, int grid, int reps, void *stream, float *ms) {
-  hipEvent_t e0, e1;
+  event_pair ev;
   float t = 0.0f;
   if (reps < 1) reps = 1;
   if (grid < 1 || (bytes & 15)) return jga_fail("jga_time_kernel_copy: bad arguments");
-  HIP_TRY(hipEventCreate(&e0));
-  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(ev.create());
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   HIP_TRY(hipEventRecord(e0, (hipStream_t)stream));
   for (int i = 0; i < reps; i++) {
     if (jga_launch_stream_copy(d_dst, d_src, bytes, grid, stream) != 0) return jga_fail("copy kernel launch failed");
@@ -362,8 +374,6 @@ JGA_EXPORT int jga_time_kernel_copy(void *d_dst, const void *d_src, size_t bytes
   HIP_TRY(hipEventRecord(e1, (hipStream_t)stream));
   HIP_TRY(hipEventSynchronize(e1));
   HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (ms) *ms = t/(float)reps;
   return EXIT_SUCCESS;
 }

@@ -51,8 +51,6 @@ struct jga_huff_batch {
   int image_errors;            // images of the last decode whose data was damaged
   int assist_hint;             // the previous decode needed the host walk
   int spec_rounds;             // rounds queued before the speculative tail (0: not yet decided)
-  hipStream_t side;            // clears the DC arrays and the planes' padding slots while the rounds run on the caller's stream
-  hipEvent_t ev_begin, ev_zeroed;
   hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
   int blocking_waits;
   int device_shared;                    // other decodes run beside this one (jga_huff_set_device_shared)
@@ -71,18 +69,18 @@ struct jga_huff_batch {
   int device_unstuff, unstuffed_on_device;
   int inputs_pinned;           // callers' JPEG buffers are pinned/registered: DMA the scans straight from them
   long long host_bytes;        // bytes of the callers' files the last prepare() read on the host
-  int assist_after, speculate, trace, pieces;   // jga_huff_set_option (0: defaults)
-  // a batch whose upload arrives in pieces (JGA_HUFF_OPT_PIECES): prepare() has queued the start states and the
-  // first synchronisation round of every piece behind that piece's upload; the next decode goes on from round 1
-  int round0_queued;           // (how many rounds: the decode goes on from that one)
-  int npieces;                 // pieces of the last prepare()'s upload (0: one upload, ev_up)
-  // pieces' uploads alternate between two copy streams of the batch's own (a 0.8 MB file DMA'd where it lies moves
-  // at 32 GB/s on one stream, two streams fill the link; and kernels and copies of ONE stream run in order: the
-  // next piece's copy would wait for this piece's rounds), their kernels go round three streams (a piece's rounds
-  // are a chain of short launches: three chains side by side keep up with the link), the caller's stream waits for
-  // all of them
-  hipStream_t own_copy[2], piece_st[3];
-  hipEvent_t ev_piece[16], ev_sync[16], ev_pieces_begin;
+  int assist_after, speculate, trace;   // jga_huff_set_option (0: defaults)
+  hipEvent_t arrived;          // the event that says "the last prepare()'s bytes are on the device"
+  bool qtab_on_device;         // the last prepare() put the quantisers into the blob (jga_huff_qtabs_device)
+  size_t off_qtab;
+  // a decode in two halves (jga_huff_decode_split_begin / _end): what _begin queued
+  struct {
+    bool active, with_tail;
+    short *d_coef, *d_dc;
+    long long coef_stride, dc_stride;
+    hipStream_t st;
+    int round;
+  } pend;
   size_t off_raw, off_uimg, off_part, off_bnd, off_info, off_perr;
   int max_chunks;
   jga_geom geom;
@@ -133,7 +131,8 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   const size_t seg_cap = b->sub_cap;   // worst case one segment per subsequence
   b->blob_cap = align_up(sizeof(hj_image)*max_images, 256) + align_up(sizeof(hj_segment)*seg_cap, 256)
    + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_tables)*max_images, 256)
-   + align_up(8*(b->sub_cap + seg_cap), 256) + align_up((size_t)max_scan_bytes + 64*max_images, 256);
+   + align_up(8*(b->sub_cap + seg_cap), 256) + align_up((size_t)max_scan_bytes + 64*max_images, 256)
+   + align_up(384*(size_t)max_images, 256);
   bool ok = hipHostMalloc((void **)&b->h_blob, b->blob_cap, hipHostMallocDefault) == hipSuccess
    && hipMalloc((void **)&b->d_blob, b->blob_cap) == hipSuccess
    && hipMalloc((void **)&b->d_last_in, 8*b->sub_cap) == hipSuccess
@@ -143,11 +142,9 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS) == hipSuccess
    && hipMalloc((void **)&b->d_errors, 4*(size_t)max_images) == hipSuccess
    && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess
-   && hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking) == hipSuccess
-   && hipEventCreateWithFlags(&b->ev_begin, hipEventDisableTiming) == hipSuccess
-   && hipEventCreateWithFlags(&b->ev_zeroed, hipEventDisableTiming) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) == hipSuccess;
+  b->arrived = b->ev_up;
   if (!ok) {
     jga_fail("huff: allocation failed (%d images, %lld scan bytes)", max_images, max_scan_bytes);
     jga_huff_destroy(b);
@@ -170,14 +167,6 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_dcpart) (void)hipFree(b->d_dcpart);
   if (b->d_ran) (void)hipFree(b->d_ran);
   if (b->d_errors) (void)hipFree(b->d_errors);
-  if (b->side) (void)hipStreamDestroy(b->side);
-  for (hipStream_t s_ : b->own_copy) if (s_) (void)hipStreamDestroy(s_);
-  for (hipStream_t s_ : b->piece_st) if (s_) (void)hipStreamDestroy(s_);
-  for (hipEvent_t e : b->ev_piece) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : b->ev_sync) if (e) (void)hipEventDestroy(e);
-  if (b->ev_pieces_begin) (void)hipEventDestroy(b->ev_pieces_begin);
-  if (b->ev_begin) (void)hipEventDestroy(b->ev_begin);
-  if (b->ev_zeroed) (void)hipEventDestroy(b->ev_zeroed);
   if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);
   delete b;
@@ -285,83 +274,20 @@ static int auto_iters(const jga_huff_batch *b) {
    && b->total_seg > 0 && b->total_sub/b->total_seg >= 64u;
   return long_intervals ? 6 : 3;
 }
-// Images [i0, i1) of the batch have landed (the caller has made `st` wait for their upload): their start
-// states and their first synchronisation round, exactly as a decode's first launches would run them.
-static int piece_events(jga_huff_batch *b, int np) {
-  for (int k = 0; k < np; k++) {
-    if (!b->ev_piece[k]) HOK(hipEventCreateWithFlags(&b->ev_piece[k], hipEventDisableTiming));
-  }
-  return EXIT_SUCCESS;
-}
-#define HJ_PIECE_ROUNDS 6
-static int queue_piece_start(jga_huff_batch *b, int i0, int i1, uint32_t seg_base, uint32_t nsegs, uint32_t max_nsub,
- hipStream_t st) {
-  const round_knobs &K = the_round_knobs();
-  hj_args A;
-  fill_sync_args(b, A);
-  A.images += i0;
-  A.tables += i0;
-  A.nimages = i1 - i0;
-  if (hj_launch_init_piece(&A, (int)seg_base, (int)nsegs, (int)max_nsub, st)) return jga_fail("huff: launch failed");
-  const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;
-  const int it0 = K.it0 > 0 ? K.it0 : auto_iters(b), it1 = K.it1 > 0 ? K.it1 : auto_iters(b);
-  // the piece's whole first burst of rounds (HJ_PIECE_ROUNDS: what a photograph settles in): its chain of
-  // synchronisation steps is over by the time the last piece lands, whose own chain is what is left
-  for (int r = 0; r < HJ_PIECE_ROUNDS; r++) {
-    const int kind = long_subs || (K.sparse_from >= 0 ? r >= K.sparse_from : r >= 1) ? 1 : K.lean ? -1 : 0;
-    if (hj_launch_round(&A, (int)max_nsub, r, r ? it1 : it0, kind, st)) return jga_fail("huff: launch failed");
-  }
-  return EXIT_SUCCESS;
-}
-// Streams and events of piece k: its upload goes on *up, its kernels on *ps (which has been made to wait for
-// whatever the caller had queued on `st` before prepare()).
-static int piece_streams(jga_huff_batch *b, int k, hipStream_t *up, hipStream_t *ps) {
-  hipStream_t &c = b->own_copy[k & 1], &p = b->piece_st[k % 3];
-  if (!c) HOK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
-  if (!p) HOK(hipStreamCreateWithFlags(&p, hipStreamNonBlocking));
-  *up = b->copy_stream ? b->copy_stream : c;
-  *ps = p;
-  return EXIT_SUCCESS;
-}
-static int pieces_begin(jga_huff_batch *b, int np, hipStream_t st) {
-  if (piece_events(b, np) != EXIT_SUCCESS) return EXIT_FAILURE;
-  for (int k = 0; k < np; k++) {
-    if (!b->ev_sync[k]) HOK(hipEventCreateWithFlags(&b->ev_sync[k], hipEventDisableTiming));
-  }
-  if (!b->ev_pieces_begin) HOK(hipEventCreateWithFlags(&b->ev_pieces_begin, hipEventDisableTiming));
-  HOK(hipMemsetAsync(b->d_ran, 0, 4*HJ_MAX_ROUNDS, st));        // (the pieces' rounds flag ran[])
-  HOK(hipEventRecord(b->ev_pieces_begin, st));
-  for (int q = 0; q < 3 && q < np; q++) {
-    hipStream_t up, ps;
-    if (piece_streams(b, q, &up, &ps) != EXIT_SUCCESS) return EXIT_FAILURE;
-    HOK(hipStreamWaitEvent(ps, b->ev_pieces_begin, 0));
-  }
-  return EXIT_SUCCESS;
-}
-// Piece boundaries: `pieces` runs of consecutive images of about equal byte counts (piece k = images
-// [cut[k], cut[k+1])); fewer when the batch has fewer images.
-static std::vector<int> cut_pieces(const std::vector<uint32_t> &bytes, int pieces) {
-  const int n = (int)bytes.size();
-  uint64_t total = 0;
-  for (uint32_t v : bytes) total += v;
-  std::vector<int> cut{0};
-  uint64_t run = 0;
-  for (int i = 0; i < n; i++) {
-    run += bytes[(size_t)i];
-    const int k = (int)cut.size();                             // pieces closed so far + 1
-    if (k < pieces && i + 1 < n && run*(uint64_t)pieces >= total*(uint64_t)k) cut.push_back(i + 1);
-  }
-  cut.push_back(n);
-  return cut;
-}
-
 // prepare() with the unstuffing left to the device: the host parses the marker segments
-// (phase A, as below), copies the RAW entropy-coded bytes of every image into the pinned blob,
-// uploads, and queues unstuff_kernels.hip behind the copy.  Per-lane arrays are sized by what
-// the raw lengths allow (a clean stream is never longer than the raw one): image i may own up
-// to ceil(avail/sub) + nseg subsequences; how many it really has is known on the device only.
+// (phase A, as below) and the device does the rest (unstuff_kernels.hip).  The RAW entropy-coded
+// bytes of image i either stay where they lie — the copy engine reads them out of the caller's buffer, one copy
+// call per file naming it (pinned or registered memory; or ordinary memory, which the runtime then pins per copy) —
+// or a host core copies them into the pinned blob and runs of such files go up from there.
+// (Round 5 also built a third way — the first clean-up pass READING pinned files over the link itself, no copy call
+// at all: 57 GB/s from one launch against 33 per stream for copy calls per 0.8 MB file — and took it out again: a
+// kernel with host reads in flight slows every kernel working in HBM beside it two- to fourfold, the copy engines
+// do not; tools/r5_probes.hip `contend`, profiles/r5_fetch_by_kernel.md.)
+// Per-lane arrays are sized by what the raw lengths allow (a clean stream is never longer than the raw one): image i
+// may own up to ceil(avail/sub) + nseg subsequences; how many it really has is known on the device only.
 static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, const int *sizes, int n,
  jga_geom *geom, void *stream) {
+  enum { COPIED = 0, NAMED = 1 };
   std::vector<hj_prepared> prep((size_t)n);
   std::atomic<int> next_a(0), next_b(0), failed(0), irregular(0);
   const bool trace = b->trace != 0;
@@ -372,24 +298,20 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     if (nt > 64) nt = 64;
   }
   if (nt > n) nt = n;
-  // which files are DMA'd where they lie: all (jga_huff_set_inputs_pinned), or those the caller flagged
-  std::vector<unsigned char> in_place((size_t)n, (unsigned char)(b->inputs_pinned != 0));
+  std::vector<unsigned char> how((size_t)n, (unsigned char)(b->inputs_pinned ? NAMED : COPIED));
   if (!b->input_flags.empty()) {
-    for (int i = 0; i < n; i++) in_place[(size_t)i] = (size_t)i < b->input_flags.size() && b->input_flags[(size_t)i] != 0;
+    for (int i = 0; i < n; i++) how[(size_t)i] = (size_t)i < b->input_flags.size() && b->input_flags[(size_t)i] ? NAMED : COPIED;
   }
   int n_in_place = 0;
-  for (int i = 0; i < n; i++) n_in_place += in_place[(size_t)i];
-  // files that stay where they are leave 10-30 us of host work per image (marker parse, tables):
-  // starting and joining a thread team costs more than it saves until the batch is large — except
-  // when the upload goes in pieces, where the first piece waits for ALL the heads (a 77-file batch:
-  // 2.3 ms on one thread, round 4's first trace of a short job)
-  if (n_in_place == n && n <= 128) nt = b->pieces > 1 && n > 16 ? (nt < (n + 7)/8 ? nt : (n + 7)/8) : 1;
+  for (int i = 0; i < n; i++) n_in_place += how[(size_t)i] != COPIED;
+  // files that stay where they are leave a few microseconds of host work per image (marker parse; the tables of a
+  // file that brings the same DHT segments as the one before it are not built again): starting and joining a
+  // thread team costs more than it saves until the batch is large
+  if (n_in_place == n && n <= 128) nt = 1;
   b->host_bytes = 0;
   b->qtab.assign((size_t)n*192, 0);
   b->verdict.assign((size_t)n, 0);
   b->nimages = 0;
-  b->round0_queued = 0;
-  b->npieces = 0;
   auto heads = [&]() {
     for (int i = next_a.fetch_add(1); i < n; i = next_a.fetch_add(1)) {
       const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
@@ -448,9 +370,13 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   const size_t raw_bytes = align_up(o, 256);
   size_t q = 0;
   b->off_raw = q; q += raw_bytes;
+  // [images | tables | unstuff descriptors | per-image results, preset | quantisers]: one copy call
   b->off_images = q; q += align_up(sizeof(hj_image)*n, 256);
   b->off_tables = q; q += align_up(sizeof(hj_tables)*n, 256);
   b->off_uimg = q; q += align_up(sizeof(hj_unstuff_image)*n, 256);
+  b->off_info = q; q += align_up(sizeof(hj_unstuff_info)*n, 256);
+  b->off_perr = q; q += align_up(4*(size_t)n, 256);
+  b->off_qtab = q; q += align_up(384*(size_t)n, 256);
   b->upload_size = q;                                        // what crosses PCIe
   b->off_scan = q; q += raw_bytes;                           // the clean streams, same offsets as the raw ones
   b->off_segs = q; q += align_up(sizeof(hj_segment)*total_seg, 256);
@@ -458,8 +384,6 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->off_S = q; q += align_up(8*(total_sub + total_seg), 256);
   b->off_part = q; q += align_up(8*total_chunks, 256);
   b->off_bnd = q; q += align_up(4*total_seg, 256);
-  b->off_info = q; q += align_up(sizeof(hj_unstuff_info)*n, 256);
-  b->off_perr = q; q += align_up(4*(size_t)n, 256);
   b->blob_size = q;
   const size_t need_sub = total_sub > total_seg ? total_sub : total_seg;
   if ((need_sub > b->sub_cap || q > b->blob_cap) && !grow_batch(b, need_sub, q)) {
@@ -467,7 +391,6 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   }
   hj_image *images = (hj_image *)(b->h_blob + b->off_images);
   hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
-  memcpy(b->h_blob + b->off_uimg, uimg.data(), sizeof(hj_unstuff_image)*(size_t)n);
   b->nimages = n;
   b->total_sub = (uint32_t)total_sub;
   b->total_seg = (uint32_t)total_seg;
@@ -485,134 +408,13 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->shadow.clear();
   hipStream_t st = (hipStream_t)stream;
   hipStream_t up = b->copy_stream ? b->copy_stream : st;       // (see jga_huff_set_copy_stream)
-  // ---- the upload in pieces (JGA_HUFF_OPT_PIECES): runs of consecutive images of about equal byte counts go up
-  // one after the other on a copy stream of their own, and behind each one's arrival its clean-up, its start
-  // states and its first synchronisation round are queued at once — the device works on the first images
-  // while the link still carries the last (a short job's tail after its upload is what it waits for)
-  if (b->pieces > 1 && n >= 2) {
-    std::vector<uint32_t> sizes_v((size_t)n);
-    for (int i = 0; i < n; i++) sizes_v[(size_t)i] = prep[i].avail;
-    const std::vector<int> cut = cut_pieces(sizes_v, b->pieces < 16 ? b->pieces : 16);
-    const int np = (int)cut.size() - 1;
-    if (pieces_begin(b, np, st) != EXIT_SUCCESS) { b->nimages = 0; return EXIT_FAILURE; }
-    std::vector<int> piece_of((size_t)n);
-    std::vector<std::atomic<int>> left((size_t)np);
-    for (int k = 0; k < np; k++) {
-      left[(size_t)k].store(cut[(size_t)k + 1] - cut[(size_t)k]);
-      for (int i = cut[(size_t)k]; i < cut[(size_t)k + 1]; i++) piece_of[(size_t)i] = k;
-    }
-    for (int i = 0; i < n; i++) if (!in_place[(size_t)i]) b->host_bytes += (long long)prep[i].avail;
-    std::mutex qm;
-    bool gated = false;
-    std::atomic<int> queue_failed(0);
-    hj_unstuff_args U0;
-    memset(&U0, 0, sizeof(U0));
-    U0.raw = b->d_blob + b->off_raw;
-    U0.clean = b->d_blob + b->off_scan;
-    U0.images = (hj_image *)(b->d_blob + b->off_images);
-    U0.segs = (hj_segment *)(b->d_blob + b->off_segs);
-    U0.uimg = (const hj_unstuff_image *)(b->d_blob + b->off_uimg);
-    U0.part = (uint32_t *)(b->d_blob + b->off_part);
-    U0.bnd = (uint32_t *)(b->d_blob + b->off_bnd);
-    U0.info = (hj_unstuff_info *)(b->d_blob + b->off_info);
-    U0.errors = (uint32_t *)(b->d_blob + b->off_perr);
-    U0.sub_log2 = b->sub_log2;
-    auto queue_piece = [&](int k) -> int {
-      const int i0 = cut[(size_t)k], i1 = cut[(size_t)k + 1], cnt = i1 - i0;
-      hipStream_t up, ps;
-      if (piece_streams(b, k, &up, &ps) != EXIT_SUCCESS) return EXIT_FAILURE;
-      for (int i = i0; i < i1; ) {
-        if (in_place[(size_t)i]) {
-          HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
-           prep[i].avail, hipMemcpyHostToDevice, up));
-          i++;
-          continue;
-        }
-        int j = i;
-        while (j + 1 < i1 && !in_place[(size_t)j + 1]) j++;
-        const size_t from = uimg[(size_t)i].raw_off, to = (size_t)uimg[(size_t)j].raw_off + uimg[(size_t)j].avail;
-        HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, to - from, hipMemcpyHostToDevice, up));
-        i = j + 1;
-      }
-      const size_t slices[3][2] = {{b->off_images + sizeof(hj_image)*(size_t)i0, sizeof(hj_image)*(size_t)cnt},
-       {b->off_tables + sizeof(hj_tables)*(size_t)i0, sizeof(hj_tables)*(size_t)cnt},
-       {b->off_uimg + sizeof(hj_unstuff_image)*(size_t)i0, sizeof(hj_unstuff_image)*(size_t)cnt}};
-      for (const auto &sl : slices) HOK(hipMemcpyAsync(b->d_blob + sl[0], b->h_blob + sl[0], sl[1], hipMemcpyHostToDevice, up));
-      HOK(hipEventRecord(b->ev_piece[k], up));
-      HOK(hipStreamWaitEvent(ps, b->ev_piece[k], 0));
-      HOK(hipMemsetAsync(b->d_blob + b->off_info + sizeof(hj_unstuff_info)*(size_t)i0, 0xFF, sizeof(hj_unstuff_info)*(size_t)cnt, ps));
-      HOK(hipMemsetAsync(b->d_blob + b->off_perr + 4*(size_t)i0, 0, 4*(size_t)cnt, ps));
-      hj_unstuff_args U = U0;
-      U.images += i0; U.uimg += i0; U.info += i0; U.errors += i0;
-      U.nimages = cnt;
-      uint32_t chunks = 1, nsegs = 0, nsub_max = 1;
-      for (int i = i0; i < i1; i++) {
-        const hj_unstuff_image &u = uimg[(size_t)i];
-        if (u.nchunks > chunks) chunks = u.nchunks;
-        nsegs += u.nseg;
-        const uint32_t bound = ((u.avail + (1u << b->sub_log2) - 1) >> b->sub_log2) + u.nseg;
-        if (bound > nsub_max) nsub_max = bound;
-      }
-      if (hj_launch_unstuff(&U, (int)chunks, ps)) return jga_fail("huff: launch failed");
-      if (queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, ps) != EXIT_SUCCESS) return EXIT_FAILURE;
-      HOK(hipEventRecord(b->ev_sync[k], ps));
-      HOK(hipStreamWaitEvent(st, b->ev_sync[k], 0));
-      return EXIT_SUCCESS;
-    };
-    auto work = [&]() {
-      for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
-        hj_prepared &p = prep[i];
-        if (!in_place[(size_t)i]) memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + p.desc->scan_off, p.avail);
-        p.im.sub0 = sub0v[(size_t)i];
-        p.im.seg0 = seg0v[(size_t)i];
-        p.im.scan_off = uimg[(size_t)i].raw_off;
-        p.im.nseg = uimg[(size_t)i].nseg;
-        p.im.nsub = 0;                                         // (the device fills these two in)
-        p.im.scan_len = 0;
-        images[i] = p.im;
-        tables[i] = p.tabs;
-        memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
-        const int k = piece_of[(size_t)i];
-        if (left[(size_t)k].fetch_sub(1) == 1) {                // the piece's last image: off it goes
-          {
-            // (only the turn on the link is taken one at a time: the ~35 API calls of a piece cost their thread
-            // 0.2 ms, and eight pieces queued one after the other kept the last one's upload waiting 1.5 ms)
-            std::lock_guard<std::mutex> lk(qm);
-            if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
-            gated = true;
-          }
-          if (queue_piece(k) != EXIT_SUCCESS) queue_failed.store(1);
-        }
-      }
-    };
-    {
-      std::vector<std::thread> pool;
-      for (int t = 1; t < nt; t++) pool.emplace_back(work);
-      work();
-      for (auto &th : pool) th.join();
-    }
-    if (queue_failed.load()) {
-      for (hipStream_t s_ : b->own_copy) if (s_) (void)hipStreamSynchronize(s_);   // (copies out of the callers' buffers may be in flight)
-      if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
-      for (hipStream_t s_ : b->piece_st) if (s_) (void)hipStreamSynchronize(s_);
-      (void)hipStreamSynchronize(st);
-      b->nimages = 0;
-      return EXIT_FAILURE;
-    }
-    b->round0_queued = HJ_PIECE_ROUNDS;
-    b->npieces = np;
-    if (trace) {
-      fprintf(stderr, "  prepare (device clean-up, %d of %d files in place, %d threads, %d pieces): %.2f ms\n", n_in_place, n, nt, np,
-       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
-    }
-    if (geom) *geom = b->geom;
-    return EXIT_SUCCESS;
-  }
-  const bool zero_copy = n_in_place > 0;
+  memcpy(b->h_blob + b->off_uimg, uimg.data(), sizeof(hj_unstuff_image)*(size_t)n);
+  memset(b->h_blob + b->off_info, 0xFF, sizeof(hj_unstuff_info)*(size_t)n);   // (hard_end = "none yet")
+  memset(b->h_blob + b->off_perr, 0, 4*(size_t)n);
   auto copies = [&]() {
     for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
       hj_prepared &p = prep[i];
-      if (!in_place[(size_t)i]) memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + p.desc->scan_off, p.avail);
+      if (how[(size_t)i] == COPIED) memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + p.desc->scan_off, p.avail);
       p.im.sub0 = sub0v[(size_t)i];
       p.im.seg0 = seg0v[(size_t)i];
       p.im.scan_off = uimg[(size_t)i].raw_off;
@@ -630,38 +432,33 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     copies();
     for (auto &th : pool) th.join();
   }
+  memcpy(b->h_blob + b->off_qtab, b->qtab.data(), 384*(size_t)n);
+  b->qtab_on_device = true;
   int ncopies = 1;
   for (int i = 0; i < n; i++) {
-    if (!in_place[(size_t)i]) b->host_bytes += (long long)prep[i].avail;
-    if (in_place[(size_t)i] || (i > 0 && in_place[(size_t)i - 1])) ncopies++;
+    if (how[(size_t)i] == COPIED) b->host_bytes += (long long)prep[i].avail;
+    if (how[(size_t)i] == NAMED || i == 0 || how[(size_t)i - 1] != COPIED) ncopies++;
   }
   if (b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, ncopies);
   const auto t_1 = std::chrono::steady_clock::now();
-  if (zero_copy) {
-    // files lying in pinned / registered memory: the DMA engine reads their scans where they are
-    // (the host never touches an entropy-coded byte); runs of files that were copied into the blob go up
-    // from there, one copy call per run, and so do the descriptors + tables
-    for (int i = 0; i < n; ) {
-      if (in_place[(size_t)i]) {
-        HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
-         prep[i].avail, hipMemcpyHostToDevice, up));
-        i++;
-        continue;
-      }
-      int j = i;
-      while (j + 1 < n && !in_place[(size_t)j + 1]) j++;
-      const size_t from = uimg[(size_t)i].raw_off, to = (size_t)uimg[(size_t)j].raw_off + uimg[(size_t)j].avail;
-      HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, to - from, hipMemcpyHostToDevice, up));
-      i = j + 1;
+  // copy calls: files the copy engine reads where they lie, runs of files a host core put into the blob, and the
+  // descriptors
+  for (int i = 0; i < n; ) {
+    if (how[(size_t)i] == NAMED) {
+      HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
+       prep[i].avail, hipMemcpyHostToDevice, up));
+      i++;
+      continue;
     }
-    HOK(hipMemcpyAsync(b->d_blob + b->off_images, b->h_blob + b->off_images, b->upload_size - b->off_images,
-     hipMemcpyHostToDevice, up));
+    int j = i;
+    while (j + 1 < n && how[(size_t)j + 1] == COPIED) j++;
+    const size_t from = uimg[(size_t)i].raw_off, to = (size_t)uimg[(size_t)j].raw_off + uimg[(size_t)j].avail;
+    HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, to - from, hipMemcpyHostToDevice, up));
+    i = j + 1;
   }
-  else HOK(hipMemcpyAsync(b->d_blob, b->h_blob, b->upload_size, hipMemcpyHostToDevice, up));
-  HOK(hipEventRecord(b->ev_up, up));                          // (jga_huff_wait_upload)
-  if (up != st) HOK(hipStreamWaitEvent(st, b->ev_up, 0));
-  HOK(hipMemsetAsync(b->d_blob + b->off_info, 0xFF, sizeof(hj_unstuff_info)*(size_t)n, st));
-  HOK(hipMemsetAsync(b->d_blob + b->off_perr, 0, 4*(size_t)n, st));
+  HOK(hipMemcpyAsync(b->d_blob + b->off_images, b->h_blob + b->off_images, b->upload_size - b->off_images,
+   hipMemcpyHostToDevice, up));
+  HOK(hipEventRecord(b->ev_up, up));
   hj_unstuff_args U;
   memset(&U, 0, sizeof(U));
   U.raw = b->d_blob + b->off_raw;
@@ -676,199 +473,15 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   U.nimages = n;
   U.sub_log2 = b->sub_log2;
   const auto t_2 = std::chrono::steady_clock::now();
+  if (up != st) HOK(hipStreamWaitEvent(st, b->ev_up, 0));
+  b->arrived = b->ev_up;
   if (hj_launch_unstuff(&U, b->max_chunks, st)) return jga_fail("huff: launch failed");
   if (trace) {
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) {
       return std::chrono::duration<double, std::milli>(c - a).count(); };
-    fprintf(stderr, "  prepare (device clean-up, %d of %d files in place, %d threads): heads + blob %.2f ms, %d copy call(s) + 2 memsets %.2f ms, 4 launches %.2f ms\n",
+    fprintf(stderr, "  prepare (device clean-up, %d of %d files in place, %d threads): heads + blob %.2f ms, %d copy call(s) %.2f ms, 4 launches %.2f ms\n",
      n_in_place, n, nt, ms(t_0, t_1), ncopies, ms(t_1, t_2),
      ms(t_2, std::chrono::steady_clock::now()));
-  }
-  if (geom) *geom = b->geom;
-  return EXIT_SUCCESS;
-}
-
-// prepare() with the clean-up on the host and the upload in pieces (JGA_HUFF_OPT_PIECES).  Everything a piece's
-// kernels need must be known when ITS images are clean, not when all are — so the lanes' index spaces are laid
-// out from what the headers promise instead of from what the scans turn out to hold: image i owns
-// ceil(avail / subsequence) + nseg subsequence slots (a clean stream is never longer than the raw one) and
-// the ceil(MCUs / DRI) segments its frame must have (hj_prepare_scan fails a file that has any other number).
-// The thread that cleans a piece's last image queues that piece: scan bytes + descriptors on the copy stream,
-// and behind their arrival the start states and the first synchronisation round.
-static int prepare_pieces_host(jga_huff_batch *b, const unsigned char *const *jpegs, const int *sizes, int n,
- jga_geom *geom, void *stream) {
-  const auto t_0 = std::chrono::steady_clock::now();
-  std::vector<hj_prepared> prep((size_t)n);
-  std::atomic<int> next_a(0), next_b(0), failed(0), irregular(0);
-  int nt = b->prepare_threads;
-  if (nt <= 0) {
-    nt = jga_cpu_budget();
-    if (nt > 64) nt = 64;
-  }
-  if (nt > n) nt = n;
-  b->unstuffed_on_device = 0;
-  b->host_bytes = 0;
-  b->round0_queued = 0;
-  b->qtab.assign((size_t)n*192, 0);
-  b->verdict.assign((size_t)n, 0);
-  b->nimages = 0;
-  auto heads = [&]() {
-    for (int i = next_a.fetch_add(1); i < n; i = next_a.fetch_add(1)) {
-      const int rc = hj_prepare_head(jpegs[i], sizes[i], &prep[i]);
-      if (rc != EXIT_SUCCESS) failed.fetch_add(1);
-      if (rc == HJ_PREPARE_IRREGULAR) irregular.fetch_add(1);
-      b->verdict[i] = (unsigned char)(rc == EXIT_SUCCESS ? 0 : rc == HJ_PREPARE_IRREGULAR ? 2 : 1);
-    }
-  };
-  {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; t++) pool.emplace_back(heads);
-    heads();
-    for (auto &th : pool) th.join();
-  }
-  if (irregular.load()) {
-    return jga_fail("huff: %d image(s) of the batch have Huffman tables too irregular (or a frame too "
-     "large) for the GPU entropy stage", irregular.load());
-  }
-  if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
-  std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n), nsegv((size_t)n), avail((size_t)n);
-  size_t o = 0, total_sub = 0, total_seg = 0;
-  for (int i = 0; i < n; i++) {
-    if (i && !same_geometry(prep[i].geom, prep[0].geom)) return jga_fail("huff: images of one batch must share a geometry");
-    scan_off[(size_t)i] = (uint32_t)o;
-    avail[(size_t)i] = prep[i].avail;
-    o += align_up((size_t)prep[i].avail + 16, 16);
-  }
-  if ((long long)o > b->max_scan + 64ll*n || o >= ((size_t)1 << 32)) {
-    return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
-  }
-  b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o, prep[0].im.nslots, prep[0].geom.restart_interval);
-  b->max_seg_mcus = 0; b->max_segs_image = 0;
-  for (int i = 0; i < n; i++) {
-    const jga_geom &g = prep[i].geom;
-    const uint32_t mcus = (uint32_t)g.nhmb*(uint32_t)g.nvmb, ri = (uint32_t)g.restart_interval;
-    nsegv[(size_t)i] = ri ? (mcus + ri - 1)/ri : 1u;
-    sub0v[(size_t)i] = (uint32_t)total_sub;
-    seg0v[(size_t)i] = (uint32_t)total_seg;
-    total_sub += ((prep[i].avail + (1u << b->sub_log2) - 1) >> b->sub_log2) + nsegv[(size_t)i];
-    total_seg += nsegv[(size_t)i];
-    const uint32_t sm = ri && ri < mcus ? ri : mcus;
-    if (sm > b->max_seg_mcus) b->max_seg_mcus = sm;
-    if (nsegv[(size_t)i] > b->max_segs_image) b->max_segs_image = nsegv[(size_t)i];
-    prep[i].sub_log2 = b->sub_log2;
-  }
-  b->off_scan = 0;
-  b->scan_bytes = 0;                                           // (nothing written yet: nothing to carry over if the blob grows)
-  {
-    size_t q = align_up(o, 256);
-    b->off_images = q; q += align_up(sizeof(hj_image)*n, 256);
-    b->off_segs = q; q += align_up(sizeof(hj_segment)*total_seg, 256);
-    b->off_tables = q; q += align_up(sizeof(hj_tables)*n, 256);
-    b->upload_size = q;
-    b->off_subseg = q; q += align_up(4*total_sub, 256);
-    b->off_S = q; q += align_up(8*(total_sub + total_seg), 256);
-    b->blob_size = q;
-    const size_t need_sub = total_sub > total_seg ? total_sub : total_seg;
-    if ((need_sub > b->sub_cap || q > b->blob_cap) && !grow_batch(b, need_sub, q)) {
-      return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
-    }
-  }
-  b->scan_bytes = align_up(o, 256);
-  b->total_sub = (uint32_t)total_sub;
-  b->total_seg = (uint32_t)total_seg;
-  b->geom = prep[0].geom;
-  b->max_nsub = 0;
-  const std::vector<int> cut = cut_pieces(avail, b->pieces < 16 ? b->pieces : 16);
-  const int np = (int)cut.size() - 1;
-  hipStream_t st = (hipStream_t)stream;
-  if (pieces_begin(b, np, st) != EXIT_SUCCESS) return EXIT_FAILURE;
-  std::vector<int> piece_of((size_t)n);
-  std::vector<std::atomic<int>> left((size_t)np);
-  for (int k = 0; k < np; k++) {
-    left[(size_t)k].store(cut[(size_t)k + 1] - cut[(size_t)k]);
-    for (int i = cut[(size_t)k]; i < cut[(size_t)k + 1]; i++) piece_of[(size_t)i] = k;
-  }
-  hj_image *images = (hj_image *)(b->h_blob + b->off_images);
-  hj_segment *segs = (hj_segment *)(b->h_blob + b->off_segs);
-  hj_tables *tables = (hj_tables *)(b->h_blob + b->off_tables);
-  std::mutex qm;
-  bool gated = false;
-  std::atomic<int> queue_failed(0);
-  uint32_t max_nsub = 0;                                        // (qm held)
-  auto queue_piece = [&](int k) -> int {
-    const int i0 = cut[(size_t)k], i1 = cut[(size_t)k + 1], cnt = i1 - i0;
-    const size_t from = scan_off[(size_t)i0], to = (size_t)scan_off[(size_t)i1 - 1] + align_up((size_t)avail[(size_t)i1 - 1] + 16, 16);
-    uint32_t nsegs = 0, nsub_max = 1;
-    for (int i = i0; i < i1; i++) {
-      nsegs += nsegv[(size_t)i];
-      if (prep[i].im.nsub > nsub_max) nsub_max = prep[i].im.nsub;
-    }
-    const size_t slices[4][2] = {{from, to - from},
-     {b->off_images + sizeof(hj_image)*(size_t)i0, sizeof(hj_image)*(size_t)cnt},
-     {b->off_segs + sizeof(hj_segment)*(size_t)seg0v[(size_t)i0], sizeof(hj_segment)*(size_t)nsegs},
-     {b->off_tables + sizeof(hj_tables)*(size_t)i0, sizeof(hj_tables)*(size_t)cnt}};
-    hipStream_t up, ps;
-    if (piece_streams(b, k, &up, &ps) != EXIT_SUCCESS) return EXIT_FAILURE;
-    for (const auto &sl : slices) HOK(hipMemcpyAsync(b->d_blob + sl[0], b->h_blob + sl[0], sl[1], hipMemcpyHostToDevice, up));
-    HOK(hipEventRecord(b->ev_piece[k], up));
-    HOK(hipStreamWaitEvent(ps, b->ev_piece[k], 0));
-    if (queue_piece_start(b, i0, i1, seg0v[(size_t)i0], nsegs, nsub_max, ps) != EXIT_SUCCESS) return EXIT_FAILURE;
-    HOK(hipEventRecord(b->ev_sync[k], ps));
-    HOK(hipStreamWaitEvent(st, b->ev_sync[k], 0));
-    return EXIT_SUCCESS;
-  };
-  auto work = [&]() {
-    for (int i = next_b.fetch_add(1); i < n; i = next_b.fetch_add(1)) {
-      hj_prepared &p = prep[i];
-      bool ok = hj_prepare_scan(jpegs[i], sizes[i], &p, b->h_blob + scan_off[(size_t)i]) == EXIT_SUCCESS;
-      if (ok && p.segs.size() != (size_t)nsegv[(size_t)i]) ok = false;      // (cannot happen: a file that passes has its frame's intervals)
-      if (!ok) {
-        failed.fetch_add(1);
-        b->verdict[i] = 1;
-        continue;                                              // (its piece is never queued; the whole prepare fails)
-      }
-      p.im.sub0 = sub0v[(size_t)i];
-      p.im.seg0 = seg0v[(size_t)i];
-      p.im.scan_off = scan_off[(size_t)i];
-      images[i] = p.im;
-      tables[i] = p.tabs;
-      memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
-      for (size_t si = 0; si < p.segs.size(); si++) segs[seg0v[(size_t)i] + si] = p.segs[si];
-      const int k = piece_of[(size_t)i];
-      if (left[(size_t)k].fetch_sub(1) == 1 && !failed.load()) { // the piece's last image: off it goes
-        {
-          std::lock_guard<std::mutex> lk(qm);                   // (the link turn, and the batch's widest piece)
-          if (!gated && b->before_upload) b->before_upload(b->before_upload_arg, (long long)b->upload_size, np);
-          gated = true;
-          for (int q = cut[(size_t)k]; q < cut[(size_t)k + 1]; q++) if (prep[q].im.nsub > max_nsub) max_nsub = prep[q].im.nsub;
-        }
-        if (queue_piece(k) != EXIT_SUCCESS) queue_failed.store(1);
-      }
-    }
-  };
-  {
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto &th : pool) th.join();
-  }
-  if (failed.load() || queue_failed.load()) {
-    // pieces already queued read the blob and run their rounds: wait them out before anybody reuses either
-    for (hipStream_t s_ : b->own_copy) if (s_) (void)hipStreamSynchronize(s_);
-    if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
-    for (hipStream_t s_ : b->piece_st) if (s_) (void)hipStreamSynchronize(s_);
-    (void)hipStreamSynchronize(st);
-    if (failed.load()) return jga_fail("huff: %d image(s) of the batch could not be prepared", failed.load());
-    return EXIT_FAILURE;
-  }
-  for (int i = 0; i < n; i++) b->host_bytes += (long long)avail[(size_t)i];
-  b->nimages = n;
-  b->max_nsub = max_nsub;
-  b->round0_queued = HJ_PIECE_ROUNDS;
-  b->npieces = np;
-  if (b->trace) {
-    fprintf(stderr, "  prepare (host clean-up, %d threads, %d pieces): %.2f ms\n", nt, np,
-     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
   }
   if (geom) *geom = b->geom;
   return EXIT_SUCCESS;
@@ -881,11 +494,9 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
  const int *sizes, int n, jga_geom *geom, void *stream) {
   if (n < 1 || n > b->max_images) return jga_fail("huff: batch size %d out of range", n);
   if (b->device_unstuff) return prepare_raw(b, jpegs, sizes, n, geom, stream);
-  if (b->pieces > 1 && n >= 2) return prepare_pieces_host(b, jpegs, sizes, n, geom, stream);
   b->unstuffed_on_device = 0;
   b->host_bytes = 0;
-  b->round0_queued = 0;
-  b->npieces = 0;
+  b->qtab_on_device = false;
   const auto t_p0 = std::chrono::steady_clock::now();
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
@@ -966,6 +577,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       b->off_images = o; o += align_up(sizeof(hj_image)*n, 256);
       b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
       b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
+      b->off_qtab = o; o += align_up(384*(size_t)n, 256);
       b->upload_size = o;           // what crosses PCIe; the rest is written by hj_init_states
       b->off_subseg = o; o += align_up(4*total_sub, 256);
       b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
@@ -1010,6 +622,9 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   if (fatal.load()) return jga_fail("huff: batch exceeds the capacity given to jga_huff_create");
   b->nimages = n;
   for (int i = 0; i < n; i++) b->host_bytes += (long long)prep[i].avail;
+  memcpy(b->h_blob + b->off_qtab, b->qtab.data(), 384*(size_t)n);
+  b->qtab_on_device = true;
+  b->arrived = b->ev_up;
   // the scan region is sized from the raw lengths; the bytes between an image's clean
   // stream (+16 pad) and the next image's start are never read
   const bool trace = b->trace != 0;
@@ -1051,11 +666,7 @@ JGA_EXPORT void jga_huff_set_blocking_waits(jga_huff_batch *b, int on) { b->bloc
 JGA_EXPORT void jga_huff_set_device_shared(jga_huff_batch *b, int on) { b->device_shared = on != 0; }
 // Wait until the last prepare()'s upload has arrived (its kernels, if it queued any, may still run).
 JGA_EXPORT int jga_huff_wait_upload(jga_huff_batch *b) {
-  for (int k = 0; k < b->npieces; k++) {      // (an upload in pieces: every piece's own event)
-    HOK(b->blocking_waits ? jga_event_wait_sleeping(b->ev_piece[k]) : hipEventSynchronize(b->ev_piece[k]));
-  }
-  if (b->npieces) return EXIT_SUCCESS;
-  HOK(b->blocking_waits ? jga_event_wait_sleeping(b->ev_up) : hipEventSynchronize(b->ev_up));
+  HOK(b->blocking_waits ? jga_event_wait_sleeping(b->arrived) : hipEventSynchronize(b->arrived));
   return EXIT_SUCCESS;
 }
 JGA_EXPORT void jga_huff_set_upload_gate(jga_huff_batch *b, void (*fn)(void *, long long, int), void *arg) {
@@ -1084,7 +695,6 @@ JGA_EXPORT int jga_huff_set_option(jga_huff_batch *b, int option, int value) {
       return value == 0 || b->force_sub_log2 ? EXIT_SUCCESS : jga_fail("huff: subsequence length %d (32, 64, 128, 256 or 512)", value);
     case JGA_HUFF_OPT_ASSIST_AFTER : b->assist_after = value > 0 ? value : 0; return EXIT_SUCCESS;
     case JGA_HUFF_OPT_SPECULATE : b->speculate = value < 0 ? -1 : 0; return EXIT_SUCCESS;
-    case JGA_HUFF_OPT_PIECES : b->pieces = value > 1 ? (value > 16 ? 16 : value) : 0; return EXIT_SUCCESS;
     case JGA_HUFF_OPT_TRACE : b->trace = value != 0; return EXIT_SUCCESS;
     default : return jga_fail("huff: unknown option %d", option);
   }
@@ -1096,6 +706,11 @@ JGA_EXPORT int jga_huff_last_rounds(const jga_huff_batch *b) { return b->last_ro
 JGA_EXPORT int jga_huff_last_assisted(const jga_huff_batch *b) { return b->last_assisted; }
 // Quantisation tables of the prepared batch: nimages*3*64 uint16 (host memory).
 JGA_EXPORT const unsigned short *jga_huff_qtabs(const jga_huff_batch *b) { return b->qtab.data(); }
+// The same in device memory: they went up with the last prepare()'s descriptors (valid once the stream prepare() was
+// given has passed its upload, i.e. for anything queued on that stream afterwards; until the next prepare()).
+JGA_EXPORT const unsigned short *jga_huff_qtabs_device(const jga_huff_batch *b) {
+  return b->qtab_on_device && b->nimages ? (const unsigned short *)(b->d_blob + b->off_qtab) : NULL;
+}
 
 // Decode the prepared batch into d_coef (image i at d_coef + i*coef_stride shorts).
 // May be called repeatedly on the same prepared batch (state is reset each time).
@@ -1158,9 +773,6 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
   return EXIT_SUCCESS;
 }
 
-static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
- hipStream_t st);
-
 // Wait for everything queued on `st`.  hipStreamSynchronize spins on a host core — the right
 // thing for one frame's latency, the wrong one for a pipeline whose lanes outnumber the CPUs
 // the container grants: there the waiting lane polls and sleeps (host_wait.h; an event with
@@ -1171,56 +783,27 @@ static hipError_t wait_stream(jga_huff_batch *b, hipStream_t st) {
   return jga_stream_wait_sleeping(st, b->ev_wait);
 }
 
-static int decode_checked(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
- void *stream) {
-  hipStream_t st = (hipStream_t)stream;
-  // verdicts of an earlier decode must not outlive it: a launch failure below would otherwise
-  // be read as "some members were damaged" by callers that look at jga_huff_image_errors()
-  b->image_errors = 0;
-  for (int i = 0; i < b->max_images; i++) b->h_ran[HJ_MAX_ROUNDS + i] = 0;
-  if (!b->nimages) return jga_fail("huff: nothing prepared");
-  if (coef_stride < b->geom.coef_shorts) return jga_fail("huff: coef_stride too small");
-  if (d_dc && dc_stride < b->geom.coef_shorts/64) return jga_fail("huff: dc_stride too small");
-  const int rc = decode_batch(b, d_coef, coef_stride, d_dc, dc_stride, st);
-  if (rc != EXIT_SUCCESS && !b->image_errors) {
-    // a launch or copy failed part-way: the clears on the side stream (and whatever
-    // rounds were queued) may still be running — the caller is free to reuse or release
-    // d_coef the moment this returns, so wait them out first
-    (void)hipStreamSynchronize(b->side);
-    (void)hipStreamSynchronize(st);
-  }
-  return rc;
-}
-
-// Finished QUANT-stage planes (DC prediction applied), as jga_entropy_decode() makes them on the host.
-JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
- void *stream) {
-  return decode_checked(b, d_coef, coef_stride, NULL, 0, stream);
-}
-
-// The same decode for a caller that runs a block-decode kernel next (jga_idct_*_batch_dc): the
-// planes' DC positions are left holding the DC DIFFERENCES, the DC values come in d_dc — image i
-// at d_dc + i*dc_stride, one int16 per 128-byte slot of the image's coefficient buffer
-// (dc_stride >= coef_shorts/64) — and the strided 2-byte pass over the planes that would put them
-// in place is saved.
-JGA_EXPORT int jga_huff_decode_split(jga_huff_batch *b, short *d_coef, long long coef_stride,
- short *d_dc, long long dc_stride, void *stream) {
-  if (!d_dc) return jga_fail("huff: jga_huff_decode_split needs a DC array");
-  return decode_checked(b, d_coef, coef_stride, d_dc, dc_stride, stream);
-}
-
 static double thread_cpu_ms() {
   timespec ts;
   clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
   return (double)ts.tv_sec*1e3 + (double)ts.tv_nsec*1e-6;
 }
 
-static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
- hipStream_t st) {
-  const bool trace = b->trace != 0;
-  double c0 = trace ? thread_cpu_ms() : 0.0, c_launch = 0.0, c_wait = 0.0;
-  auto lap = [&](double &acc) { if (trace) { const double c = thread_cpu_ms(); acc += c - c0; c0 = c; } };
+// ---- a decode, in two halves -------------------------------------------------------------------------------
+// decode_begin() queues the start states, the first burst of synchronisation rounds and — speculatively, see
+// below — the whole tail (prefix sums, write pass, DC values, verdict copy) and RETURNS: nothing has been waited
+// for.  decode_end() waits for the stream, looks at what the rounds reported and, if the speculation did not
+// hold (or was not made), goes on: more rounds, the host's walk over stretches that never fall into step, the
+// tail again.  A caller that runs a block-decode kernel next queues it between the two halves — one host wait
+// per decode instead of two, and the kernel is in the queue before anybody else's work can get between the
+// write pass and it — and asks decode_end() whether what it queued saw the final planes (`*valid_behind`).
+struct decode_plan {
   hj_args A;
+  int it0, it1, group, sparse_from, assist_after, lean;
+  bool speculate;
+};
+static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride, decode_plan &P) {
+  hj_args &A = P.A;
   fill_sync_args(b, A);
   {
     // DC differences (scan order) and, unless the caller brings its own array, DC values (by
@@ -1249,31 +832,14 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   }
   A.coef = (int16_t *)d_coef;
   A.coef_stride = coef_stride;
-  int round = 0;
-  if (b->round0_queued) {
-    // prepare() has queued every piece's start states and first round behind that piece's upload: go on
-    // from round 1 (the images' verdicts — what the on-device clean-up found, or nothing — are set here)
-    round = b->round0_queued;
-    b->round0_queued = 0;
-    if (b->unstuffed_on_device) {
-      HOK(hipMemcpyAsync(b->d_errors, b->d_blob + b->off_perr, 4*(size_t)b->nimages, hipMemcpyDeviceToDevice, st));
-    }
-    else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
-  }
-  // reset: states back to the guesses, "never ran"
-  // (on-device unstuffing has already had its say about every image: early end, RSTn counters)
-  else if (hj_launch_init(&A, (int)b->total_seg, (int)b->max_nsub,
-   b->unstuffed_on_device ? (const uint32_t *)(b->d_blob + b->off_perr) : NULL, st)) {
-    return jga_fail("huff: launch failed");
-  }
-  const int first_round = round;
-  b->last_assisted = 0;
-  b->image_errors = 0;
   const round_knobs &K = the_round_knobs();
   const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;     // no LDS rows that long: global-memory readers only
   const int it_auto = auto_iters(b);
-  const int it0 = K.it0 > 0 ? K.it0 : it_auto, it1 = K.it1 > 0 ? K.it1 : it_auto, group = K.group,
-            flush_lanes = K.flush_lanes, assist_after = b->assist_after > 0 ? b->assist_after : 12;
+  P.it0 = K.it0 > 0 ? K.it0 : it_auto;
+  P.it1 = K.it1 > 0 ? K.it1 : it_auto;
+  P.group = K.group;
+  P.lean = K.lean;
+  P.assist_after = b->assist_after > 0 ? b->assist_after : 12;
   // Which kernel runs the later rounds.  The sparse one (a wave per 256 subsequences, rows read from
   // global memory) is for batches that fill the device: there a dense launch pays staging for
   // every group that still has one moving lane.  Up to ~200k subsequences (8 x 4K, 32 x 1080p) the
@@ -1283,75 +849,117 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
   // (with other decodes beside it — a pipeline's lanes — the groups fill the device together: 1024 x 1080p
   // in groups of 32 ran 22.5 ms with the sparse kernel and 24.2 with the dense one)
   const bool small_batch = !b->device_shared && b->total_sub <= 200u*1024u;
-  const int sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from : small_batch ? HJ_MAX_ROUNDS : 1;
-  A.flush_lanes = flush_lanes;
+  P.sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from : small_batch ? HJ_MAX_ROUNDS : 1;
+  A.flush_lanes = K.flush_lanes;
   A.sub_log2 = b->sub_log2;
-  const int GROUP = group;
-  // What the write pass needs cleared (DC arrays, padding slots) is queued on the side stream AFTER
-  // the first burst of rounds has been handed to the device: the seven API calls take the host
-  // ~40 us, which a lone frame's first round used to spend waiting to be launched.
-  bool side_queued = false;
-  auto queue_side = [&]() -> int {
-    if (side_queued) return EXIT_SUCCESS;
-    side_queued = true;
-    HOK(hipStreamWaitEvent(b->side, b->ev_begin, 0));
-    // (the planes themselves need no clear: the write pass stores whole 128-byte lines, and the lines
-    // of blocks that two lanes share are zeroed by hj_scan<true> — only the slots at the end of a
-    // decimated plane that hold no block are cleared here, so that the buffer reads like the host
-    // stage's)
-    for (int p = 0; p < b->geom.nplanes; p++) {
-      const jga_plane_geom &pg = b->geom.plane[p];
-      const long long rs = (long long)b->geom.w0*8, used = (long long)pg.hblocks*pg.vblocks*64;
-      const long long end = p + 1 < b->geom.nplanes ? b->geom.plane[p + 1].coef_off : b->geom.coef_shorts;
-      if ((long long)pg.hblocks*64 != (rs >> pg.xdec)) {          // rows with gaps (rare samplings): clear it all
-        HOK(hipMemsetAsync(d_coef, 0, (size_t)coef_stride*2*(size_t)b->nimages, b->side));
-        break;
-      }
-      if (end > pg.coef_off + used) {
-        HOK(hipMemset2DAsync(d_coef + pg.coef_off + used, (size_t)coef_stride*2, 0, (size_t)(end - pg.coef_off - used)*2,
-         (size_t)b->nimages, b->side));
-      }
-    }
-    // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
-    HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
-    HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, b->side));
-    HOK(hipEventRecord(b->ev_zeroed, b->side));
-    return EXIT_SUCCESS;
+  P.speculate = b->speculate >= 0 && !b->assist_hint;
+  return EXIT_SUCCESS;
+}
+// What the write pass needs cleared (DC arrays, padding slots): one launch on the decode's stream (hj_clear).
+static int queue_clear(jga_huff_batch *b, const hj_args &A, hipStream_t st) {
+  hj_clear_args C;
+  memset(&C, 0, sizeof(C));
+  auto add = [&](void *base, uint64_t row_bytes, uint64_t stride, uint32_t rows) {
+    hj_clear_region &r = C.region[C.nregions++];
+    r.base = base; r.row_bytes = row_bytes; r.stride = stride; r.rows = rows;
   };
-  HOK(hipEventRecord(b->ev_begin, st));          // (the side stream starts behind whatever the caller queued before us)
-  // The tail of a decode: prefix sums, write pass, DC values, the images' verdicts.
-  auto queue_tail = [&]() -> int {
-    if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
-    HOK(hipStreamWaitEvent(st, b->ev_zeroed, 0));
-    if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
-    // DC differences -> DC values; into the planes too unless the caller takes the array itself
-    if (hj_launch_dc(&A, (int)b->total_seg, (int)b->max_seg_mcus, b->d_dcpart, d_dc ? 0 : (int)(b->geom.coef_shorts/64), st)) {
+  // (the planes themselves need no clear: the write pass stores whole 128-byte lines, and the lines
+  // of blocks that two lanes share are zeroed by hj_scan<true> — only the slots at the end of a
+  // decimated plane that hold no block are cleared here, so that the buffer reads like the host
+  // stage's)
+  for (int p = 0; p < b->geom.nplanes; p++) {
+    const jga_plane_geom &pg = b->geom.plane[p];
+    const long long rs = (long long)b->geom.w0*8, used = (long long)pg.hblocks*pg.vblocks*64;
+    const long long end = p + 1 < b->geom.nplanes ? b->geom.plane[p + 1].coef_off : b->geom.coef_shorts;
+    if ((long long)pg.hblocks*64 != (rs >> pg.xdec)) {          // rows with gaps (rare samplings): clear it all
+      C.nregions = 0;
+      add(A.coef, (uint64_t)A.coef_stride*2*(uint64_t)b->nimages, 0, 1);
+      break;
+    }
+    if (end > pg.coef_off + used) add(A.coef + pg.coef_off + used, (uint64_t)(end - pg.coef_off - used)*2, (uint64_t)A.coef_stride*2, (uint32_t)b->nimages);
+  }
+  // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
+  add(A.dc_diff, sizeof(int16_t)*(uint64_t)A.dc_stride*(uint64_t)b->nimages, 0, 1);
+  add(A.dc_val, sizeof(int16_t)*(uint64_t)A.dc_stride*(uint64_t)b->nimages, 0, 1);
+  if (hj_launch_clear(&C, st)) return jga_fail("huff: launch failed");
+  return EXIT_SUCCESS;
+}
+// The tail of a decode: prefix sums, write pass, DC values, the images' verdicts.
+static int queue_tail(jga_huff_batch *b, const hj_args &A, bool split, hipStream_t st) {
+  if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+  if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+  // DC differences -> DC values; into the planes too unless the caller takes the array itself
+  if (hj_launch_dc(&A, (int)b->total_seg, (int)b->max_seg_mcus, b->d_dcpart, split ? 0 : (int)(b->geom.coef_shorts/64), st)) {
+    return jga_fail("huff: launch failed");
+  }
+  HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
+  return EXIT_SUCCESS;
+}
+static int queue_rounds(jga_huff_batch *b, const decode_plan &P, int &round, int count, hipStream_t st) {
+  for (int k = 0; k < count && round < HJ_MAX_ROUNDS; k++, round++) {
+    if (hj_launch_round(&P.A, (int)b->max_nsub, round, round ? P.it1 : P.it0, round >= P.sparse_from ? 1 : P.lean ? -1 : 0, st)) {
       return jga_fail("huff: launch failed");
     }
-    HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
-    return EXIT_SUCCESS;
-  };
+  }
+  HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
+  return EXIT_SUCCESS;
+}
+
+static int decode_begin(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
+ hipStream_t st) {
+  b->pend.active = false;
+  // verdicts of an earlier decode must not outlive it: a launch failure below would otherwise
+  // be read as "some members were damaged" by callers that look at jga_huff_image_errors()
+  b->image_errors = 0;
+  for (int i = 0; i < b->max_images; i++) b->h_ran[HJ_MAX_ROUNDS + i] = 0;
+  if (!b->nimages) return jga_fail("huff: nothing prepared");
+  if (coef_stride < b->geom.coef_shorts) return jga_fail("huff: coef_stride too small");
+  if (d_dc && dc_stride < b->geom.coef_shorts/64) return jga_fail("huff: dc_stride too small");
+  decode_plan P;
+  if (make_plan(b, d_coef, coef_stride, d_dc, dc_stride, P) != EXIT_SUCCESS) return EXIT_FAILURE;
+  // reset: states back to the guesses, "never ran"
+  // (on-device unstuffing has already had its say about every image: early end, RSTn counters)
+  if (hj_launch_init(&P.A, (int)b->total_seg, (int)b->max_nsub,
+   b->unstuffed_on_device ? (const uint32_t *)(b->d_blob + b->off_perr) : NULL, st)) {
+    return jga_fail("huff: launch failed");
+  }
+  b->last_assisted = 0;
   // A photograph settles in 4-6 rounds, so the tail is queued SPECULATIVELY behind the first
   // group of rounds: one host round trip per decode instead of two (a lone 1080p frame: ~60 us of
   // its ~700).  If the last of those rounds still moved something, the tail ran on unsettled
   // states — bounded like a corrupt stream's, but wrong: outputs and verdicts are reset, the
   // rounds go on, the tail runs again, and the next decode of this batch object queues more
   // rounds first (JGA_HUFF_SPECULATE=0: never).
-  bool speculated = b->speculate >= 0 && !b->assist_hint, tail_done = false;
-  if (b->spec_rounds < GROUP) b->spec_rounds = GROUP;
+  if (b->spec_rounds < P.group) b->spec_rounds = P.group;
+  int round = 0;
+  if (queue_rounds(b, P, round, P.speculate ? b->spec_rounds : P.group, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+  // (the clears are queued behind the first burst of rounds — their launch would otherwise stand between a lone
+  // frame's upload and its first round — and in front of the tail that needs them)
+  if (queue_clear(b, P.A, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+  if (P.speculate && queue_tail(b, P.A, d_dc != NULL, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+  b->pend.active = true;
+  b->pend.with_tail = P.speculate;
+  b->pend.d_coef = d_coef; b->pend.coef_stride = coef_stride;
+  b->pend.d_dc = d_dc; b->pend.dc_stride = dc_stride;
+  b->pend.st = st;
+  b->pend.round = round;
+  return EXIT_SUCCESS;
+}
+
+static int decode_end(jga_huff_batch *b, int *valid_behind) {
+  if (valid_behind) *valid_behind = 0;
+  if (!b->pend.active) return jga_fail("huff: no decode in flight");
+  b->pend.active = false;
+  hipStream_t st = b->pend.st;
+  short *d_dc = b->pend.d_dc;
+  const bool trace = b->trace != 0;
+  double c0 = trace ? thread_cpu_ms() : 0.0, c_launch = 0.0, c_wait = 0.0;
+  auto lap = [&](double &acc) { if (trace) { const double c = thread_cpu_ms(); acc += c - c0; c0 = c; } };
+  decode_plan P;
+  if (make_plan(b, b->pend.d_coef, b->pend.coef_stride, d_dc, b->pend.dc_stride, P) != EXIT_SUCCESS) return EXIT_FAILURE;
+  int round = b->pend.round;
+  bool with_tail = b->pend.with_tail, tail_done = false, first = true;
   for (;;) {
-    const bool first_burst = round == first_round;
-    const int burst = (speculated && first_burst ? b->spec_rounds : GROUP) - (first_burst ? first_round : 0);
-    for (int k = 0; k < burst && round < HJ_MAX_ROUNDS; k++, round++) {
-      if (hj_launch_round(&A, (int)b->max_nsub, round, round ? it1 : it0, round >= sparse_from ? 1 : K.lean ? -1 : 0, st)) {
-        return jga_fail("huff: launch failed");
-      }
-    }
-    if (queue_side() != EXIT_SUCCESS) return EXIT_FAILURE;
-    const bool with_tail = speculated && first_burst;
-    HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
-    if (with_tail && queue_tail() != EXIT_SUCCESS) return EXIT_FAILURE;
-    lap(c_launch);
     HOK(wait_stream(b, st));
     lap(c_wait);
     if (b->h_ran[round - 1] == 0) { tail_done = with_tail; break; }   // a round in which nothing moved
@@ -1363,40 +971,93 @@ static int decode_batch(jga_huff_batch *b, short *d_coef, long long coef_stride,
       }
       else HOK(hipMemsetAsync(b->d_errors, 0, 4*(size_t)b->nimages, st));
       // (the planes: every line the final write pass touches is rewritten or zeroed first)
-      HOK(hipMemsetAsync(A.dc_diff, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, st));
-      HOK(hipMemsetAsync(A.dc_val, 0, sizeof(int16_t)*(size_t)A.dc_stride*(size_t)b->nimages, st));
+      HOK(hipMemsetAsync(P.A.dc_diff, 0, sizeof(int16_t)*(size_t)P.A.dc_stride*(size_t)b->nimages, st));
+      HOK(hipMemsetAsync(P.A.dc_val, 0, sizeof(int16_t)*(size_t)P.A.dc_stride*(size_t)b->nimages, st));
     }
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
     // (a batch object whose previous decode needed the walk — the same camera, the same
     // letterbox — gets it at the first check instead of waiting out twelve rounds)
-    if (round >= (b->assist_hint ? 1 : assist_after) && assist_chains(b, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (round >= (b->assist_hint ? 1 : P.assist_after) && assist_chains(b, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+    with_tail = false;
+    first = false;
+    if (queue_rounds(b, P, round, P.group, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+    lap(c_launch);
   }
   b->last_rounds = 0;
   while (b->last_rounds < round && b->h_ran[b->last_rounds]) b->last_rounds++;
   b->assist_hint = b->last_assisted > 0;
-  if (tail_done && b->last_rounds + 2 < b->spec_rounds && b->spec_rounds > GROUP) b->spec_rounds--;   // (drifts back)
+  if (tail_done && b->last_rounds + 2 < b->spec_rounds && b->spec_rounds > P.group) b->spec_rounds--;   // (drifts back)
   if (!tail_done) {
-    if (queue_tail() != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (queue_tail(b, P.A, d_dc != NULL, st) != EXIT_SUCCESS) return EXIT_FAILURE;
     lap(c_launch);
     HOK(wait_stream(b, st));
     lap(c_wait);
   }
-  if (trace) fprintf(stderr, "  huff decode: this thread's CPU in launches + copies %.2f ms, in waits %.2f ms\n", c_launch, c_wait);
+  // what the caller queued behind decode_begin() ran behind the FINAL tail only if the speculation held at the
+  // first look
+  if (valid_behind) *valid_behind = tail_done && first;
+  if (trace) fprintf(stderr, "  huff decode (second half): this thread's CPU in launches + copies %.2f ms, in waits %.2f ms\n", c_launch, c_wait);
   // per-image verdicts stay readable (jga_huff_image_error): the other images of the batch
   // are decoded correctly whatever one damaged member did
   b->image_errors = 0;
-  int first = -1;
+  int bad = -1;
   for (int i = 0; i < b->nimages; i++) {
     if (b->h_ran[HJ_MAX_ROUNDS + i]) {
-      if (first < 0) first = i;
+      if (bad < 0) bad = i;
       b->image_errors++;
     }
   }
-  if (first >= 0) {
-    return jga_fail("huff: image %d: %s", first, (b->h_ran[HJ_MAX_ROUNDS + first] & 2)
+  if (bad >= 0) {
+    return jga_fail("huff: image %d: %s", bad, (b->h_ran[HJ_MAX_ROUNDS + bad] & 2)
      ? "Error indexing outside block." : "Error, entropy data ended early.");
   }
   return EXIT_SUCCESS;
+}
+
+// A launch or copy failed part-way: whatever was queued may still be running — the caller is free to reuse or
+// release d_coef the moment the call returns, so wait it out first.
+static int drained(jga_huff_batch *b, hipStream_t st, int rc) {
+  if (rc != EXIT_SUCCESS && !b->image_errors) (void)hipStreamSynchronize(st);
+  return rc;
+}
+
+static int decode_checked(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride,
+ void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = decode_begin(b, d_coef, coef_stride, d_dc, dc_stride, st);
+  if (rc == EXIT_SUCCESS) rc = decode_end(b, NULL);
+  return drained(b, st, rc);
+}
+
+// Finished QUANT-stage planes (DC prediction applied), as jga_entropy_decode() makes them on the host.
+JGA_EXPORT int jga_huff_decode(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ void *stream) {
+  return decode_checked(b, d_coef, coef_stride, NULL, 0, stream);
+}
+
+// The same decode for a caller that runs a block-decode kernel next (jga_idct_*_batch_dc): the
+// planes' DC positions are left holding the DC DIFFERENCES, the DC values come in d_dc — image i
+// at d_dc + i*dc_stride, one int16 per 128-byte slot of the image's coefficient buffer
+// (dc_stride >= coef_shorts/64) — and the strided 2-byte pass over the planes that would put them
+// in place is saved.
+JGA_EXPORT int jga_huff_decode_split(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ short *d_dc, long long dc_stride, void *stream) {
+  if (!d_dc) return jga_fail("huff: jga_huff_decode_split needs a DC array");
+  return decode_checked(b, d_coef, coef_stride, d_dc, dc_stride, stream);
+}
+// ... in two halves: _begin queues the decode on `stream` and returns without waiting; the caller queues what
+// consumes the planes (the block-decode kernel, copies of its output) on the same stream; _end waits for the
+// stream, finishes the decode if the first burst of rounds had not settled it, and says in *valid_behind whether
+// the work queued in between saw the final planes and DC values (1) or has to be queued again (0).  Verdicts
+// (jga_huff_image_errors / _error) are those of jga_huff_decode_split.
+JGA_EXPORT int jga_huff_decode_split_begin(jga_huff_batch *b, short *d_coef, long long coef_stride,
+ short *d_dc, long long dc_stride, void *stream) {
+  if (!d_dc) return jga_fail("huff: jga_huff_decode_split needs a DC array");
+  return drained(b, (hipStream_t)stream, decode_begin(b, d_coef, coef_stride, d_dc, dc_stride, (hipStream_t)stream));
+}
+JGA_EXPORT int jga_huff_decode_split_end(jga_huff_batch *b, int *valid_behind) {
+  hipStream_t st = b->pend.st;
+  return drained(b, st, decode_end(b, valid_behind));
 }
 
 JGA_EXPORT int jga_huff_image_errors(const jga_huff_batch *b) { return b->image_errors; }

@@ -1034,16 +1034,12 @@ __global__ __launch_bounds__(256) void hj_dc_apply(const hj_args A, int slots_pe
 // uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
 // (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
 // their first byte.  A workgroup takes 4096 subsequences of one segment.
-// `seg_base`: the launch covers the segments of a PIECE of the batch (A.images / A.nimages are the piece's
-// images; a batch whose upload arrives in pieces starts each piece's first round as it lands) — the
-// bookkeeping words are then none of its business (`book` = 0: the caller has cleared them).
-__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg, const uint32_t *verdicts0,
- uint32_t seg_base, int book) {
-  const uint32_t gs = blockIdx.x + seg_base;
+__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg, const uint32_t *verdicts0) {
+  const uint32_t gs = blockIdx.x;
   // (also the decode's bookkeeping words, instead of two memsets in front of it: "did anything
   // run in round r", and every image's verdict — what the on-device scan clean-up already
   // found, or nothing)
-  if (book && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
     for (int i = threadIdx.x; i < HJ_MAX_ROUNDS; i += 256) A.ran[i] = 0;
     for (int i = threadIdx.x; i < A.nimages; i += 256) A.errors[i] = verdicts0 ? verdicts0[i] : 0u;
   }
@@ -1068,14 +1064,36 @@ __global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t 
   }
   if (k1 == sg.nsub && threadIdx.x == 0) S[sg.nsub] = 0;
 }
-extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream) {
-  hipLaunchKernelGGL(hj_init_states, dim3(total_segs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
-   const_cast<uint32_t *>(A->sub_seg), verdicts0, 0u, 1);
+// What the write pass and the DC pass need cleared before they run — the two DC arrays (blocks a damaged stream never
+// reaches, slots that hold no block) and the slots at the end of a decimated plane that hold no block — in ONE
+// launch on the decode's own stream.  (Rounds 2-4 queued these as three or four memsets on a side stream, for free
+// beside the LDS-bound first round; with eight lanes' side streams sharing four hardware queues with their main
+// streams "beside" was rarely what happened, and the events around them cost every decode three more calls.)
+__global__ __launch_bounds__(256) void hj_clear(const hj_clear_args C) {
+  const hj_clear_region r = C.region[blockIdx.y];
+  const uint64_t per_row = r.row_bytes >> 4, total = per_row*r.rows;
+  typedef __attribute__((address_space(1))) hj_v4u global_v4u;
+  const hj_v4u zero = {0u, 0u, 0u, 0u};
+  for (uint64_t u = (uint64_t)blockIdx.x*256u + threadIdx.x; u < total; u += (uint64_t)gridDim.x*256u) {
+    const uint64_t row = per_row == total ? 0 : u/per_row, col = u - row*per_row;
+    *(global_v4u *)((uintptr_t)r.base + row*r.stride + (col << 4)) = zero;
+  }
+}
+extern "C" int hj_launch_clear(const hj_clear_args *C, void *stream) {
+  if (C->nregions < 1) return 0;
+  uint64_t most = 1;
+  for (int k = 0; k < C->nregions; k++) {
+    const uint64_t units = (C->region[k].row_bytes >> 4)*C->region[k].rows;
+    if (units > most) most = units;
+  }
+  const uint64_t want = (most + 1023)/1024;                     // four units per lane
+  hipLaunchKernelGGL(hj_clear, dim3((unsigned)(want < 4096 ? want : 4096), C->nregions), dim3(256), 0, (hipStream_t)stream, *C);
   return (int)hipGetLastError();
 }
-extern "C" int hj_launch_init_piece(const hj_args *A, int seg_base, int nsegs, int max_nsub, void *stream) {
-  hipLaunchKernelGGL(hj_init_states, dim3(nsegs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
-   const_cast<uint32_t *>(A->sub_seg), (const uint32_t *)nullptr, (uint32_t)seg_base, 0);
+
+extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream) {
+  hipLaunchKernelGGL(hj_init_states, dim3(total_segs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
+   const_cast<uint32_t *>(A->sub_seg), verdicts0);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,

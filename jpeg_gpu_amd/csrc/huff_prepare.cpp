@@ -4,6 +4,8 @@
 // 593-629): tables are built once on the host, the scan itself is decoded on the GPU.
 #include <stdlib.h>
 #include <string.h>
+#include <new>
+#include <memory>
 #include "huff_prepare.h"
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -131,7 +133,28 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
   }
   int slot = 0, l2_used = 0;
   int nslot[2] = {0, 0}, slot_id[2][2] = {{-1, -1}, {-1, -1}};       // [DC / AC]: DHT ids in the two table slots
-  memset(&out->tabs, 0, sizeof(out->tabs));
+  // A stream of files from one encoder brings the same DHT segments file after file (every file of the bench, of a
+  // camera, of a transcoding farm): the lookup tables of the file before — 10 KB that took ~20 us to build — are
+  // kept per thread and taken over when the tables this frame SELECTS are byte for byte the ones they were built
+  // from.  What a frame selects, in component order: (DC id, AC id, 16 counts + 256 values of each).
+  struct table_memo {
+    bool valid = false;
+    int nplanes = 0;
+    unsigned char sel[3][2];
+    unsigned char bits[3][2][16], vals[3][2][256];
+    hj_tables tabs;
+    uint8_t comp_tbl[3];
+  };
+  static thread_local std::unique_ptr<table_memo> memo;     // (freed when the thread ends)
+  bool memo_hit = memo && memo->valid && memo->nplanes == g.nplanes;
+  for (int c = 0; c < g.nplanes && memo_hit; c++) {
+    for (int w = 0; w < 2 && memo_hit; w++) {
+      const int id = w ? 4 + d->ta[c] : d->td[c];
+      memo_hit = memcmp(memo->bits[c][w], d->dht_bits[id], 16) == 0 && memcmp(memo->vals[c][w], d->dht_vals[id], 256) == 0;
+    }
+  }
+  if (memo_hit) memcpy(&out->tabs, &memo->tabs, sizeof(out->tabs));
+  else memset(&out->tabs, 0, sizeof(out->tabs));
   for (int c = 0; c < g.nplanes; c++) {
     const jpeg_component &cp = d->header.comp[c];
     im.comp_hs[c] = (uint8_t)cp.hsamp;
@@ -152,7 +175,8 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
         slot++;
       }
     }
-    {
+    if (memo_hit) im.comp_tbl[c] = memo->comp_tbl[c];
+    else {
       // the device format holds two DC and two AC tables (luma / chroma): components that
       // select the same DHT share a slot
       int rc = 0;
@@ -188,6 +212,22 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
     memcpy(out->qtab + 64*c, cp.quant->tbl, 64*sizeof(unsigned short));
   }
   for (int c = g.nplanes; c < 3; c++) memset(out->qtab + 64*c, 0, 64*sizeof(unsigned short));
+  if (!memo_hit) {
+    if (!memo) memo.reset(new (std::nothrow) table_memo());    // (one per thread that prepares)
+    if (memo) {
+      memo->valid = true;
+      memo->nplanes = g.nplanes;
+      for (int c = 0; c < g.nplanes; c++) {
+        for (int w = 0; w < 2; w++) {
+          const int id = w ? 4 + d->ta[c] : d->td[c];
+          memcpy(memo->bits[c][w], d->dht_bits[id], 16);
+          memcpy(memo->vals[c][w], d->dht_vals[id], 256);
+        }
+        memo->comp_tbl[c] = im.comp_tbl[c];
+      }
+      memcpy(&memo->tabs, &out->tabs, sizeof(out->tabs));
+    }
+  }
   im.nslots = slot;
   im.nhmb = g.nhmb;
   im.w0_blocks = g.w0/8;

@@ -39,23 +39,24 @@ namespace {
 // tuning build, the JGA_PIPE_* variables of rounds 2-3 have had their say): one helper for
 // jga_pipeline_create and jga_pipeline_plan_cfg, so that a plan is the plan a run makes.
 struct sched_knobs {
-  int lanes, batch, link_slots, dev_slots, groups_per_lane, min_group_eq, offload_at, copy_streams, short_job;
+  int lanes, batch, link_slots, dev_slots, groups_per_lane, min_group_eq, offload_at, copy_streams;
   bool ramp_first, blocking, trace;
 };
 sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   sched_knobs k;
   k.lanes = c.depth > 0 ? c.depth : 6;
   k.batch = c.batch > 0 ? c.batch : 48;
-  k.link_slots = c.link_slots < 0 ? 0 : c.link_slots > 0 ? c.link_slots : 2;
-  k.dev_slots = c.device_slots > 0 ? c.device_slots : 3;
-  k.groups_per_lane = c.groups_per_lane > 0 ? c.groups_per_lane : 4;
-  k.min_group_eq = c.min_group > 0 ? c.min_group : 4;
-  k.ramp_first = c.ramp_first >= 0;
   k.blocking = c.spin_waits == 0;
-  k.offload_at = c.offload_at > 0 ? c.offload_at : 8;
-  k.copy_streams = c.copy_streams > 0 ? (c.copy_streams > 8 ? 8 : c.copy_streams) : 0;
   k.trace = c.trace != 0;
-  k.short_job = c.short_job == 2 ? 2 : 1;                       // (0 = auto: cut like any other job, for now)
+  // (not configuration since round 5 — every other value measured slower or the same, profiles/r4_host_side_steps.md
+  // — but still A/B-able in the tuning build)
+  k.link_slots = 2;
+  k.dev_slots = 3;
+  k.groups_per_lane = 4;
+  k.min_group_eq = 4;
+  k.ramp_first = true;
+  k.offload_at = 8;
+  k.copy_streams = 0;
   if (const char *e = jga_tune("JGA_PIPE_DEVICE_SLOTS")) k.dev_slots = atoi(e) > 0 ? atoi(e) : 1;
   if (const char *e = jga_tune("JGA_PIPE_SPIN")) k.blocking = atoi(e) == 0;
   if (const char *e = jga_tune("JGA_PIPE_COPY_STREAMS")) k.copy_streams = atoi(e) > 8 ? 8 : atoi(e) > 0 ? atoi(e) : 0;
@@ -70,13 +71,43 @@ sched_knobs resolve_knobs(const jga_pipeline_config &c) {
 }
 
 // Callers' pageable JPEG buffers kept registered with the device (jga_pipeline_config.input_cache_mb):
-// (address, size) -> registration, least recently used out first.  A lane ACQUIRES the buffers of its
-// group before it queues copies that read them and RELEASES them when its stream has drained; only
-// buffers nobody holds are evicted or forgotten.  hipHostRegister runs outside the lock (it takes
-// a few hundred microseconds; lanes register different buffers side by side) — a buffer in the middle of
-// being registered by one lane reads as "not registered" to the others, who copy it as before.
+// address -> registration, least recently used out first.  A lane ACQUIRES the buffers of its
+// group before it queues work that reads them and RELEASES them when its stream has drained; only
+// buffers nobody holds are evicted or forgotten.  hipHostRegister runs outside the lock (lanes register
+// different buffers side by side) — a buffer in the middle of being registered by one lane reads as "not
+// registered" to the others, who copy it as before.
+// A registration is made for a FILE, not for an address: the entry keeps a fingerprint of the buffer's contents
+// (size, first and last 64 bytes, sixteen 8-byte words spread over the rest) which the host re-reads at every sight.
+// The caller's buffer is plain malloc memory (reference src/jpeg_info.c:31-62: malloc, fread, free in
+// jpeg_info_clear): freed and handed out again at the same address for another file, it may be backed by other
+// pages than the ones the device has mapped — such a buffer fails the check, loses its registration and is
+// registered afresh (or copied, if somebody still holds the old one).
 struct input_cache {
-  struct entry { size_t bytes = 0; unsigned long long last = 0; int users = 0, sights = 0; bool registered = false, busy = false; };
+  struct fingerprint {
+    size_t bytes = 0;
+    unsigned long long head[8], tail[8], mid[16];
+    bool operator==(const fingerprint &o) const {
+      return bytes == o.bytes && !memcmp(head, o.head, sizeof(head)) && !memcmp(tail, o.tail, sizeof(tail))
+       && !memcmp(mid, o.mid, sizeof(mid));
+    }
+  };
+  static fingerprint print_of(const void *p, size_t bytes) {
+    fingerprint f;
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    f.bytes = bytes;
+    memcpy(f.head, c, 64);                               // (bytes >= MIN_BYTES)
+    memcpy(f.tail, c + bytes - 64, 64);
+    const size_t step = (bytes - 136)/16;
+    for (int k = 0; k < 16; k++) memcpy(&f.mid[k], c + 64 + (size_t)k*step, 8);
+    return f;
+  }
+  struct entry {
+    size_t bytes = 0;
+    unsigned long long last = 0;
+    int users = 0, sights = 0;
+    bool registered = false, busy = false, foreign = false;   // foreign: somebody else registered it (we never unregister it)
+    fingerprint print;
+  };
   std::mutex m;
   std::unordered_map<const void *, entry> map;
   size_t cap = 0, held = 0;
@@ -84,8 +115,12 @@ struct input_cache {
   int sight = 1;
   static constexpr size_t MIN_BYTES = 64u << 10;     // (below this a copy is cheaper than a registration can ever be)
   static constexpr size_t MAX_TRACKED = 4096;        // addresses whose sights are being counted
-  std::atomic<long long> n_registered{0}, n_evicted{0}, us_register{0}, n_in_place{0}, n_copied{0}, host_bytes{0};
+  std::atomic<long long> n_registered{0}, n_evicted{0}, us_register{0}, n_in_place{0}, n_copied{0}, host_bytes{0}, n_stale{0};
   bool enabled() const { return cap > 0; }
+  void drop(const void *p, entry &e) {               // (lock held, nobody uses it)
+    if (e.registered && !e.foreign) (void)hipHostUnregister(const_cast<void *>(p));
+    if (e.registered) held -= e.bytes;
+  }
   // make room for `bytes` by unregistering idle entries, oldest first (lock held)
   bool make_room(size_t bytes) {
     while (held + bytes > cap) {
@@ -97,26 +132,28 @@ struct input_cache {
         }
       }
       if (!victim) return false;
-      (void)hipHostUnregister(const_cast<void *>(victim));
-      held -= map[victim].bytes;
+      drop(victim, map[victim]);
       map.erase(victim);
       n_evicted++;
     }
     return true;
   }
-  // true: [p, p + bytes) is registered and now held by the caller (release() it).  `count_sight`: a run is
-  // looking at the buffer (explicit registration passes false and registers at once)
+  // true: [p, p + bytes) is registered — for THESE contents — and now held by the caller (release() it).
+  // `count_sight`: a run is looking at the buffer (explicit registration passes false and registers at once)
   bool acquire(const void *p, size_t bytes, bool count_sight = true) {
     if (!enabled() || !p || bytes < MIN_BYTES || bytes > cap) return false;
+    const fingerprint now = print_of(p, bytes);
     {
       std::lock_guard<std::mutex> lk(m);
       auto it = map.find(p);
       if (it != map.end() && it->second.busy) return false;
       if (it != map.end() && it->second.registered) {
-        if (bytes <= it->second.bytes) { it->second.users++; it->second.last = ++tick; return true; }
-        if (it->second.users > 0) return false;        // the same address, longer now, and still in use: copy
-        (void)hipHostUnregister(const_cast<void *>(p));
-        held -= it->second.bytes;
+        if (it->second.print == now) { it->second.users++; it->second.last = ++tick; return true; }
+        // the same address, another file (or another length): the registration is of no use — and may name pages
+        // the buffer no longer has
+        n_stale++;
+        if (it->second.users > 0) return false;        // still being read by a running group: copy
+        drop(p, it->second);
         map.erase(it);
         it = map.end();
       }
@@ -136,7 +173,20 @@ struct input_cache {
       held += bytes;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    const hipError_t rc = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
+    hipError_t rc = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
+    bool foreign = false;
+    if (rc == hipErrorHostMemoryAlreadyRegistered) {
+      // the caller (or another pipeline) registered exactly this range and did not say so: the device can address
+      // it as it is — if it really covers the whole file
+      (void)hipGetLastError();
+      void *dp = nullptr, *de = nullptr;
+      if (hipHostGetDevicePointer(&dp, const_cast<void *>(p), 0) == hipSuccess
+       && hipHostGetDevicePointer(&de, const_cast<unsigned char *>(static_cast<const unsigned char *>(p)) + bytes - 1, 0) == hipSuccess) {
+        rc = hipSuccess;
+        foreign = true;
+      }
+      else (void)hipGetLastError();
+    }
     us_register += (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     std::lock_guard<std::mutex> lk(m);
     entry &e = map[p];
@@ -148,6 +198,8 @@ struct input_cache {
       return false;
     }
     e.registered = true;
+    e.foreign = foreign;
+    e.print = now;
     e.users = 1;
     n_registered++;
     return true;
@@ -162,13 +214,13 @@ struct input_cache {
     auto it = map.find(p);
     if (it == map.end()) return EXIT_SUCCESS;
     if (it->second.users > 0 || it->second.busy) return EXIT_FAILURE;
-    if (it->second.registered) { (void)hipHostUnregister(const_cast<void *>(p)); held -= it->second.bytes; }
+    drop(p, it->second);
     map.erase(it);
     return EXIT_SUCCESS;
   }
   void clear() {
     std::lock_guard<std::mutex> lk(m);
-    for (auto &kv : map) if (kv.second.registered) (void)hipHostUnregister(const_cast<void *>(kv.first));
+    for (auto &kv : map) if (kv.second.registered && !kv.second.foreign) (void)hipHostUnregister(const_cast<void *>(kv.first));
     map.clear();
     held = 0;
   }
@@ -272,8 +324,6 @@ struct jga_pipeline {
   int run_done = 0;
   bool quit = false;
   std::vector<std::vector<jga_job *>> *run_groups = nullptr;
-  std::vector<int> *run_pieces = nullptr;         // per group: pieces of its upload (short_job = 2)
-  int short_job = 1;
   std::atomic<int> *run_next = nullptr;
   int run_threads = 1;
 };
@@ -491,11 +541,9 @@ struct link_turn {
   jga_pipeline *pl;
   int held = 0;
   explicit link_turn(jga_pipeline *p) : pl(p) {}
-  bool whole = false;                  // an upload in pieces (a short job's batch): the link to itself, so that the
-                                       // batches' uploads follow each other instead of sharing it
   static void take_hook(void *arg, long long bytes, int copies) {
     link_turn *t = static_cast<link_turn *>(arg);
-    t->take(t->whole || (copies == 1 && bytes >= (64ll << 20)) ? t->pl->link_slots : 1);
+    t->take(copies == 1 && bytes >= (64ll << 20) ? t->pl->link_slots : 1);
   }
   void take(int units) {
     if (pl->link_slots <= 0) return;
@@ -517,10 +565,14 @@ struct link_turn {
 // Decode jobs[0..m) as ONE batch of the GPU entropy stage.  Fails as a whole (mixed
 // geometry, an unparsable member, ...): GROUP_REJECTED when prepare() turned the group down
 // (its per-member verdicts then say who is to blame), EXIT_FAILURE for anything else.
+// `short_run`: the run gives every lane a group or two — what it waits for is the LAST group's chain of kernels
+// behind the last byte over the link, so the groups take the route with the fewest host steps: clean-up on the
+// device whatever the core count (no host pass over the bytes before the first upload can start), the files read
+// where they lie, one host wait per group.
 enum { GROUP_REJECTED = 2 };
 uint64_t geometry_key(const unsigned char *p, int size);
 int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int threads, bool shared = true,
- bool reserve_full = false, int pieces = 0) {
+ bool reserve_full = false, bool short_run = false) {
   const bool rgb = pl->cfg.out == JPEG_DECODE_RGB;
   const bool copy_back = pl->cfg.copy_back != 0;
   std::vector<const unsigned char *> ptrs((size_t)m);
@@ -548,10 +600,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     if (cap > full) full = (int)cap;
   }
   // (with the clean-up on the device the batch holds the raw scans AND the clean streams)
-  // (a short job's batches, uploaded in pieces, leave the clean-up to the device whatever the core count: what the
-  // run waits for is the host's pass over the bytes before the first piece can go — a copy, or nothing at all
-  // for files that are pinned or in the input cache, against an unstuffing pass four times as long)
-  const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && (pl->offload_cleanup || pieces > 1));
+  const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && (pl->offload_cleanup || short_run));
   const long long total_full = (total/m*full + total/4)*(on_device ? 2 : 1);
   if (on_device) total *= 2;
   if (!l.hb || m > l.hb_images || total > l.hb_scan) {
@@ -568,9 +617,6 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
       l.hb = jga_huff_create(l.hb_images, l.hb_scan);
     }
     if (!l.hb) { l.hb_images = 0; l.hb_scan = 0; return EXIT_FAILURE; }
-    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_SUB_BYTES, pl->cfg.huff_sub_bytes);
-    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_ASSIST_AFTER, pl->cfg.huff_assist_after);
-    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_SPECULATE, pl->cfg.huff_speculate);
     (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_TRACE, pl->trace);
   }
   const bool trace = pl->trace;
@@ -582,13 +628,24 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   const auto t_a = std::chrono::steady_clock::now();
   const double c_a = trace ? thread_cpu_ms() : 0.0;
   jga_huff_set_threads(l.hb, threads);
-  // Which files the DMA engine reads where they lie (clean-up on the device only): those the caller
-  // says are pinned, and ordinary buffers the input cache holds registered (or registers now).
+  // From the first queued copy or fetch on, the device may be reading the callers' JPEG buffers (pinned, cached and
+  // named inputs are read where they lie) or writing their pixel buffers (pinned destinations): no return may
+  // leave that in flight — the caller is free to release both the moment jga_pipeline_run() is back — and no
+  // buffer of the input cache may be let go (and evicted: unregistered) before the streams have drained.  Declared
+  // in this order so that the drain runs first.
   struct held_inputs {
     input_cache &c;
     std::vector<const void *> v;
     ~held_inputs() { for (const void *p : v) c.release(p); }
   } held{pl->inputs, {}};
+  struct drain_on_failure {
+    hipStream_t st;
+    bool armed = true;
+    ~drain_on_failure() { if (armed) (void)hipStreamSynchronize(st); }
+  } guard{l.stream};
+  // How each file reaches the device (clean-up on the device only; jga_huff_set_input_flags): read where it lies by
+  // a copy call that names it — the caller says it is pinned, or the input cache holds it registered (or registers it
+  // now), or, with no cache, ordinary memory the runtime pins per copy — or copied into the pinned blob by this thread.
   std::vector<unsigned char> in_place((size_t)m, 0);
   {
     for (int i = 0; i < m && on_device; i++) {
@@ -597,14 +654,11 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
         in_place[(size_t)i] = 1;
         held.v.push_back(jobv[i]->jpeg);
       }
-      // Ordinary memory the cache does not hold (no cache, too small, no room, first of two sights): the copy
-      // names it all the same and the runtime pins what it touches — no host core passes over the bytes.
-      // [MI355X] the headline on the 2 CPUs a rank of 8 gets: 131 Gpixel/s this way, 145 through the cache,
-      // 86 with a host copy of every file into the pinned blob (rounds 2-3; input_cache_mb < 0 keeps it).
-      else if (pl->cfg.input_cache_mb >= 0) in_place[(size_t)i] = 1;
+      // [MI355X] the headline on the 2 CPUs a rank of 8 gets: 131 Gpixel/s with named copies, 145 through the
+      // cache, 86 with a host copy of every file into the pinned blob (rounds 2-3)
+      else if (pl->cfg.input_cache_mb == -1) in_place[(size_t)i] = 1;
     }
     jga_huff_set_device_unstuff(l.hb, on_device);
-    (void)jga_huff_set_option(l.hb, JGA_HUFF_OPT_PIECES, pieces);
     jga_huff_set_inputs_pinned(l.hb, 0);
     jga_huff_set_input_flags(l.hb, in_place.data(), m);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
@@ -614,10 +668,9 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   }
   // A lone image whose Huffman tables do not fit the device lookup format takes the host
   // entropy stage (csrc/entropy.c) instead; everything after it is the same.
-  bool host_entropy = false, damaged = false;
+  bool host_entropy = false;
   jpeg_header hdr;
   link_turn link(pl);
-  link.whole = pieces > 1;
   jga_huff_set_upload_gate(l.hb, pl->link_slots > 0 ? &link_turn::take_hook : nullptr, &link);
   const int prc = jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream);
   jga_huff_set_upload_gate(l.hb, nullptr, nullptr);
@@ -634,15 +687,6 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     }
     host_entropy = true;
   }
-  // From here on the lane's stream may hold copies that read the callers' JPEG buffers (pinned
-  // inputs are DMA'd where they lie) or write their pixel buffers (pinned destinations): no
-  // return may leave them in flight — the caller is free to release both the moment
-  // jga_pipeline_run() is back.
-  struct drain_on_failure {
-    hipStream_t st;
-    bool armed = true;
-    ~drain_on_failure() { if (armed) (void)hipStreamSynchronize(st); }
-  } guard{l.stream};
   const long long cstride = (g.coef_shorts + 127) & ~127ll;
   const long long out_bytes = rgb ? g.rgb_bytes : g.yuv_bytes;
   const long long ostride = (out_bytes + 255) & ~255ll;
@@ -674,6 +718,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   turn.take((int)(((long long)m*g.width*g.height + 3840ll*2160 - 1)/(3840ll*2160)));   // (the group's upload is already in flight)
   const auto t_b = std::chrono::steady_clock::now();
   const double c_b = trace ? thread_cpu_ms() : 0.0;
+  const unsigned short *d_q = l.d_q;                         // quantisers: they came up with prepare()'s descriptors
   if (host_entropy) {
     unsigned short q[192];
     memset(q, 0, sizeof(q));
@@ -685,33 +730,63 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     if (!HOK(hipMemcpyAsync(l.d_coef, l.h_coef, (size_t)g.coef_shorts*2, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
   }
   else {
-    if (!HOK(hipMemcpyAsync(l.d_q, jga_huff_qtabs(l.hb), 384*(size_t)m, hipMemcpyHostToDevice, l.stream))) return EXIT_FAILURE;
-    // damaged data in some members does not spoil the others' planes: go on, and report the
-    // damaged ones alone (anything else — a launch failure — fails the group)
+    d_q = jga_huff_qtabs_device(l.hb);
+    if (!d_q) return EXIT_FAILURE;
     // (DC values in their own array: the block-decode kernel takes them from there)
-    if (jga_huff_decode_split(l.hb, l.d_coef, cstride, l.d_dc, dcstride, l.stream) != EXIT_SUCCESS) {
-      if (jga_huff_image_errors(l.hb) <= 0) return EXIT_FAILURE;
-      damaged = true;
-    }
+    if (jga_huff_decode_split_begin(l.hb, l.d_coef, cstride, l.d_dc, dcstride, l.stream) != EXIT_SUCCESS) return EXIT_FAILURE;
   }
   const auto t_c = std::chrono::steady_clock::now();
   const double c_c = trace ? thread_cpu_ms() : 0.0;
   const short *dcv = host_entropy ? nullptr : l.d_dc;       // (the host entropy stage makes finished planes)
-  if (!scattered || strided) {
-    unsigned char *base = strided ? jobv[0]->dev_out : l.d_out;
-    const long long step = strided ? pitch : ostride;
-    if ((rgb ? jga_idct_rgb_batch_dc(&g, m, l.d_coef, cstride, dcv, dcstride, l.d_q, 1, base, step, l.stream)
-     : jga_idct_yuv_batch_dc(&g, m, l.d_coef, cstride, dcv, dcstride, l.d_q, 1, base, step, l.stream)) != EXIT_SUCCESS) {
-      return EXIT_FAILURE;
+  // Everything behind the entropy decode: block decode into the pixels' place, copies back.  Queued right behind
+  // the decode's first half — the lane waits ONCE per group — and again if the decode's second half says that
+  // what was queued in between did not see the final planes (streams that need more rounds than were queued).
+  auto queue_behind = [&]() -> bool {
+    if (!scattered || strided) {
+      unsigned char *base = strided ? jobv[0]->dev_out : l.d_out;
+      const long long step = strided ? pitch : ostride;
+      if ((rgb ? jga_idct_rgb_batch_dc(&g, m, l.d_coef, cstride, dcv, dcstride, d_q, 1, base, step, l.stream)
+       : jga_idct_yuv_batch_dc(&g, m, l.d_coef, cstride, dcv, dcstride, d_q, 1, base, step, l.stream)) != EXIT_SUCCESS) {
+        return false;
+      }
     }
+    else {
+      for (int i = 0; i < m; i++) {
+        unsigned char *dst = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
+        if ((rgb ? jga_idct_rgb_batch_dc(&g, 1, l.d_coef + cstride*i, cstride, dcv ? dcv + dcstride*i : nullptr, dcstride, d_q + 192*i, 1, dst, ostride, l.stream)
+         : jga_idct_yuv_batch_dc(&g, 1, l.d_coef + cstride*i, cstride, dcv ? dcv + dcstride*i : nullptr, dcstride, d_q + 192*i, 1, dst, ostride, l.stream)) != EXIT_SUCCESS) {
+          return false;
+        }
+      }
+    }
+    return true;
+  };
+  auto queue_copies_back = [&](bool only_damaged) -> bool {
+    for (int i = 0; i < m && copy_back; i++) {
+      if (!jobv[i]->host_out) continue;
+      if (only_damaged && jga_huff_image_error(l.hb, i) == 0) continue;
+      const unsigned char *src = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
+      unsigned char *to = (jobv[i]->pinned & 2) ? jobv[i]->host_out : l.h_out + ostride*i;   // pinned destination: no staging
+      if (!HOK(hipMemcpyAsync(to, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return false;
+    }
+    return true;
+  };
+  auto wait_lane = [&]() { return HOK(pl->blocking ? jga_stream_wait_sleeping(l.stream, l.done) : hipStreamSynchronize(l.stream)); };
+  if (!queue_behind() || !queue_copies_back(false)) return EXIT_FAILURE;
+  bool damaged = false;
+  if (host_entropy) {
+    if (!wait_lane()) return EXIT_FAILURE;
   }
   else {
-    for (int i = 0; i < m; i++) {
-      unsigned char *dst = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
-      if ((rgb ? jga_idct_rgb_batch_dc(&g, 1, l.d_coef + cstride*i, cstride, dcv ? dcv + dcstride*i : nullptr, dcstride, l.d_q + 192*i, 1, dst, ostride, l.stream)
-       : jga_idct_yuv_batch_dc(&g, 1, l.d_coef + cstride*i, cstride, dcv ? dcv + dcstride*i : nullptr, dcstride, l.d_q + 192*i, 1, dst, ostride, l.stream)) != EXIT_SUCCESS) {
-        return EXIT_FAILURE;
-      }
+    // damaged data in some members does not spoil the others' planes: go on, and report the
+    // damaged ones alone (anything else — a launch failure — fails the group)
+    int valid_behind = 0;
+    if (jga_huff_decode_split_end(l.hb, &valid_behind) != EXIT_SUCCESS) {
+      if (jga_huff_image_errors(l.hb) <= 0) return EXIT_FAILURE;
+      damaged = true;
+    }
+    if (!valid_behind) {
+      if (!queue_behind() || !queue_copies_back(false) || !wait_lane()) return EXIT_FAILURE;
     }
   }
   if (damaged) {
@@ -722,19 +797,9 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
       unsigned char *dst = jobv[i]->dev_out ? jobv[i]->dev_out : strided ? jobv[0]->dev_out + pitch*i : l.d_out + ostride*i;
       if (!HOK(hipMemsetAsync(dst, 0, (size_t)out_bytes, l.stream))) return EXIT_FAILURE;
     }
+    if (!queue_copies_back(true) || !wait_lane()) return EXIT_FAILURE;
   }
-  if (copy_back) {
-    for (int i = 0; i < m; i++) {
-      if (!jobv[i]->host_out) continue;
-      const unsigned char *src = jobv[i]->dev_out ? jobv[i]->dev_out : l.d_out + ostride*i;
-      unsigned char *to = (jobv[i]->pinned & 2) ? jobv[i]->host_out : l.h_out + ostride*i;   // pinned destination: no staging
-      if (!HOK(hipMemcpyAsync(to, src, (size_t)out_bytes, hipMemcpyDeviceToHost, l.stream))) return EXIT_FAILURE;
-    }
-  }
-  if (!HOK(pl->blocking ? jga_stream_wait_sleeping(l.stream, l.done) : hipStreamSynchronize(l.stream))) {
-    return EXIT_FAILURE;
-  }
-  guard.armed = false;                 // the stream is empty
+  guard.armed = false;                 // the streams hold nothing of this group any more
   turn.give();
   if (trace) {
     const auto t_d = std::chrono::steady_clock::now();
@@ -742,7 +807,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
       return std::chrono::duration<double, std::milli>(b - a).count(); };
     const double c_d = thread_cpu_ms();
     fprintf(stderr, "lane group of %d: began at %.2f ms; prepare + wait for a device slot %.2f ms (%.2f of this thread's CPU), "
-     "entropy decode %.2f ms (%.2f), idct+out+sync %.2f ms (%.2f); done at %.2f ms\n",
+     "entropy decode queued %.2f ms (%.2f), block decode queued + the group's one wait %.2f ms (%.2f); done at %.2f ms\n",
      m, ms(pl->run_t0, t_a), ms(t_a, t_b), c_b - c_a, ms(t_b, t_c), c_c - c_b, ms(t_c, t_d), c_d - c_c, pl->since_run_start_ms());
   }
   const long long up = host_entropy ? g.coef_shorts*2 : jga_huff_upload_bytes(l.hb)/m;
@@ -804,15 +869,8 @@ uint64_t geometry_key(const unsigned char *p, int size) {
 // files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
 // entropy stage and block decode of different groups overlap: about groups_per_lane groups
 // per lane, none below min_group_eq frame equivalents.
-// short_job = 2 (jga_pipeline_config; an experiment, measured slower: DESIGN.md §6): a geometry whose jobs would
-// all fit ONE full group is not cut into small groups — eight 16-file decodes keep the device busy 3.2 ms where
-// one 128-file batch takes 1.8, each paying the launches' latencies anew — but kept as one batch whose upload
-// arrives in pieces of ~12 MB: a piece's scan clean-up, start states and first synchronisation rounds start when
-// ITS bytes are there (jga_huff_set_option JGA_HUFF_OPT_PIECES).  `pieces[k]` = pieces of group k's upload
-// (0: one upload).
-struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; int short_job; };
-void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups,
- std::vector<int> *pieces = nullptr) {
+struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; };
+void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups) {
   const int nl = pp.lanes, batch = pp.batch;
   std::unordered_map<uint64_t, long long> pixels;            // geometry -> pixels of all its jobs
   std::vector<uint64_t> keys((size_t)n);
@@ -851,23 +909,7 @@ void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<
       cap = (cap*(made + 1) + nl - 1)/nl;
       if (cap < 1) cap = 1;
     }
-    const bool short_mode = pp.short_job == 2 && px > 0 && pixels[key] <= (long long)batch*frame;
-    if (short_mode) {
-      const long long count = pixels[key]/px;
-      cap = count;                                  // ONE batch (its upload in pieces)
-    }
     if ((long long)groups[it->second].size() >= cap) { open.erase(it); made++; }
-  }
-  if (pieces) {
-    pieces->assign(groups.size(), 0);
-    for (size_t k = 0; k < groups.size(); k++) {
-      const uint64_t key = groups[k].empty() ? 0 : keys[(size_t)groups[k][0]];
-      if (pp.short_job != 2 || !key || pixels[key] > (long long)batch*frame) continue;
-      long long bytes = 0;
-      for (int i : groups[k]) bytes += jobs[i].size;
-      const long long p = (bytes + (6ll << 20))/(12ll << 20);
-      (*pieces)[k] = (int)(p < 2 ? (bytes >= (8ll << 20) ? 2 : 0) : p > 8 ? 8 : p);
-    }
   }
 }
 
@@ -879,8 +921,7 @@ void lane_groups(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>>
     if (gi >= (int)groups->size()) break;
     std::vector<jga_job *> &grp = (*groups)[gi];
     const int m = (int)grp.size();
-    const int rc = lane_group(pl, *l, grp.data(), m, threads, groups->size() > 1, long_run,
-     pl->run_pieces && (size_t)gi < pl->run_pieces->size() ? (*pl->run_pieces)[(size_t)gi] : 0);
+    const int rc = lane_group(pl, *l, grp.data(), m, threads, groups->size() > 1, long_run, !long_run);
     if (rc == EXIT_SUCCESS || m == 1) continue;
     // One member with an unparsable header, or with Huffman tables outside the device lookup
     // format, must not cost the other 47 their batch: the members prepare() found usable go
@@ -891,11 +932,11 @@ void lane_groups(jga_pipeline *pl, hlane *l, std::vector<std::vector<jga_job *>>
       (rc == GROUP_REJECTED && jga_huff_prepare_verdict(l->hb, i) == 0 ? good : rest).push_back(grp[i]);
     }
     if (!rest.empty() && good.size() > 1
-     && lane_group(pl, *l, good.data(), (int)good.size(), threads) == EXIT_SUCCESS) {
+     && lane_group(pl, *l, good.data(), (int)good.size(), threads, true, false, !long_run) == EXIT_SUCCESS) {
       good.clear();
     }
-    for (jga_job *j : good) (void)lane_group(pl, *l, &j, 1, 1);
-    for (jga_job *j : rest) (void)lane_group(pl, *l, &j, 1, 1);
+    for (jga_job *j : good) (void)lane_group(pl, *l, &j, 1, 1, true, false, !long_run);
+    for (jga_job *j : rest) (void)lane_group(pl, *l, &j, 1, 1, true, false, !long_run);
   }
 }
 
@@ -979,9 +1020,8 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->min_group_eq = K.min_group_eq;
     pl->ramp_first = K.ramp_first;
     pl->link_slots = pl->link_free = K.link_slots;
-    pl->short_job = K.short_job;
-    if (pl->cfg.input_cache_mb > 0) {
-      pl->inputs.cap = (size_t)pl->cfg.input_cache_mb << 20;
+    if (pl->cfg.input_cache_mb >= 0) {
+      pl->inputs.cap = (size_t)(pl->cfg.input_cache_mb > 0 ? pl->cfg.input_cache_mb : 512) << 20;
       pl->inputs.sight = pl->cfg.input_cache_sight > 0 ? pl->cfg.input_cache_sight : 1;
     }
     for (int i = 0; i < K.copy_streams; i++) {                 // (measured: profiles/r3_pipe_sweep.txt)
@@ -1023,10 +1063,9 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     const int batch = pl->cfg.batch > 0 ? pl->cfg.batch : 48;
     const int nl = (int)pl->lanes.size();
     std::vector<std::vector<jga_job *>> groups;
-    std::vector<int> pieces;
     {
       std::vector<std::vector<int>> plan;
-      plan_groups({nl, batch, pl->groups_per_lane, pl->min_group_eq, pl->ramp_first != 0, pl->short_job}, jobs, n, plan, &pieces);
+      plan_groups({nl, batch, pl->groups_per_lane, pl->min_group_eq, pl->ramp_first != 0}, jobs, n, plan);
       groups.resize(plan.size());
       for (size_t k = 0; k < plan.size(); k++) {
         groups[k].reserve(plan[k].size());
@@ -1040,7 +1079,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     if (trace) fprintf(stderr, "run: %d jobs in %d groups at %.2f ms\n", n, (int)groups.size(), pl->since_run_start_ms());
     {
       std::lock_guard<std::mutex> lk(pl->run_mutex);
-      pl->run_groups = &groups; pl->run_next = &next; pl->run_threads = per; pl->run_pieces = &pieces;
+      pl->run_groups = &groups; pl->run_next = &next; pl->run_threads = per;
       pl->run_done = 0;
       pl->run_gen++;
     }
@@ -1069,7 +1108,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
 JGA_EXPORT int jga_pipeline_plan_cfg(const jga_pipeline_config *cfg, const jga_job *jobs, int n, int *group_of) {
   std::vector<std::vector<int>> plan;
   const sched_knobs K = resolve_knobs(*cfg);     // (what jga_pipeline_create makes of the same configuration)
-  plan_groups({K.lanes, K.batch, K.groups_per_lane, K.min_group_eq, K.ramp_first, K.short_job}, jobs, n, plan);
+  plan_groups({K.lanes, K.batch, K.groups_per_lane, K.min_group_eq, K.ramp_first}, jobs, n, plan);
   for (size_t k = 0; k < plan.size(); k++) for (int i : plan[k]) group_of[i] = (int)k;
   return (int)plan.size();
 }
@@ -1082,11 +1121,11 @@ JGA_EXPORT int jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int 
 }
 
 JGA_EXPORT int jga_pipeline_register_input(jga_pipeline *pl, const unsigned char *jpeg, int size) {
-  if (!pl->inputs.enabled()) return jga_fail("pipeline: no input cache (jga_pipeline_config.input_cache_mb = 0)");
+  if (!pl->inputs.enabled()) return jga_fail("pipeline: no input cache (jga_pipeline_config.input_cache_mb < 0)");
   if (!hip_ok(hipSetDevice(pl->cfg.device), "hipSetDevice")) return EXIT_FAILURE;
   if (!pl->inputs.acquire(jpeg, (size_t)(size > 0 ? size : 0), false)) {
     return jga_fail("pipeline: could not register %d bytes at %p (cache of %d MB, buffers under 64 KB are never registered)",
-     size, (const void *)jpeg, pl->cfg.input_cache_mb);
+     size, (const void *)jpeg, (int)(pl->inputs.cap >> 20));
   }
   pl->inputs.release(jpeg);
   return EXIT_SUCCESS;
@@ -1099,10 +1138,10 @@ JGA_EXPORT int jga_pipeline_forget_input(jga_pipeline *pl, const unsigned char *
 JGA_EXPORT int jga_pipeline_counters(const jga_pipeline *pl, long long *out, int n) {
   const input_cache &c = pl->inputs;
   const bool on_device = pl->cfg.unstuff == 2 || (pl->cfg.unstuff == 0 && pl->offload_cleanup);
-  const long long v[8] = {c.n_registered.load(), (long long)(c.held >> 20), c.n_in_place.load(), c.n_copied.load(),
-   c.n_evicted.load(), c.us_register.load(), on_device ? 1 : 0, c.host_bytes.load()};
-  for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
-  return 8;
+  const long long v[9] = {c.n_registered.load(), (long long)(c.held >> 20), c.n_in_place.load(), c.n_copied.load(),
+   c.n_evicted.load(), c.us_register.load(), on_device ? 1 : 0, c.host_bytes.load(), c.n_stale.load()};
+  for (int i = 0; i < n && i < 9; i++) out[i] = v[i];
+  return 9;
 }
 
 JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {

@@ -45,6 +45,8 @@ struct hipjpeg_ctx {
   short *h_coef;              // pinned
   unsigned char *h_out;       // pinned
   short *d_coef;
+  short *d_dc;                // DC values beside the planes (jga_huff_decode_split_begin)
+  long long cap_dc;
   unsigned short *d_qtab;
   unsigned char *d_out;
   long long cap_coef, cap_out;
@@ -245,10 +247,11 @@ void release_device(hipjpeg_ctx *c) {
   if (c->h_coef) (void)hipHostFree(c->h_coef);
   if (c->h_out) (void)hipHostFree(c->h_out);
   if (c->d_coef) (void)hipFree(c->d_coef);
+  if (c->d_dc) (void)hipFree(c->d_dc);
   if (c->d_qtab) (void)hipFree(c->d_qtab);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  c->h_coef = NULL; c->h_out = NULL; c->d_coef = NULL; c->d_qtab = NULL;
+  c->h_coef = NULL; c->h_out = NULL; c->d_coef = NULL; c->d_qtab = NULL; c->d_dc = NULL; c->cap_dc = 0;
   c->d_out = NULL; c->stream = NULL; c->cap_coef = c->cap_out = 0;
 }
 
@@ -364,6 +367,7 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
     }
     int on_gpu = !c->opt.host_entropy;
     const bool direct = c->opt.register_buffers == 0;         // (1: registered for the life of the context; -1: staged copies)
+    const long long dcstride = (g->coef_shorts/64 + 127) & ~127ll;
     if (on_gpu) {
       jga_geom g2;
       if (!c->hb || c->size + 4096ll > c->hb_scan) {
@@ -373,7 +377,13 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
         if (!c->hb) { c->hb_scan = 0; return EXIT_FAILURE; }
         jga_huff_set_threads(c->hb, 1);
       }
-      // (a caller that lets its buffers be registered: a big file is DMA'd where it lies and the
+      if (dcstride > c->cap_dc) {
+        if (c->d_dc) (void)hipFree(c->d_dc);
+        c->d_dc = NULL; c->cap_dc = 0;
+        HIP_OK(hipMalloc((void **)&c->d_dc, (size_t)dcstride*sizeof(short)));
+        c->cap_dc = dcstride;
+      }
+      // (a caller that lets its buffers be registered: a big file is read where it lies and the
       // device cleans the scan up — the host's pass over the entropy-coded bytes takes one core
       // 0.2 ms for a 4K file, the four launches of the device's ~0.1 ms whatever the size: a 4K frame
       // 1.15 -> 1.08 ms, 8K 3.5 -> 2.7, a 1080p frame is better off with the host's)
@@ -384,51 +394,69 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
         if (jga_huff_prepare_verdict(c->hb, 0) != 2) return EXIT_FAILURE;
         on_gpu = 0;                        // tables / frame size outside the device format
       }
-      else if (jga_huff_decode(c->hb, c->d_coef, g->coef_shorts, c->stream) != EXIT_SUCCESS) {
+      // the decode's first half: everything is queued, nothing waited for — the block decode and the copy back
+      // go in behind it, and the frame costs ONE host wait
+      else if (jga_huff_decode_split_begin(c->hb, c->d_coef, g->coef_shorts, c->d_dc, dcstride, c->stream) != EXIT_SUCCESS) {
         return EXIT_FAILURE;
       }
     }
-    if (!on_gpu && jga_entropy_decode(c->buf, c->size, g, c->h_coef, 0) != EXIT_SUCCESS) {
-      return EXIT_FAILURE;
-    }
-    memset(qtab, 0, sizeof(qtab));
-    for (i = 0; i < g->nplanes; i++) {
-      memcpy(qtab + 64*i, c->header.comp[i].quant->tbl, 64*sizeof(unsigned short));
-    }
-    HIP_OK(hipMemcpyAsync(c->d_qtab, qtab, sizeof(qtab), hipMemcpyHostToDevice, c->stream));
-    if (!on_gpu) {
+    const unsigned short *d_q = c->d_qtab;
+    if (on_gpu) d_q = jga_huff_qtabs_device(c->hb);            // (they came up with the file's descriptors)
+    else {
+      if (jga_entropy_decode(c->buf, c->size, g, c->h_coef, 0) != EXIT_SUCCESS) return EXIT_FAILURE;
+      memset(qtab, 0, sizeof(qtab));
+      for (i = 0; i < g->nplanes; i++) {
+        memcpy(qtab + 64*i, c->header.comp[i].quant->tbl, 64*sizeof(unsigned short));
+      }
+      HIP_OK(hipMemcpyAsync(c->d_qtab, qtab, sizeof(qtab), hipMemcpyHostToDevice, c->stream));
+      HIP_OK(hipStreamSynchronize(c->stream));                 // (qtab is on this stack frame)
       HIP_OK(hipMemcpyAsync(c->d_coef, c->h_coef, g->coef_shorts*sizeof(short),
        hipMemcpyHostToDevice, c->stream));
     }
-    if ((rgb ? jga_idct_rgb_batch(g, 1, c->d_coef, g->coef_shorts, c->d_qtab, 1,
-     c->d_out, c->cap_out, c->stream)
-     : jga_idct_yuv_batch(g, 1, c->d_coef, g->coef_shorts, c->d_qtab, 1,
-     c->d_out, c->cap_out, c->stream)) != EXIT_SUCCESS) {
-      return EXIT_FAILURE;
-    }
-    // D2H straight into the caller's buffers when they can be registered, else through
-    // the pinned staging buffer
-    if (rgb) {
-      if (direct || registered(c, img->pixels, (size_t)out_bytes)) {
-        HIP_OK(hipMemcpyAsync(img->pixels, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipStreamSynchronize(c->stream));
-      }
-      else {
-        const out_segment one = {img->pixels, (size_t)out_bytes};
-        if (copy_back_staged(c, &one, 1, c->d_out, c->h_out, (size_t)out_bytes) != EXIT_SUCCESS) return EXIT_FAILURE;
-      }
-    }
+    // D2H straight into the caller's buffers when the copies may name them, else through
+    // the pinned staging buffer (which does its own waiting)
+    bool in_place = true;
+    if (rgb) in_place = direct || registered(c, img->pixels, (size_t)out_bytes);
     else {
-      bool in_place = true;
       for (i = 0; i < img->nplanes; i++) {
         in_place = in_place && (direct || registered(c, img->plane[i].data, (size_t)img->plane[i].ystride*img->plane[i].height));
       }
-      if (in_place) {
-        for (i = 0; i < img->nplanes; i++) {
-          HIP_OK(hipMemcpyAsync(img->plane[i].data, c->d_out + g->plane[i].data_off,
-           (size_t)img->plane[i].ystride*img->plane[i].height, hipMemcpyDeviceToHost, c->stream));
+    }
+    auto queue_behind = [&]() -> int {
+      const short *dcv = on_gpu ? c->d_dc : NULL;
+      if ((rgb ? jga_idct_rgb_batch_dc(g, 1, c->d_coef, g->coef_shorts, dcv, dcstride, d_q, 1, c->d_out, c->cap_out, c->stream)
+       : jga_idct_yuv_batch_dc(g, 1, c->d_coef, g->coef_shorts, dcv, dcstride, d_q, 1, c->d_out, c->cap_out, c->stream)) != EXIT_SUCCESS) {
+        return EXIT_FAILURE;
+      }
+      if (!in_place) return EXIT_SUCCESS;
+      if (rgb) HIP_OK(hipMemcpyAsync(img->pixels, c->d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+      else {
+        for (int k = 0; k < img->nplanes; k++) {
+          HIP_OK(hipMemcpyAsync(img->plane[k].data, c->d_out + g->plane[k].data_off,
+           (size_t)img->plane[k].ystride*img->plane[k].height, hipMemcpyDeviceToHost, c->stream));
         }
-        HIP_OK(hipStreamSynchronize(c->stream));
+      }
+      return EXIT_SUCCESS;
+    };
+    // (a failure from here on must not leave copies into the caller's buffers in flight)
+    int rc = queue_behind();
+    if (rc == EXIT_SUCCESS && on_gpu) {
+      int valid_behind = 0;
+      rc = jga_huff_decode_split_end(c->hb, &valid_behind);    // (waits for the stream)
+      if (rc == EXIT_SUCCESS && !valid_behind) {
+        rc = queue_behind();
+        if (rc == EXIT_SUCCESS && hipStreamSynchronize(c->stream) != hipSuccess) rc = jga_fail("hipjpeg: device wait failed");
+      }
+    }
+    else if (rc == EXIT_SUCCESS && hipStreamSynchronize(c->stream) != hipSuccess) rc = jga_fail("hipjpeg: device wait failed");
+    if (rc != EXIT_SUCCESS) {
+      (void)hipStreamSynchronize(c->stream);
+      return EXIT_FAILURE;
+    }
+    if (!in_place) {
+      if (rgb) {
+        const out_segment one = {img->pixels, (size_t)out_bytes};
+        if (copy_back_staged(c, &one, 1, c->d_out, c->h_out, (size_t)out_bytes) != EXIT_SUCCESS) return EXIT_FAILURE;
       }
       else {
         // (the padded planes lie back to back in d_out, g->plane[i].data_off: ONE staged copy of all of

@@ -28,6 +28,7 @@ EXPORTED = [
     "jga_pipeline_plan_cfg", "jga_pipeline_register_input", "jga_pipeline_forget_input", "jga_pipeline_counters",
     "jga_huff_set_input_flags", "jga_huff_host_bytes", "jga_huff_set_option", "jga_plugin_configure",
     "jga_time_device_copy", "jga_time_kernel_copy",
+    "jga_huff_decode_split_begin", "jga_huff_decode_split_end", "jga_huff_qtabs_device",
 ]
 
 
@@ -126,6 +127,10 @@ L.jga_huff_prepare.argtypes = [_vp, C.POINTER(C.c_char_p), C.POINTER(_i), _i, _G
 L.jga_huff_decode.argtypes = [_vp, _vp, _ll, _vp]
 if hasattr(L, "jga_huff_decode_split"):
     L.jga_huff_decode_split.argtypes = [_vp, _vp, _ll, _vp, _ll, _vp]
+L.jga_huff_decode_split_begin.argtypes = [_vp, _vp, _ll, _vp, _ll, _vp]
+L.jga_huff_decode_split_end.argtypes = [_vp, C.POINTER(_i)]
+L.jga_huff_qtabs_device.argtypes = [_vp]
+L.jga_huff_qtabs_device.restype = _vp
 L.jga_huff_prepare_verdict.argtypes = [_vp, _i]
 L.jga_huff_upload_bytes.argtypes = [_vp]
 L.jga_huff_upload_bytes.restype = _ll
@@ -434,9 +439,8 @@ class Pipeline:
     @staticmethod
     def config(device=0, nthreads=0, out=abi.JPEG_DECODE_RGB, copy_back=False,
                max_coef_shorts=0, max_out_bytes=0, transport=0, batch=0, depth=0, unstuff=0, **more):
-        """A jga_pipeline_config; `more` = any of its round-4 fields by name (link_slots, device_slots,
-        groups_per_lane, min_group, ramp_first, spin_waits, offload_at, copy_streams, trace,
-        input_cache_mb, input_cache_sight, huff_sub_bytes, huff_assist_after, huff_speculate, short_job)."""
+        """A jga_pipeline_config; `more` = any of its other fields by name (spin_waits, trace, input_cache_mb,
+        input_cache_sight)."""
         cfg = abi.jga_pipeline_config(C.sizeof(abi.jga_pipeline_config), C.sizeof(abi.jga_job),
                                       device, nthreads, depth, out, int(copy_back),
                                       max_coef_shorts, max_out_bytes, int(transport), int(batch),
@@ -456,11 +460,11 @@ class Pipeline:
         self.copy_back = bool(cfg.copy_back)
 
     def counters(self):
-        """{registered, registered_MB, jobs_in_place, jobs_copied, evicted, register_us} since create."""
-        v = (_ll * 8)()
-        L.jga_pipeline_counters(self.ptr, v, 8)
+        """{registered, registered_MB, jobs_in_place, jobs_copied, evicted, register_us, ..., stale} since create."""
+        v = (_ll * 9)()
+        L.jga_pipeline_counters(self.ptr, v, 9)
         return dict(zip(("registered", "registered_MB", "jobs_in_place", "jobs_copied", "evicted", "register_us",
-                         "cleanup_on_device", "host_bytes"), [int(x) for x in v]))
+                         "cleanup_on_device", "host_bytes", "stale"), [int(x) for x in v]))
 
     def register_input(self, array):
         check(L.jga_pipeline_register_input(self.ptr, array.ctypes.data, array.size))
@@ -551,6 +555,19 @@ class HuffBatch:
         """Planes with DC differences + the DC values by buffer slot in d_dc (for *_batch_dc)."""
         check(L.jga_huff_decode_split(self.ptr, d_coef_ptr, coef_stride, d_dc_ptr, dc_stride, stream))
         return L.jga_huff_last_rounds(self.ptr)
+
+    def decode_split_begin(self, d_coef_ptr, coef_stride, d_dc_ptr, dc_stride, stream=None):
+        """The decode's first half: everything queued on `stream`, nothing waited for."""
+        check(L.jga_huff_decode_split_begin(self.ptr, d_coef_ptr, coef_stride, d_dc_ptr, dc_stride, stream))
+
+    def decode_split_end(self):
+        """The second half: waits for the stream; -> (sync rounds, did work queued in between see the final planes)."""
+        valid = C.c_int(0)
+        check(L.jga_huff_decode_split_end(self.ptr, C.byref(valid)))
+        return L.jga_huff_last_rounds(self.ptr), bool(valid.value)
+
+    def qtabs_device(self):
+        return L.jga_huff_qtabs_device(self.ptr)
 
     def assisted(self):
         return L.jga_huff_last_assisted(self.ptr)

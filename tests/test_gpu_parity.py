@@ -303,13 +303,12 @@ def test_pipeline_gpu_entropy_group_with_a_damaged_scan(gpu, orc, synth):
         pl.close()
 
 
-@pytest.mark.parametrize("device_slots", [None, "1", "9"])
-def test_pipeline_gpu_entropy_batches(gpu, orc, synth, device_slots):
+@pytest.mark.parametrize("more", [{}, {"unstuff": 1}, {"unstuff": 2, "input_cache_mb": -1}, {"spin_waits": 1}])
+def test_pipeline_gpu_entropy_batches(gpu, orc, synth, more):
     """transport 2 on a stream of same-geometry images: full groups, a ragged last group,
-    results left in HBM at caller-given addresses and in internal buffers; with the default
-    number of lanes allowed on the device at a time, with one, and with no limit."""
+    results left in HBM at caller-given addresses and in internal buffers; with the clean-up where the
+    pipeline puts it, on the host, on the device with copy calls naming the files, and with spinning waits."""
     from jpeg_gpu_amd import abi
-    more = {"device_slots": int(device_slots)} if device_slots else {}
     datas = [synth.synthetic_jpeg(640, 360, "420", quality=50 + i, seed=i, restart_interval=(i % 2) * 40)
              for i in range(37)]
     _, g = gpu.geom_of(datas[0])
@@ -399,9 +398,13 @@ def test_pipeline_unstuff_modes_and_pinned_inputs(gpu, orc, synth, mode):
             if i != 7:
                 assert np.array_equal(outs[i], want[i]), (mode, i)
         assert not outs[7].any()              # a failed job hands out zeros, not leftovers of other images
-        # (clean-up on the device: the copy engine reads every file where it lies — pinned or not — and no
-        # host core passes over it; on the host: every byte)
-        assert all(j.host_bytes == (0 if mode != "host" else j.size) for i, j in enumerate(jobs) if i != 7)
+        # (clean-up on the device: the device reads every file where it lies — pinned, or ordinary memory the input
+        # cache registers; buffers under 64 KB are cheaper to copy than to register — and no host core passes over
+        # it; on the host: every byte)
+        for i, j in enumerate(jobs):
+            if i != 7:
+                copied = mode == "host" or (not (j.pinned & 1) and j.size < 65536)
+                assert j.host_bytes == (j.size if copied else 0), (mode, i, j.size)
     finally:
         pl.close()
         for p in pins:
@@ -410,11 +413,11 @@ def test_pipeline_unstuff_modes_and_pinned_inputs(gpu, orc, synth, mode):
 
 def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
     """jga_pipeline_config.input_cache_mb: callers' ordinary (pageable) buffers are registered with the
-    device the first (or input_cache_sight-th) time a run sees them and DMA'd where they lie from then
+    device the first (or input_cache_sight-th) time a run sees them and read where they lie from then
     on, least recently used out first when the cache is full; buffers the cache does not hold (under 64 KB,
-    larger than the cache, seen once under the second-sight policy) are named in the copies as they are and
-    pinned by the runtime; input_cache_mb < 0: a host core copies them (rounds 2-3); forget / explicit
-    register; same pixels as the oracle's every time."""
+    larger than the cache, seen once under the second-sight policy) are copied by a host core;
+    input_cache_mb = -1: no cache, the copies name the buffers as they are and the runtime pins them; -2: a host
+    core copies every file (rounds 2-3); forget / explicit register; same pixels as the oracle's every time."""
     from jpeg_gpu_amd import abi
     datas = [synth.synthetic_jpeg(1280, 720, "420", quality=90, seed=40 + i, restart_interval=(i % 2) * 80)
              for i in range(10)]
@@ -440,7 +443,7 @@ def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
         jobs = run(pl, list(range(11)))
         c = pl.counters()
         assert c["cleanup_on_device"] == 1 and c["registered"] == 10 and c["evicted"] == 0
-        assert all(j.host_bytes == 0 for j in jobs)                             # first sight registers; the small file goes as it is
+        assert all(j.host_bytes == 0 for j in jobs[:10]) and jobs[10].host_bytes == jobs[10].size   # first sight registers; the small file is copied
         jobs = run(pl, [3, 3, 9, 0, 3])
         c2 = pl.counters()
         assert c2["registered"] == 10 and c2["jobs_in_place"] == c["jobs_in_place"] + 5
@@ -473,8 +476,15 @@ def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
             pl.register_input(big)                                              # larger than the whole cache
     finally:
         pl.close()
-    # no cache: the default names the callers' memory in the copies (no host pass), input_cache_mb < 0 copies it
-    for mb, copied in ((0, False), (-1, True)):
+    # the default is a cache of 512 MB
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2, unstuff=2)
+    try:
+        run(pl, list(range(10)))
+        assert pl.counters()["registered"] == 10
+    finally:
+        pl.close()
+    # no cache: -1 names the callers' memory in the copies (no host pass), -2 copies it
+    for mb, copied in ((-1, False), (-2, True)):
         pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2,
                           unstuff=2, input_cache_mb=mb)
         try:
@@ -490,6 +500,58 @@ def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
         assert pl.counters()["registered"] == 0 and all(j.host_bytes == j.size for j in jobs)
     finally:
         pl.close()
+
+
+def test_input_cache_never_serves_a_stale_buffer(gpu, orc, synth):
+    """The reference's caller keeps its file in plain malloc memory and frees it with the jpeg_info
+    (src/jpeg_info.c:31-62).  A buffer that is freed (unmapped) and handed out again AT THE SAME ADDRESS AND SIZE
+    for another file must decode as the NEW file: the cache's registration was made for the old contents — and may
+    name pages the buffer no longer has.  Every entry carries a fingerprint of its file that is re-read at every
+    sight; a mismatch drops the registration and registers afresh (counter `stale`)."""
+    import ctypes as C
+    import mmap
+    from jpeg_gpu_amd import abi
+    a = synth.synthetic_jpeg(1280, 720, "420", quality=90, seed=501)
+    b = synth.synthetic_jpeg(1280, 720, "420", quality=90, seed=502)
+    n = (max(len(a), len(b)) + 2 * mmap.PAGESIZE) // mmap.PAGESIZE * mmap.PAGESIZE
+    a, b = a + b"\0" * (n - len(a)), b + b"\0" * (n - len(b))     # (bytes after the EOI are nobody's business)
+    assert a[:64] == b[:64] and a[-64:] == b[-64:] and len(a) == len(b)         # only the scans differ
+    _, g = gpu.geom_of(a)
+    libc = C.CDLL(None, use_errno=True)
+    libc.mmap.restype = C.c_void_p
+    libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+    libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
+    MAP_FIXED = 0x10
+    addr = libc.mmap(None, n, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, -1, 0)
+    assert addr not in (None, C.c_void_p(-1).value)
+    out = np.zeros(g.rgb_bytes, np.uint8)
+    pl = gpu.Pipeline(device=0, nthreads=2, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2, unstuff=2)
+    try:
+        def decode_what_lies_there():
+            buf = np.ctypeslib.as_array((C.c_ubyte * n).from_address(addr))
+            jobs = gpu.Pipeline.make_jobs([buf], host_outs=[out])
+            assert pl.run_jobs(jobs) == 0
+            return out.copy()
+        C.memmove(addr, a, n)
+        assert np.array_equal(decode_what_lies_there(), orc.decode_rgb(a)[1].reshape(-1))
+        assert np.array_equal(decode_what_lies_there(), orc.decode_rgb(a)[1].reshape(-1))
+        c = pl.counters()
+        assert c["registered"] == 1 and c["jobs_in_place"] == 2 and c["stale"] == 0
+        # the caller frees the buffer; the allocator hands the same range out again, backed by fresh pages
+        assert libc.munmap(addr, n) == 0
+        again = libc.mmap(addr, n, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | MAP_FIXED, -1, 0)
+        assert again == addr
+        C.memmove(addr, b, n)
+        assert np.array_equal(decode_what_lies_there(), orc.decode_rgb(b)[1].reshape(-1))
+        c = pl.counters()
+        assert c["stale"] == 1 and c["registered"] == 2
+        # ... and a buffer that is simply overwritten in place (same pages) is caught the same way
+        C.memmove(addr, a, n)
+        assert np.array_equal(decode_what_lies_there(), orc.decode_rgb(a)[1].reshape(-1))
+        assert pl.counters()["stale"] == 2
+    finally:
+        pl.close()
+        libc.munmap(addr, n)
 
 
 # ---- PACK wire format expanded on the GPU (SURVEY.md §8f-2) ---------------------------
@@ -881,97 +943,94 @@ def test_split_decode_dc_values_beside_the_planes(gpu, orc, synth, sampling, ri)
             b.free()
 
 
-@pytest.mark.parametrize("device_unstuff", [False, True])
+@pytest.mark.parametrize("nstreams", [0, 1])
 @pytest.mark.parametrize("sampling,ri", [("420", 0), ("420", 9), ("444", 0), ("422", -1), ("grey", 3)])
-def test_upload_in_pieces_gives_the_same_planes(gpu, orc, synth, sampling, ri, device_unstuff):
-    """JGA_HUFF_OPT_PIECES: prepare() uploads the batch in pieces and queues each piece's start states and first
-    synchronisation round behind its arrival; the decode goes on from round 1.  Same QUANT planes as the
-    oracle's for every piece count (more pieces than images included), with the clean-up on the host and on
-    the device, pinned files DMA'd in place among copied ones, a second decode of the same prepared batch
-    (which starts from scratch), and a later ordinary prepare on the same batch object."""
+def test_files_read_where_they_lie_among_copied_ones(gpu, orc, synth, sampling, ri, nstreams):
+    """Clean-up on the device: files the caller flags are read where they lie, one copy call each — at whatever
+    alignment their scans start — on the decode's own stream or on the copy stream the caller names
+    (jga_huff_set_copy_stream); the others are copied into the blob by the host and go up from there.  Same QUANT
+    planes as the oracle's for every mix, on a second decode of the same prepared batch, and for a later ordinary
+    prepare on the same batch object."""
+    import ctypes as C
     datas = [synth.synthetic_jpeg(333, 211, sampling, quality=40 + 5 * i, restart_interval=ri, seed=70 + i)
              for i in range(11)]
     want = [oracle_quant(orc, d) for d in datas]
-    pins = [gpu.PinnedBytes(d) for d in datas]
-    hb = gpu.HuffBatch(len(datas), sum(map(len, datas)) + 4096 * len(datas), device_unstuff=device_unstuff)
+    # (every pinned copy starts at another offset inside its buffer)
+    pins = [gpu.PinnedBytes(b"\0" * (i % 7) + d) for i, d in enumerate(datas)]
+    addr = lambda i: pins[i].array.ctypes.data + i % 7
+    hb = gpu.HuffBatch(len(datas), sum(map(len, datas)) + 4096 * len(datas), device_unstuff=True)
+    streams = [gpu.L.jga_stream_create() for _ in range(nstreams)]
     d = None
     try:
-        for pieces in (2, 3, 16, 0):
-            hb.set_option(4, pieces)              # JGA_HUFF_OPT_PIECES
-            for mixed in ((False, True) if device_unstuff else (False,)):
-                if mixed:                       # every other file lies in pinned memory and says so
-                    flags = bytes(i % 2 for i in range(len(datas)))
-                    gpu.L.jga_huff_set_input_flags(hb.ptr, flags, len(datas))
-                    g = hb.prepare_at([pins[i].array.ctypes.data if i % 2 else np.frombuffer(datas[i], np.uint8).ctypes.data
-                                       for i in range(len(datas))], [len(x) for x in datas])
-                else:
-                    gpu.L.jga_huff_set_input_flags(hb.ptr, None, 0)
-                    g = hb.prepare(datas)
-                cs = gpu._align(g.coef_shorts * 2) // 2
-                if d is None:
-                    d = gpu.DeviceBuffer(cs * 2 * len(datas))
-                m = gpu.real_coef_mask(g)
-                for rep in range(2):
-                    d.upload(np.full(cs * len(datas), 0x5A5A, np.int16))
-                    hb.decode(d.ptr, cs)
-                    got = d.download(dtype=np.int16).reshape(len(datas), cs)
-                    for i in range(len(datas)):
-                        assert np.array_equal(got[i][:g.coef_shorts][m], want[i][m]), (pieces, mixed, rep, i)
+        gpu.L.jga_huff_set_copy_stream.argtypes = [C.c_void_p, C.c_void_p]
+        gpu.L.jga_huff_set_copy_stream(hb.ptr, streams[0] if streams else None)
+        for flags in ([1] * 11, [i % 2 for i in range(11)], [int(i % 3 == 0) for i in range(11)], [0] * 11):
+            gpu.L.jga_huff_set_input_flags(hb.ptr, bytes(flags), len(datas))
+            g = hb.prepare_at([addr(i) if flags[i] else np.frombuffer(datas[i], np.uint8).ctypes.data
+                               for i in range(len(datas))], [len(x) for x in datas])
+            cs = gpu._align(g.coef_shorts * 2) // 2
+            if d is None:
+                d = gpu.DeviceBuffer(cs * 2 * len(datas))
+            m = gpu.real_coef_mask(g)
+            for rep in range(2):
+                d.upload(np.full(cs * len(datas), 0x5A5A, np.int16))
+                hb.decode(d.ptr, cs)
+                got = d.download(dtype=np.int16).reshape(len(datas), cs)
+                for i in range(len(datas)):
+                    assert np.array_equal(got[i][:g.coef_shorts][m], want[i][m]), (flags, rep, i)
+        gpu.L.jga_huff_set_input_flags(hb.ptr, None, 0)
+        gpu.L.jga_huff_set_copy_stream(hb.ptr, None)
+        g = hb.prepare(datas)
+        hb.decode(d.ptr, cs)
+        got = d.download(dtype=np.int16).reshape(len(datas), cs)
+        assert all(np.array_equal(got[i][:g.coef_shorts][m], want[i][m]) for i in range(len(datas)))
     finally:
         hb.close()
+        for st in streams:
+            gpu.L.jga_stream_destroy(st)
         if d is not None:
             d.free()
         for p in pins:
             p.free()
 
 
-def test_upload_in_pieces_with_a_damaged_member(gpu, orc, synth):
-    """A file with restart intervals that breaks off in mid-scan (an EOI where data should be) inside a batch
-    uploaded in pieces: with the clean-up on the host prepare() fails — after the pieces already queued have
-    drained — and names it; with the clean-up on the device the decode reports that member alone and the
-    others' planes are the oracle's."""
+def test_device_cleanup_with_a_damaged_member(gpu, orc, synth):
+    """A file with restart intervals that breaks off in mid-scan (an EOI where data should be) inside a batch whose
+    files are read where they lie: the decode reports that member alone and the others' planes are the oracle's."""
     datas = [synth.synthetic_jpeg(320, 200, "420", quality=80, seed=i, restart_interval=(i % 2) * 11) for i in range(9)]
     bad = bytearray(datas[7])
     bad[len(bad) // 2:len(bad) // 2 + 2] = b"\xff\xd9"
     datas[7] = bytes(bad[:len(bad) // 2 + 2])
     verdicts = [0] * 7 + [1, 0]
-    for device_unstuff in (False, True):
-        hb = gpu.HuffBatch(len(datas), sum(map(len, datas)) + 4096 * len(datas), device_unstuff=device_unstuff)
-        try:
-            hb.set_option(4, 4)                        # JGA_HUFF_OPT_PIECES
-            if not device_unstuff:
-                with pytest.raises(gpu.JgaError):
-                    hb.prepare(datas)
-                assert [gpu.L.jga_huff_prepare_verdict(hb.ptr, i) for i in range(9)] == verdicts
-                good = datas[:7] + datas[8:]
-                g = hb.prepare(good)                   # ... and the batch object is fine afterwards
-            else:
-                good = datas
-                g = hb.prepare(datas)
-            cs = gpu._align(g.coef_shorts * 2) // 2
-            d = gpu.DeviceBuffer(cs * 2 * len(good))
-            m = gpu.real_coef_mask(g)
-            if device_unstuff:
-                with pytest.raises(gpu.JgaError):
-                    hb.decode(d.ptr, cs)
-                assert [int(gpu.L.jga_huff_image_error(hb.ptr, i) != 0) for i in range(9)] == verdicts
-            else:
-                hb.decode(d.ptr, cs)
-            got = d.download(dtype=np.int16).reshape(len(good), cs)
-            for i, f in enumerate(good):
-                if device_unstuff and i == 7:
-                    continue
-                assert np.array_equal(got[i][:g.coef_shorts][m], oracle_quant(orc, f)[m]), (device_unstuff, i)
-            d.free()
-        finally:
-            hb.close()
+    pins = [gpu.PinnedBytes(d) for d in datas]
+    hb = gpu.HuffBatch(len(datas), sum(map(len, datas)) + 4096 * len(datas), device_unstuff=True)
+    try:
+        gpu.L.jga_huff_set_input_flags(hb.ptr, bytes([1] * 9), 9)
+        g = hb.prepare_at([p.array.ctypes.data for p in pins], [len(x) for x in datas])
+        cs = gpu._align(g.coef_shorts * 2) // 2
+        d = gpu.DeviceBuffer(cs * 2 * len(datas))
+        m = gpu.real_coef_mask(g)
+        with pytest.raises(gpu.JgaError):
+            hb.decode(d.ptr, cs)
+        assert [int(gpu.L.jga_huff_image_error(hb.ptr, i) != 0) for i in range(9)] == verdicts
+        got = d.download(dtype=np.int16).reshape(len(datas), cs)
+        for i, f in enumerate(datas):
+            if i != 7:
+                assert np.array_equal(got[i][:g.coef_shorts][m], oracle_quant(orc, f)[m]), i
+        d.free()
+    finally:
+        hb.close()
+        for p in pins:
+            p.free()
 
 
 @pytest.mark.parametrize("pinned", [False, True])
-@pytest.mark.parametrize("unstuff", [1, 2])
-def test_pipeline_short_job_as_two_batches_in_pieces(gpu, orc, synth, pinned, unstuff):
-    """jga_pipeline_config.short_job = 2: a job that fits one group runs as two batches whose uploads arrive in
-    pieces.  Same pixels as the oracle's; a later, long job on the same pipeline is cut as usual."""
+@pytest.mark.parametrize("more", [{}, {"unstuff": 1}, {"unstuff": 2}, {"input_cache_mb": -1}, {"input_cache_mb": -2}])
+def test_pipeline_short_and_long_runs(gpu, orc, synth, pinned, more):
+    """A run that gives every lane a group or two takes the route with the fewest host steps (clean-up on the
+    device, the files read where they lie, one wait per group); a long
+    one the steady-state route.  Same pixels as the oracle's either way, for pinned files and ordinary ones (held by
+    the input cache, named in copy calls, or copied), one run after the other on the same pipeline."""
     from jpeg_gpu_amd import abi
     datas = [synth.synthetic_jpeg(1280, 720, "420", quality=92, seed=200 + i, restart_interval=(i % 3 == 0) * 40)
              for i in range(12)]
@@ -980,9 +1039,9 @@ def test_pipeline_short_job_as_two_batches_in_pieces(gpu, orc, synth, pinned, un
     pins = [gpu.PinnedBytes(d) for d in datas] if pinned else []
     src = [p.array for p in pins] if pinned else datas
     pl = gpu.Pipeline(device=0, nthreads=6, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=16, depth=3,
-                      unstuff=unstuff, short_job=2)
+                      **more)
     try:
-        for n in (72, 5, 160):                           # 8 / 0.6 / 18 frame equivalents: two batches, one, ordinary groups
+        for n in (72, 5, 1, 160, 9):                     # 8 / 0.6 / 0.1 / 18 / 1 frame equivalents
             outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in range(n)]
             jobs = gpu.Pipeline.make_jobs([src[i % 12] for i in range(n)], host_outs=outs, pinned=pinned)
             assert pl.run_jobs(jobs) == 0
@@ -992,6 +1051,39 @@ def test_pipeline_short_job_as_two_batches_in_pieces(gpu, orc, synth, pinned, un
         pl.close()
         for p in pins:
             p.free()
+
+
+def test_decode_in_two_halves_with_the_block_decode_in_between(gpu, orc, synth):
+    """jga_huff_decode_split_begin / _end: the block-decode kernel is queued between the two halves, the host waits
+    once, and _end says that what was queued in between saw the final planes (a photograph-like stream settles
+    within the rounds queued up front).  Pixels = the oracle's, on a repeat decode too; _end without _begin fails."""
+    import ctypes as C
+    datas = [synth.synthetic_jpeg(640, 360, "420", quality=88, seed=300 + i, restart_interval=(i % 2) * 13) for i in range(5)]
+    n = len(datas)
+    hb = gpu.HuffBatch(n, sum(map(len, datas)) + 4096 * n)
+    g = hb.prepare(datas)
+    cs = gpu._align(g.coef_shorts * 2) // 2
+    dcs = (g.coef_shorts // 64 + 127) // 128 * 128
+    os_ = gpu._align(g.rgb_bytes)
+    d_coef, d_dc, d_rgb = gpu.DeviceBuffer(cs * 2 * n), gpu.DeviceBuffer(dcs * 2 * n), gpu.DeviceBuffer(os_ * n)
+    try:
+        with pytest.raises(gpu.JgaError):
+            hb.decode_split_end()
+        for rep in range(2):
+            d_rgb.fill(0x11)
+            hb.decode_split_begin(d_coef.ptr, cs, d_dc.ptr, dcs)
+            q = hb.qtabs_device()
+            assert q
+            gpu.check(gpu.L.jga_idct_rgb_batch_dc(C.byref(g), n, d_coef.ptr, cs, d_dc.ptr, dcs, q, 1, d_rgb.ptr, os_, None))
+            rounds, valid = hb.decode_split_end()
+            assert valid and rounds >= 1
+            got = d_rgb.download().reshape(n, os_)
+            for i, f in enumerate(datas):
+                assert np.array_equal(got[i][:g.rgb_bytes], orc.decode_rgb(f)[1].reshape(-1)), (rep, i)
+    finally:
+        hb.close()
+        for b in (d_coef, d_dc, d_rgb):
+            b.free()
 
 
 def test_speculative_tail_that_ran_too_early_is_undone(gpu):
@@ -1031,6 +1123,29 @@ for batch, damaged in ((files, None), (files[:2] + [bad], 2)):
             if i == damaged: continue
             want = orc.decode(f, oracle.QUANT)[1]
             assert np.array_equal(got[i][:g.coef_shorts][m], want[m]), (rep, i)
+    if damaged is None:
+        # the same through the two halves: a block decode queued in between ran on unsettled planes at least once
+        # (the first tail of a fresh batch object always does here) — _end must say so, and the redo must be right
+        hb2 = lib.HuffBatch(len(batch), sum(map(len, batch)) + 4096 * len(batch))
+        hb2.prepare(batch)
+        dcs = (g.coef_shorts // 64 + 127) // 128 * 128
+        osz = lib._align(g.rgb_bytes)
+        ddc, drgb = lib.DeviceBuffer(dcs * 2 * len(batch)), lib.DeviceBuffer(osz * len(batch))
+        seen_invalid = False
+        for rep in range(3):
+            hb2.decode_split_begin(d.ptr, cs, ddc.ptr, dcs)
+            q = hb2.qtabs_device()
+            lib.check(lib.L.jga_idct_rgb_batch_dc(C.byref(g), len(batch), d.ptr, cs, ddc.ptr, dcs, q, 1, drgb.ptr, osz, None))
+            rounds, valid = hb2.decode_split_end()
+            if not valid:
+                seen_invalid = True
+                lib.check(lib.L.jga_idct_rgb_batch_dc(C.byref(g), len(batch), d.ptr, cs, ddc.ptr, dcs, q, 1, drgb.ptr, osz, None))
+                lib.check(lib.L.jga_stream_sync(None))
+            px = drgb.download().reshape(len(batch), osz)
+            for i, f in enumerate(batch):
+                assert np.array_equal(px[i][:g.rgb_bytes], orc.decode_rgb(f)[1].reshape(-1)), ("halves", rep, i)
+        assert seen_invalid, "one round per burst: the first tail cannot have been final"
+        hb2.close(); ddc.free(); drgb.free()
     hb.close(); d.free()
 print("OK", lib.L.jga_huff_last_rounds.__name__)
 """ % ROOT

@@ -5,6 +5,7 @@ import ctypes as C
 from collections import Counter
 
 import numpy as np
+import pytest
 
 
 def plan(lib, files, order, lanes=8, batch=48):
@@ -58,26 +59,22 @@ def test_geometries_are_kept_apart_and_bad_files_alone(lib, synth):
     assert Counter(len([1 for k, o in zip(g, order) if o == 2 and k == kk]) for kk in set(g[np.array(order) == 2])) == Counter({1: 10})
 
 
-def test_plan_of_a_configuration_honours_its_scheduling_fields(lib, synth):
+def test_plan_of_a_configuration_is_the_plan_of_its_lanes_and_batch(lib, synth):
     """jga_pipeline_plan_cfg makes the plan jga_pipeline_run of a pipeline created from the same
-    configuration makes: groups_per_lane / min_group / ramp_first are read from the struct (rounds 2-3
-    read them from the environment, and jga_pipeline_plan ignored them: ADVICE r3)."""
+    configuration makes.  (The scheduling fields of round 4 — groups per lane, smallest group, the ramp — are
+    no longer configuration: round 5 removed them, every other value had measured slower or the same.)"""
     f = [tiny(synth, 1920, 1080)]
     jobs = lib.Pipeline.make_jobs(f * 128)
     group_of = (C.c_int * 128)()
 
     def sizes(**cfg):
-        c = lib.Pipeline.config(transport=2, depth=8, batch=32, **cfg)
+        c = lib.Pipeline.config(transport=2, **cfg)
         ng = lib.L.jga_pipeline_plan_cfg(C.byref(c), jobs, 128, group_of)
         g = np.array(group_of[:128])
         return [int((g == k).sum()) for k in range(ng)]
-    assert sizes() == [16] * 8                                    # the defaults: as jga_pipeline_plan
-    assert sizes(min_group=8) == [32] * 4
-    assert sizes(min_group=1, groups_per_lane=2) == [8] * 16
-    assert sizes(min_group=16) == [64] * 2
-    long_jobs = lib.Pipeline.make_jobs([tiny(synth, 3840, 2160)] * 2560)
-    group_of = (C.c_int * 2560)()
-    c = lib.Pipeline.config(transport=2, depth=8, batch=48, ramp_first=-1)
-    ng = lib.L.jga_pipeline_plan_cfg(C.byref(c), long_jobs, 2560, group_of)
-    g = np.array(group_of[:2560])
-    assert [int((g == k).sum()) for k in range(8)] == [48] * 8 and ng == 54     # no rising start
+    assert sizes(depth=8, batch=32) == [16] * 8                   # as jga_pipeline_plan(8, 32, ...)
+    assert sizes(depth=4, batch=32) == [16] * 8                   # none under four frame equivalents
+    assert sizes(depth=2, batch=32) == [8] + [16] * 7 + [8]       # (long for two lanes: the first groups rise)
+    assert sizes(depth=8, batch=2) == [8] * 16                    # ... and none over a full group
+    with pytest.raises(TypeError):
+        lib.Pipeline.config(transport=2, min_group=8)             # (gone)

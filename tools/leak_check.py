@@ -20,8 +20,8 @@ import numpy as np  # noqa: E402
 arrs = [np.frombuffer(j, np.uint8).copy() for j in jpegs]
 # (round 4: also the input cache — registrations must be dropped by destroy — and the upload in pieces,
 # whose batch objects own copy / kernel streams and events of their own)
-configs = ((2, {}), (2, dict(unstuff=2, input_cache_mb=64)), (2, dict(short_job=2, batch=48, unstuff=2)),
-           (2, dict(short_job=2, batch=48, unstuff=1)), (0, {}), (1, {}))
+configs = ((2, {}), (2, dict(unstuff=2, input_cache_mb=64)), (2, dict(batch=48, unstuff=2, input_cache_mb=-1)),
+           (2, dict(batch=48, unstuff=1)), (0, {}), (1, {}))
 if len(sys.argv) > 2:                      # e.g. "1" or "1,0": only these transports, plain
     configs = tuple((int(t), {}) for t in sys.argv[2].split(","))
 for transport, more in configs:

@@ -34,12 +34,7 @@ def measure(pinned, reps=15, **cfg):
 
 
 variants = [
-    {},
-    {"min_group": 8}, {"min_group": 16}, {"min_group": 32},
-    {"min_group": 2, "groups_per_lane": 2}, {"min_group": 2},
-    {"link_slots": 1}, {"link_slots": -1}, {"device_slots": 8}, {"device_slots": 8, "min_group": 8},
-    {"spin_waits": 1}, {"spin_waits": 1, "min_group": 8}, {"spin_waits": 1, "min_group": 16},
-    {"short_job": 2}, {"short_job": 2, "spin_waits": 1},
+    {}, {"spin_waits": 1}, {"unstuff": 1}, {"unstuff": 2}, {"input_cache_mb": -1}, {"input_cache_mb": -2},
 ]
 extra = [eval("dict(%s)" % a) for a in sys.argv[2:]]
 for v in (extra or variants):

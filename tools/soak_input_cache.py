@@ -1,6 +1,6 @@
 """Soak of round 4's host-side routes against the oracle's RGB: the input cache under pressure (a cache too
 small for the working set, eight lanes acquiring / registering / evicting side by side, both sight policies,
-buffers forgotten and re-registered between runs), uploads in pieces (short_job = 2), mixed pinned / pageable
+buffers forgotten and re-registered between runs), short runs (files fetched by the device), mixed pinned / pageable
 jobs.  Usage: soak_input_cache.py [rounds] [seed]   (the oracle is the checker here, as in tests/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,7 +25,7 @@ print("%d files, %.1f MB" % (len(files), total_mb), flush=True)
 bad = 0
 t0 = time.time()
 for cfg in (dict(input_cache_mb=max(2, int(total_mb / 3))), dict(input_cache_mb=max(2, int(total_mb / 3)), input_cache_sight=2),
-            dict(input_cache_mb=int(total_mb) + 8, short_job=2), dict(short_job=2, unstuff=1), dict(input_cache_mb=4, spin_waits=1)):
+            dict(input_cache_mb=int(total_mb) + 8, unstuff=2), dict(unstuff=1), dict(input_cache_mb=4, spin_waits=1)):
     pl = lib.Pipeline(device=0, nthreads=16, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=8, depth=8,
                       unstuff=cfg.pop("unstuff", 2), **cfg)
     mism = 0
