@@ -104,6 +104,10 @@ def parse_args(argv=None):
                     help="N = 1: repeat the headline in a child confined to the CPUs ONE rank of this many "
                          "gets (cgroup grant / N, on the GPU's NUMA node) -> `scale_proxy` (0 = skip)")
     ap.add_argument("--as-rank-of", type=int, default=0, help=argparse.SUPPRESS)   # the scale-proxy child
+    ap.add_argument("--proxy-slot", type=int, default=0, help=argparse.SUPPRESS)   # ... which share of the cores it takes
+    ap.add_argument("--proxy-dir", default="", help=argparse.SUPPRESS)             # ... and where the N children meet
+    ap.add_argument("--no-concurrent-proxy", action="store_true",
+                    help="skip scale_proxy.concurrent (N children alive at once on the one GPU, each on its own CPUs)")
     ap.add_argument("--input-cache-MB", type=int, default=1024,
                     help="jga_pipeline_config.input_cache_mb of the headline pipelines (0 = none): pageable "
                          "files are registered at first sight inside the timed region and DMA'd where they "
@@ -479,7 +483,8 @@ def main():
         budget = shard.rank_cpu_budget(my_cpus, proxy_of, quota if quota else float(len(orig_cpus)))
         mine = sorted(os.sched_getaffinity(0))
         cores = shard.cpu_cores(mine) if hasattr(shard, "cpu_cores") else [[c] for c in mine]
-        take = [core[0] for core in cores[:budget]] or mine[:budget]
+        first = (args.proxy_slot * budget) % max(1, len(cores) - budget + 1)     # (concurrent children: each its own cores)
+        take = [core[0] for core in cores[first:first + budget]] or mine[:budget]
         os.sched_setaffinity(0, take)
         my_cpus = len(take)
         os.environ["JGA_CPU_BUDGET"] = str(budget)
@@ -552,13 +557,22 @@ def main():
         if warm_jobs is not None:
             pl.run_jobs(warm_jobs)                                   # W untimed steps
         kept.buf.zero_()
-        if not pinned and kw.get("input_cache_mb", 0) > 0:
+        if not pinned and kw.get("input_cache_mb", 0) >= 0:
             # whatever the warm-up left registered is dropped: every file's FIRST sight — its
             # hipHostRegister — happens inside the timed region
             for v in timed_jobs._keep[0]:
                 lib.L.jga_pipeline_forget_input(pl.ptr, v.ctypes.data)
         c0 = pl.counters()
         fence()
+        if proxy_of > 1 and args.proxy_dir:
+            # N scale-proxy children alive at once: they enter their timed regions together
+            tag = "pinned" if pinned else "pageable"
+            open(os.path.join(args.proxy_dir, "%s.%d" % (tag, args.proxy_slot)), "w").close()
+            t_meet = time.perf_counter()
+            while sum(f.startswith(tag + ".") for f in os.listdir(args.proxy_dir)) < proxy_of:
+                if time.perf_counter() - t_meet > 300:
+                    raise SystemExit("bench.py: scale-proxy child %d: the others never arrived" % args.proxy_slot)
+                time.sleep(0.002)
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         rc = pl.run_jobs(timed_jobs)                                 # exactly K steps; returns when
@@ -593,7 +607,7 @@ def main():
         keys = ("cpu_ms_per_image", "host_bytes_per_image", "scan_cleanup", "registered_in_timed_region",
                 "register_ms_total", "jobs_dma_in_place")
         print("SCALE_PROXY " + json.dumps({
-            "as_rank_of": proxy_of, "cpus": my_cpus, "cpu_list": sorted(os.sched_getaffinity(0)),
+            "as_rank_of": proxy_of, "slot": args.proxy_slot, "cpus": my_cpus, "cpu_list": sorted(os.sched_getaffinity(0)),
             "cpu_budget": budget, "host_threads": nthreads, "images": K * B, "images_verified": page["verified"] + pinn["verified"],
             "pageable": dict({"Mpixel_s": round(page["rate"] / 1e6, 1), "ms_per_step": round(page["dt"] / K * 1e3, 4)},
                              **{k: page[k] for k in keys}),
@@ -652,6 +666,64 @@ def main():
         finally:
             if pin:
                 shard.pin_rank_to_gpu_node(local_rank, world, ids)
+    # ---- ... and the same N children ALIVE AT ONCE on this one GPU, each confined to its own share of the cores:
+    # what a single child cannot show — N processes registering buffers, parsing markers and polling at once on
+    # the host's grant.  The device is shared, so the children's SUM is what compares with `value`.
+    proxy_concurrent = None
+    if world == 1 and rank == 0 and args.scale_proxy > 1 and not args.no_concurrent_proxy and scale_proxy:
+        import tempfile
+        t_sp = time.perf_counter()
+        n_ch = args.scale_proxy
+        steps_c = max(2, K // 4)
+        meet = tempfile.mkdtemp(prefix="jga_proxy_")
+        keep_gb = max(4.0, min(args.max_keep_GB, 160.0) / n_ch)
+        base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps_c), "--warmup", "1",
+                "--batch", str(B), "--group", str(G), "--lanes", str(args.lanes), "--distinct", str(args.distinct),
+                "--as-rank-of", str(n_ch), "--input-cache-MB", str(args.input_cache_MB), "--proxy-dir", meet,
+                "--max-keep-GB", "%.1f" % keep_gb, "--prewarm", "0.1"] + (["--no-pin"] if args.no_pin else [])
+        try:
+            os.sched_setaffinity(0, orig_cpus)
+            env = {k: v for k, v in os.environ.items() if k != "JGA_CPU_BUDGET"}
+            procs = [subprocess.Popen(base + ["--proxy-slot", str(k)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True, env=env) for k in range(n_ch)]
+            kids = []
+            for pr in procs:
+                try:
+                    so, se = pr.communicate(timeout=900)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    so, se = pr.communicate()
+                line = [l for l in so.splitlines() if l.startswith("SCALE_PROXY ")]
+                if pr.returncode == 0 and line:
+                    kids.append(json.loads(line[0][len("SCALE_PROXY "):]))
+                else:
+                    log("bench.py: a concurrent scale-proxy child failed (rc %s):\n%s" % (pr.returncode, se[-800:]))
+            if len(kids) == n_ch:
+                proxy_concurrent = {"children": n_ch, "steps_each": steps_c, "images_each": steps_c * B,
+                                    "seconds": round(time.perf_counter() - t_sp, 1)}
+                for leg in ("pageable", "pinned"):
+                    px = steps_c * B * W * H
+                    slow = max(k_[leg]["ms_per_step"] for k_ in kids) * steps_c / 1e3
+                    rates = [k_[leg]["Mpixel_s"] for k_ in kids]
+                    proxy_concurrent[leg] = {
+                        "sum_Mpixel_s": round(n_ch * px / slow / 1e6, 1),
+                        "child_Mpixel_s_min_max": [min(rates), max(rates)],
+                        "slowest_child_share": round(min(rates) / sum(rates), 4),
+                        "cpu_ms_per_image_min_max": [min(k_[leg]["cpu_ms_per_image"] for k_ in kids),
+                                                     max(k_[leg]["cpu_ms_per_image"] for k_ in kids)],
+                        "host_bytes_per_image": max(k_[leg]["host_bytes_per_image"] for k_ in kids),
+                        "registered_in_timed_region": sum(k_[leg]["registered_in_timed_region"] for k_ in kids),
+                        "register_ms_total": round(sum(k_[leg]["register_ms_total"] for k_ in kids), 2),
+                        "scan_cleanup": kids[0][leg]["scan_cleanup"]}
+                proxy_concurrent["cpu_lists"] = [k_["cpu_list"] for k_ in sorted(kids, key=lambda k_: k_["slot"])]
+                proxy_concurrent["images_verified"] = sum(k_["images_verified"] for k_ in kids)
+        except Exception as e:
+            log("bench.py: concurrent scale proxy unavailable (%s)" % e)
+        finally:
+            import shutil
+            shutil.rmtree(meet, ignore_errors=True)
+            if pin:
+                shard.pin_rank_to_gpu_node(local_rank, world, ids)
     cleanup_route = page["scan_cleanup"]           # (what the library's `unstuff = 0` came to: jga_pipeline_counters)
     me = {"rank": rank, "gpu": gpu, "pci": (lib.device_pci_bus_id(gpu) if ndev else None),
           "numa_node": pin["numa_node"] if pin else None, "cpus": my_cpus,
@@ -659,6 +731,11 @@ def main():
           "Mpixel_s": round(K * B * W * H / page["dt_local"] / 1e6, 1),
           "ms_per_step": round(page["dt_local"] / K * 1e3, 4),
           "Mpixel_s_pinned_ingest": round(K * B * W * H / pinn["dt_local"] / 1e6, 1),
+          # (what this rank's link carried: a slow PCIe root or a rank on the wrong NUMA node shows here)
+          "h2d_GBps": round(K * B * page["h2d"] / page["dt_local"] / 1e9, 1),
+          "h2d_GBps_pinned_ingest": round(K * B * pinn["h2d"] / pinn["dt_local"] / 1e9, 1),
+          "scan_cleanup_pinned_ingest": pinn["scan_cleanup"],
+          "cpu_ms_per_image": page["cpu_ms_per_image"],
           "images_verified": page["verified"] + pinn["verified"], "scan_cleanup": cleanup_route}
     per_rank = comm.gather(me)
     PB, B = B, args.kernel_batch       # from here on B = images per launch of the stand-alone kernel legs
@@ -829,6 +906,16 @@ def main():
                       "at N = %d if the host is the limit; same images, every output verified; pageable files go "
                       "through the input cache (hipHostRegister at first sight, inside the timed region)"
                       % (sp["as_rank_of"], sp["as_rank_of"]))
+        if proxy_concurrent:
+            pc = proxy_concurrent
+            pc["vs_value"] = {leg: round(pc[leg]["sum_Mpixel_s"] * 1e6 / rate, 3) for leg in ("pageable", "pinned")}
+            pc["note"] = ("the same %d children ALIVE AT ONCE on this one GPU, each confined to its own share of the cores "
+                          "(input cache on, first sights inside the timed regions, which the children enter together): "
+                          "sum_Mpixel_s = all their pixels / the slowest child's time - the device and the link are "
+                          "shared, so it compares with `value`, not with %d x `value`; what it adds to the single "
+                          "child: %d processes registering buffers, parsing markers and polling at once on the grant"
+                          % (pc["children"], pc["children"], pc["children"]))
+            sp["concurrent"] = pc
         out["scale_proxy"] = sp
 
     if rank == 0:

@@ -555,6 +555,15 @@ void jga_huff_set_device_shared(jga_huff_batch *b, int on);
  * bytes in `copies` copy calls (a caller that runs several batches may want their uploads to cross
  * the link one after the other: the pipeline does).  NULL clears it. */
 void jga_huff_set_upload_gate(jga_huff_batch *b, void (*fn)(void *arg, long long bytes, int copies), void *arg);
+/* With a gate set: `poll(arg)` (the gate's arg) answers "would the gate let me through now?" — non-zero: yes, and the
+ * turn is then the caller's (the gate call that follows must return at once).  prepare() with the clean-up on the
+ * device asks between copying, one by one, the files it was told to read where they lie into its pinned blob
+ * instead: a batch that waits for the link anyway then crosses it as ONE copy call at its full rate (55 GB/s; a
+ * copy call per 0.8 MB file moves ~40 from two batches side by side).  Cleared with the gate. */
+void jga_huff_set_upload_poll(jga_huff_batch *b, int (*poll)(void *arg));
+/* 1: a host core read image i's scan in the last prepare() (copied it into the pinned blob, or cleaned it up),
+ * 0: the copy engine read it where it lies, -1: no such image. */
+int  jga_huff_image_copied(const jga_huff_batch *b, int i);
 /* Returns when the last prepare()'s upload has arrived on the device. */
 int  jga_huff_wait_upload(jga_huff_batch *b);
 /* Host threads prepare() fans out over (0 = one per image, at most 64). */

@@ -312,6 +312,7 @@ struct jga_pipeline {
   // [MI355X] 1536 x 4K pageable 116 -> 131-134 Gpixel/s, lighter content 315-327 -> 373-387,
   // 1024 x 1080p 83-89 -> 106-108 (profiles/r3_link_turns.txt; JGA_PIPE_LINK_SLOTS=0: off).
   int link_slots = 2, link_free = 2;
+  bool copy_while_waiting = true;
   std::mutex link_mutex;
   std::condition_variable link_cv;
   // transport 2: the lane threads live as long as the pipeline (a run used to create its eight
@@ -543,7 +544,19 @@ struct link_turn {
   explicit link_turn(jga_pipeline *p) : pl(p) {}
   static void take_hook(void *arg, long long bytes, int copies) {
     link_turn *t = static_cast<link_turn *>(arg);
+    if (t->held) return;                                       // (the poll below already took it)
     t->take(copies == 1 && bytes >= (64ll << 20) ? t->pl->link_slots : 1);
+  }
+  // "would I get a turn now?" — takes it if so (jga_huff_set_upload_poll: a group that has to wait spends the wait
+  // copying its files into its pinned blob, and then crosses the link as one copy call)
+  static int poll_hook(void *arg) {
+    link_turn *t = static_cast<link_turn *>(arg);
+    if (t->held || t->pl->link_slots <= 0) return 1;
+    std::lock_guard<std::mutex> lk(t->pl->link_mutex);
+    if (t->pl->link_free < 1) return 0;
+    t->pl->link_free -= 1;
+    t->held = 1;
+    return 1;
   }
   void take(int units) {
     if (pl->link_slots <= 0) return;
@@ -672,6 +685,11 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   jpeg_header hdr;
   link_turn link(pl);
   jga_huff_set_upload_gate(l.hb, pl->link_slots > 0 ? &link_turn::take_hook : nullptr, &link);
+  // (short runs on a host with cores to spare: a group waiting for the link copies its files into its blob
+  // meanwhile — JGA_PIPE_COPY_WAITING=0 in the tuning build: never)
+  if (pl->link_slots > 0 && short_run && on_device && !pl->offload_cleanup && pl->copy_while_waiting) {
+    jga_huff_set_upload_poll(l.hb, &link_turn::poll_hook);
+  }
   const int prc = jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream);
   jga_huff_set_upload_gate(l.hb, nullptr, nullptr);
   if (link.held) {                                  // the upload is on its way: hold the turn until it is there
@@ -829,8 +847,9 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   for (int i = 0; i < m; i++) {
     jobv[i]->width = g.width; jobv[i]->height = g.height; jobv[i]->nplanes = g.nplanes;
     jobv[i]->h2d_bytes = up;
-    jobv[i]->host_bytes = in_place[(size_t)i] && !host_entropy ? 0 : jobv[i]->size;
-    (in_place[(size_t)i] ? pl->inputs.n_in_place : pl->inputs.n_copied)++;
+    const bool read_by_host = host_entropy || !in_place[(size_t)i] || jga_huff_image_copied(l.hb, i) == 1;
+    jobv[i]->host_bytes = read_by_host ? jobv[i]->size : 0;
+    (read_by_host ? pl->inputs.n_copied : pl->inputs.n_in_place)++;
     pl->inputs.host_bytes += jobv[i]->host_bytes;
     jobv[i]->status = (damaged && jga_huff_image_error(l.hb, i) != 0) ? EXIT_FAILURE : EXIT_SUCCESS;
   }
@@ -1024,6 +1043,7 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
       pl->inputs.cap = (size_t)(pl->cfg.input_cache_mb > 0 ? pl->cfg.input_cache_mb : 512) << 20;
       pl->inputs.sight = pl->cfg.input_cache_sight > 0 ? pl->cfg.input_cache_sight : 1;
     }
+    if (const char *e = jga_tune("JGA_PIPE_COPY_WAITING")) pl->copy_while_waiting = atoi(e) != 0;
     for (int i = 0; i < K.copy_streams; i++) {                 // (measured: profiles/r3_pipe_sweep.txt)
       hipStream_t cs = nullptr;
       if (!hip_ok(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate")) {

@@ -28,7 +28,7 @@ EXPORTED = [
     "jga_pipeline_plan_cfg", "jga_pipeline_register_input", "jga_pipeline_forget_input", "jga_pipeline_counters",
     "jga_huff_set_input_flags", "jga_huff_host_bytes", "jga_huff_set_option", "jga_plugin_configure",
     "jga_time_device_copy", "jga_time_kernel_copy",
-    "jga_huff_decode_split_begin", "jga_huff_decode_split_end", "jga_huff_qtabs_device",
+    "jga_huff_decode_split_begin", "jga_huff_decode_split_end", "jga_huff_qtabs_device", "jga_huff_set_upload_poll", "jga_huff_image_copied",
 ]
 
 

@@ -94,9 +94,10 @@ def _plugin(lib, abi, jpeg, reps):
             "note": "plugin decode_image(RGB): GPU entropy stage + fused kernel + D2H into img->pixels"}
 
 
-def _pipeline_stream(lib, abi, np, orc, jpegs, order, nthreads, group, lanes, reps=2, pinned=False):
+def _pipeline_stream(lib, abi, np, orc, jpegs, order, nthreads, group, lanes, reps=2, pinned=False, times=None):
     """`order` = indices into jpegs, one job each.  Every output is kept (slices of one device
-    buffer) and compared with the oracle's pixels of its file afterwards.  -> (best seconds, ok)."""
+    buffer) and compared with the oracle's pixels of its file afterwards.  -> (best seconds, ok);
+    `times` (a list) receives every repetition's seconds."""
     _, g = lib.geom_of(jpegs[0])
     n = len(order)
     ostride = (g.rgb_bytes + 255) // 256 * 256
@@ -113,7 +114,10 @@ def _pipeline_stream(lib, abi, np, orc, jpegs, order, nthreads, group, lanes, re
         lib.check(lib.L.jga_stream_sync(None))
         t0 = time.perf_counter()
         ok = pl.run_jobs(jobs) == 0 and ok
-        best = min(best, time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
+        best = min(best, dt)
+        if times is not None:
+            times.append(dt)
     pl.close()
     ok = ok and all(j.status == 0 for j in jobs)
     with ThreadPoolExecutor(max_workers=max(1, min(16, nthreads))) as ex:
@@ -127,6 +131,57 @@ def _pipeline_stream(lib, abi, np, orc, jpegs, order, nthreads, group, lanes, re
         for p in pins:
             p.free()
     return best, ok, sum(j.h2d_bytes for j in jobs) // n
+
+
+LINK_GBPS = 56.0          # what the host-to-device link sustains from pinned memory on these boxes (tools/h2d_probe.py)
+
+
+def _pipeline_steady(lib, abi, np, orc, jpegs, nthreads, group, lanes, seconds=0.6, pinned=False):
+    """A stream long enough for a steady state (a timed region of >= 0.5 s in ONE jga_pipeline_run), with every output
+    still checked: job i decodes file i % nfiles into slot i % R of a ring of R slots, R a multiple of nfiles, so a
+    slot only ever receives the same file and the ring's final contents are compared with the oracle's pixels."""
+    _, g = lib.geom_of(jpegs[0])
+    nf = len(jpegs)
+    px = g.width * g.height
+    ostride = (g.rgb_bytes + 255) // 256 * 256
+    ring = nf * max(1, min(256, (12 << 30) // ostride) // nf)
+    out = lib.DeviceBuffer(ostride * ring)
+    pins = [lib.PinnedBytes(j) for j in jpegs] if pinned else None
+    src = [p.array for p in pins] if pinned else jpegs
+    pl = lib.Pipeline(device=0, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False, transport=2,
+                      batch=group, depth=lanes)
+    mk = lambda n: lib.Pipeline.make_jobs([src[i % nf] for i in range(n)],
+                                          dev_outs=[out.ptr + (i % ring) * ostride for i in range(n)], pinned=pinned)
+    cal = mk(max(ring, 4 * lanes))
+    pl.run_jobs(cal)                                                 # (lanes size their buffers)
+    t0 = time.perf_counter()
+    ok = pl.run_jobs(cal) == 0
+    rate = len(cal) / (time.perf_counter() - t0)                     # images / s, short-run regime: an underestimate
+    n = int(rate * seconds * 1.6) // ring * ring + ring
+    jobs = mk(n)
+    pl.run_jobs(mk(ring))
+    lib.check(lib.L.jga_stream_sync(None))
+    t0 = time.perf_counter()
+    ok = pl.run_jobs(jobs) == 0 and ok
+    dt = time.perf_counter() - t0
+    pl.close()
+    ok = ok and all(j.status == 0 for j in jobs)
+    with ThreadPoolExecutor(max_workers=max(1, min(16, nthreads))) as ex:
+        want = list(ex.map(lambda j: orc.decode_rgb(j)[1].reshape(-1), jpegs))
+    for k in range(ring):
+        if not ok:
+            break
+        ok = bool(np.array_equal(out.download(g.rgb_bytes, offset=k * ostride), want[k % nf]))
+    out.free()
+    if pins:
+        for p in pins:
+            p.free()
+    h2d = sum(j.h2d_bytes for j in jobs) / n
+    ceiling = LINK_GBPS * 1e9 / (h2d / px) / 1e6                     # Mpixel/s the link allows at this many bytes per pixel
+    return {"images": n, "seconds": round(dt, 3), "Mpixel_s": round(n * px / dt / 1e6, 1),
+            "h2d_GBps": round(n * h2d / dt / 1e9, 1), "h2d_bytes_per_pixel": round(h2d / px, 4),
+            "link_ceiling_Mpixel_s": round(ceiling, 1), "of_link_ceiling": round(n * px / dt / 1e6 / ceiling, 3),
+            "outputs_checked": ring, "bit_exact_vs_oracle": ok}
 
 
 def _pipeline_latency(lib, abi, jpeg, nthreads, reps=8):
@@ -180,10 +235,15 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
         lat = _pipeline_latency(lib, abi, files[0], nthreads)
         order = [i % n_files for i in range(stream_n)]
         dt, ok, h2d = _pipeline_stream(lib, abi, np, orc, files, order, nthreads, group, lanes)
+        steady = _pipeline_steady(lib, abi, np, orc, files, nthreads, group, lanes, seconds=0.15 if quick else 0.6)
+        ok = ok and steady["bit_exact_vs_oracle"]
         e = {"what": what, "file_bytes": len(files[0]),
              "to_rgb_hbm": {"latency_ms": round(lat * 1e3, 3), "latency_Mpixel_s": round(px / lat / 1e6, 1),
                             "stream_images": stream_n, "Mpixel_s": round(stream_n * px / dt / 1e6, 1),
-                            "h2d_bytes_per_image": int(h2d)},
+                            "h2d_bytes_per_image": int(h2d),
+                            # (the figure above is a SHORT job: a few groups per lane, latency-bound; this one a
+                            # timed region of >= 0.5 s)
+                            "steady": steady},
              "to_host_pixels": _plugin(lib, abi, files[0], 3 if quick else 10),
              "device": dict(_kernel_alone(lib, np, files, kernel_n, 5 if quick else 20),
                             one_frame=_device_only(lib, files, 1, 2 if quick else 5)),
@@ -231,12 +291,18 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
     for name, order in (("all_%d_on_one_gpu" % n4, list(range(n4))),
                         ("rank3_shard_of_8", list(shard.shard_range(n4, 3, 8)))):
         for kind, pinned in (("pageable_files", False), ("pinned_files", True)):
+            ts = []
+            # (a short job's time moves by +-10 % from run to run: the shard is timed 15 times and the MEDIAN quoted
+            # — `ms` — with the best beside it; rounds 1-4 quoted the best of three)
             dt, ok, h2d = _pipeline_stream(lib, abi, np, orc, files, [i % distinct for i in order], nthreads,
-                                           group, lanes, reps=3, pinned=pinned)
+                                           group, lanes, reps=3 if len(order) > 256 or quick else 15, pinned=pinned, times=ts)
+            ts.sort()
+            med = ts[len(ts) // 2]
             oks.append(ok)
             e4.setdefault("to_rgb_hbm", {}).setdefault(name, {})[kind] = {
-                "images": len(order), "ms": round(dt * 1e3, 2),
-                "Mpixel_s": round(len(order) * px / dt / 1e6, 1), "h2d_bytes_per_image": int(h2d)}
+                "images": len(order), "ms": round(med * 1e3, 2), "ms_best": round(dt * 1e3, 2), "runs": len(ts),
+                "Mpixel_s": round(len(order) * px / med / 1e6, 1), "h2d_bytes_per_image": int(h2d),
+                "h2d_GBps": round(len(order) * h2d / med / 1e9, 1)}
     e4["to_host_pixels"] = _plugin(lib, abi, files[0], 3 if quick else 10)
     e4["device"] = dict(_kernel_alone(lib, np, files, n4, 3 if quick else 5),
                         whole_batch=_device_only(lib, files, n4, 1 if quick else 3),
