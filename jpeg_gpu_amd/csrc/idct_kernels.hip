@@ -741,7 +741,16 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
   }
   float z[64], t[64];
   row_pass_ldsq<DEQUANT>(rows, qlds + pl*8, z);
-  (void)col_pass(z, t);
+  const float tmax = col_pass(z, t);
+  // Clamping to [-128,127] (the level shift's clamp) is the identity unless some sample overshoots: decided once per
+  // wave — 64 blocks — and done IN PLACE, all 64 values of the lane under one wave-uniform branch (a test around
+  // each group of four published values used to be turned into med3 + select by the compiler: two instructions
+  // per value instead of none), so that the publishing below is the same code either way.  The kernel runs on
+  // its VALU issue rate (1 372 instructions per wave, profiles/r5_kernel_budgets.md): these 64 are 4.7 % of it.
+  if (__builtin_amdgcn_ballot_w64(tmax > 127.0f) != 0ull) {
+#pragma unroll
+    for (int n = 0; n < 64; n++) t[n] = __builtin_amdgcn_fmed3f(t[n], -128.0f, 127.0f);
+  }
 
   // the unit this lane converts in every phase: luma block uidx, row urr of the phase
   const int u = threadIdx.x;
@@ -764,7 +773,7 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
 
 #pragma unroll
   for (int p = 0; p < rc::NPH; p++) {
-    // publish (clamped like clamp255(s+128)-128)
+    // publish (clamped above like clamp255(s+128)-128)
     if (is_luma) {
 #pragma unroll
       for (int rr = 0; rr < rc::PR; rr++) {
@@ -775,12 +784,6 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
           for (int h = 0; h < 8; h += 4) {
             v4f v;
             v.x = t[r*8 + h]; v.y = t[r*8 + h + 1]; v.z = t[r*8 + h + 2]; v.w = t[r*8 + h + 3];
-            // (always: a wave-uniform "does anybody overshoot?" test around these four turns into
-            // med3 + select, two instructions per value instead of one)
-            v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
-            v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
-            v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
-            v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
             *reinterpret_cast<v4f *>(dst + h) = v;
           }
         }
@@ -797,12 +800,6 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
           for (int h = 0; h < 8; h += 4) {
             v4f v;
             v.x = t[crow*8 + h]; v.y = t[crow*8 + h + 1]; v.z = t[crow*8 + h + 2]; v.w = t[crow*8 + h + 3];
-            // (always: a wave-uniform "does anybody overshoot?" test around these four turns into
-            // med3 + select, two instructions per value instead of one)
-            v.x = __builtin_amdgcn_fmed3f(v.x, -128.0f, 127.0f);
-            v.y = __builtin_amdgcn_fmed3f(v.y, -128.0f, 127.0f);
-            v.z = __builtin_amdgcn_fmed3f(v.z, -128.0f, 127.0f);
-            v.w = __builtin_amdgcn_fmed3f(v.w, -128.0f, 127.0f);
             *reinterpret_cast<v4f *>(dst + h) = v;
           }
         }

@@ -136,7 +136,7 @@ def _pipeline_stream(lib, abi, np, orc, jpegs, order, nthreads, group, lanes, re
 LINK_GBPS = 56.0          # what the host-to-device link sustains from pinned memory on these boxes (tools/h2d_probe.py)
 
 
-def _pipeline_steady(lib, abi, np, orc, jpegs, nthreads, group, lanes, seconds=0.6, pinned=False):
+def _pipeline_steady(lib, abi, np, orc, jpegs, nthreads, group, lanes, seconds=0.6, pinned=False, keep=True):
     """A stream long enough for a steady state (a timed region of >= 0.5 s in ONE jga_pipeline_run), with every output
     still checked: job i decodes file i % nfiles into slot i % R of a ring of R slots, R a multiple of nfiles, so a
     slot only ever receives the same file and the ring's final contents are compared with the oracle's pixels."""
@@ -151,7 +151,8 @@ def _pipeline_steady(lib, abi, np, orc, jpegs, nthreads, group, lanes, seconds=0
     pl = lib.Pipeline(device=0, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False, transport=2,
                       batch=group, depth=lanes)
     mk = lambda n: lib.Pipeline.make_jobs([src[i % nf] for i in range(n)],
-                                          dev_outs=[out.ptr + (i % ring) * ostride for i in range(n)], pinned=pinned)
+                                          dev_outs=[out.ptr + (i % ring) * ostride for i in range(n)] if keep else None,
+                                          pinned=pinned)
     cal = mk(max(ring, 4 * lanes))
     pl.run_jobs(cal)                                                 # (lanes size their buffers)
     t0 = time.perf_counter()
@@ -159,7 +160,10 @@ def _pipeline_steady(lib, abi, np, orc, jpegs, nthreads, group, lanes, seconds=0
     rate = len(cal) / (time.perf_counter() - t0)                     # images / s, short-run regime: an underestimate
     n = int(rate * seconds * 1.6) // ring * ring + ring
     jobs = mk(n)
-    pl.run_jobs(mk(ring))
+    # (the same job list once untimed: a LONG run sizes every lane's buffers for full groups — pinned blobs of
+    # ~200 MB per lane, a few tenths of a second of page pinning the first time — where the short calibration runs
+    # above only sized them for theirs)
+    ok = pl.run_jobs(jobs) == 0 and ok
     lib.check(lib.L.jga_stream_sync(None))
     t0 = time.perf_counter()
     ok = pl.run_jobs(jobs) == 0 and ok
@@ -168,7 +172,7 @@ def _pipeline_steady(lib, abi, np, orc, jpegs, nthreads, group, lanes, seconds=0
     ok = ok and all(j.status == 0 for j in jobs)
     with ThreadPoolExecutor(max_workers=max(1, min(16, nthreads))) as ex:
         want = list(ex.map(lambda j: orc.decode_rgb(j)[1].reshape(-1), jpegs))
-    for k in range(ring):
+    for k in range(ring if keep else 0):
         if not ok:
             break
         ok = bool(np.array_equal(out.download(g.rgb_bytes, offset=k * ostride), want[k % nf]))
