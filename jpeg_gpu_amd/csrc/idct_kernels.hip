@@ -687,6 +687,13 @@ struct rows_cfg {
   static constexpr int NPH = (8 + PR - 1)/PR;                // phases
   static constexpr int CSLOTS = YDEC ? tile::LH : PR;        // chroma rows published per phase and component
   static constexpr bool STAGED = tile::ROWLEN % 64 == 0;
+  // float offset of half `hh` (4 samples) of chroma block `cb`'s published row `row` (= comp*CSLOTS + slot): where
+  // a luma block takes a whole chroma row (no horizontal decimation) consecutive lanes read consecutive chroma
+  // blocks — two planes of half rows; where two luma blocks share one, consecutive lanes read its two halves —
+  // whole rows, as the tile kernel keeps them
+  static __device__ __forceinline__ int chroma_at(int row, int cb, int hh) {
+    return XDEC == 0 ? ((row*2 + hh)*tile::TILE + cb)*4 : (row*tile::TILE + cb)*8 + hh*4;
+  }
   static_assert(PR*tile::NLB == tile::THREADS, "one unit per lane and phase");
   static_assert(tile::NLB % 64 == 0, "a wave converts one row index");
 };
@@ -696,8 +703,13 @@ __global__ __launch_bounds__((rgb_cfg<XDEC, YDEC>::THREADS))
 void jga_idct_rgb_rows_kernel(const jga_kparams P) {
   typedef rgb_cfg<XDEC, YDEC> cfg;
   typedef rows_cfg<XDEC, YDEC> rc;
-  __shared__ __attribute__((aligned(16))) float ypub[rc::PR*cfg::NLB*8];              // [row in phase][luma block][8]
-  __shared__ __attribute__((aligned(16))) float cpub[2*rc::CSLOTS*cfg::TILE*8];       // [comp][slot][chroma block][8]
+  // published rows, as two planes of HALF rows — [row in phase][half][luma block][4], and for the chroma rows
+  // rows_cfg::chroma_at — so that the 64 lanes of a ds_write_b128 / ds_read_b128 touch 64 consecutive 16-byte chunks
+  // (whole rows at a 32-byte lane stride used half the banks per pass: 3.0e7 conflict cycles per 24 frames against
+  // 2.1e7 cycles of LDS instructions; now 0: -1.7 % at 4:4:4, profiles/r5_kernel_budgets.md.  The same re-layout of
+  // the tile kernel's hand-off halved ITS conflicts and bought nothing: not kept.)
+  __shared__ __attribute__((aligned(16))) float ypub[rc::PR*cfg::NLB*8];
+  __shared__ __attribute__((aligned(16))) float cpub[2*rc::CSLOTS*cfg::TILE*8];
   __shared__ uint4 qlds[24];
   __shared__ __attribute__((aligned(16))) uint32_t stage_mem[rc::STAGED ? cfg::NLW + cfg::NCW : 1][384];
   const int lane = threadIdx.x & 63;
@@ -779,12 +791,11 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
       for (int rr = 0; rr < rc::PR; rr++) {
         const int r = p*rc::PR + rr;
         if (r < 8) {
-          float *dst = ypub + (rr*cfg::NLB + myidx)*8;
 #pragma unroll
           for (int h = 0; h < 8; h += 4) {
             v4f v;
             v.x = t[r*8 + h]; v.y = t[r*8 + h + 1]; v.z = t[r*8 + h + 2]; v.w = t[r*8 + h + 3];
-            *reinterpret_cast<v4f *>(dst + h) = v;
+            *reinterpret_cast<v4f *>(ypub + ((rr*2 + (h >> 2))*cfg::NLB + myidx)*4) = v;
           }
         }
       }
@@ -795,12 +806,11 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
         // chroma row that goes with luma row p*PR + rr of block row suby: (suby*8 + p*PR + rr) >> YDEC
         const int crow = YDEC ? sl*4 + p : p*rc::PR + sl;
         if (crow < 8) {
-          float *dst = cpub + ((comp*rc::CSLOTS + sl)*cfg::TILE + cb)*8;
 #pragma unroll
           for (int h = 0; h < 8; h += 4) {
             v4f v;
             v.x = t[crow*8 + h]; v.y = t[crow*8 + h + 1]; v.z = t[crow*8 + h + 2]; v.w = t[crow*8 + h + 3];
-            *reinterpret_cast<v4f *>(dst + h) = v;
+            *reinterpret_cast<v4f *>(cpub + rc::chroma_at(comp*rc::CSLOTS + sl, cb, h >> 2)) = v;
           }
         }
       }
@@ -808,15 +818,16 @@ void jga_idct_rgb_rows_kernel(const jga_kparams P) {
     __syncthreads();
     const int k = p*rc::PR + urr;                    // pixel row inside the luma block (wave-uniform)
     if (k < 8) {
-      const v4f *ys = reinterpret_cast<const v4f *>(ypub + (urr*cfg::NLB + uidx)*8);
-      const v4f y0 = ys[0], y1 = ys[1];
+      const v4f y0 = *reinterpret_cast<const v4f *>(ypub + ((urr*2 + 0)*cfg::NLB + uidx)*4);
+      const v4f y1 = *reinterpret_cast<const v4f *>(ypub + ((urr*2 + 1)*cfg::NLB + uidx)*4);
       const float y8[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-      const float *ub = cpub + ((0*rc::CSLOTS + uslot)*cfg::TILE + ucb)*8 + usubx*cfg::CW;
-      const float *vb = cpub + ((1*rc::CSLOTS + uslot)*cfg::TILE + ucb)*8 + usubx*cfg::CW;
+      // the CW chroma samples of this luma block's row: samples [usubx*CW, usubx*CW + CW) of chroma block ucb's row
       float u8[cfg::CW], v8[cfg::CW];
 #pragma unroll
       for (int c = 0; c < cfg::CW; c += 4) {
-        const v4f a = *reinterpret_cast<const v4f *>(ub + c), b = *reinterpret_cast<const v4f *>(vb + c);
+        const int hh = (usubx*cfg::CW + c) >> 2;
+        const v4f a = *reinterpret_cast<const v4f *>(cpub + rc::chroma_at(0*rc::CSLOTS + uslot, ucb, hh));
+        const v4f b = *reinterpret_cast<const v4f *>(cpub + rc::chroma_at(1*rc::CSLOTS + uslot, ucb, hh));
         u8[c] = a.x; u8[c + 1] = a.y; u8[c + 2] = a.z; u8[c + 3] = a.w;
         v8[c] = b.x; v8[c + 1] = b.y; v8[c + 2] = b.z; v8[c + 3] = b.w;
       }
