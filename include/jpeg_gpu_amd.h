@@ -459,19 +459,21 @@ int  jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n);
  * Host logic only (no device is touched): same-geometry jobs in arrival order, groups sized by pixels,
  * short jobs cut finer, a long job's first groups rising in size. */
 int  jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int n, int *group_of);
-/* The same for a whole configuration (depth, batch, groups_per_lane, min_group, ramp_first): exactly the
- * plan jga_pipeline_run() of a pipeline created from `cfg` makes. */
+/* The same for a whole configuration (its depth and batch): exactly the plan jga_pipeline_run() of a pipeline
+ * created from `cfg` makes. */
 int  jga_pipeline_plan_cfg(const jga_pipeline_config *cfg, const jga_job *jobs, int n, int *group_of);
-/* input_cache_mb > 0: register [jpeg, jpeg + size) now (a reader that fills its ingest buffers before the
- * first run) / drop it from the cache (before the caller frees or re-uses the memory).  Both return
- * EXIT_SUCCESS or EXIT_FAILURE; forgetting a buffer the cache does not hold is not an error. */
+/* The input cache (on unless input_cache_mb < 0): register [jpeg, jpeg + size) now (a reader that fills its ingest
+ * buffers before the first run) / drop it from the cache at once (optional: a stale entry is found by its
+ * fingerprint anyway; this unpins the pages now instead of at eviction).  Both return EXIT_SUCCESS or EXIT_FAILURE;
+ * forgetting a buffer the cache does not hold is not an error. */
 int  jga_pipeline_register_input(jga_pipeline *pl, const unsigned char *jpeg, int size);
 int  jga_pipeline_forget_input(jga_pipeline *pl, const unsigned char *jpeg);
 /* Counters of the pipeline since it was created: [0] buffers registered, [1] MB registered now, [2] jobs whose
- * scan was DMA'd where it lay, [3] jobs whose scan a host core copied or cleaned up, [4] registrations
- * evicted, [5] microseconds spent in hipHostRegister, [6] where the scan clean-up runs (0 host, 1 device: what
- * unstuff = 0 came to), [7] bytes of callers' files read by host cores.  Fills at most n entries, returns how
- * many exist. */
+ * scan the copy engine read where it lay, [3] jobs whose scan a host core copied or cleaned up, [4] registrations
+ * evicted, [5] microseconds spent in hipHostRegister, [6] where the scan clean-up of a long run takes place (0 host,
+ * 1 device: what unstuff = 0 came to), [7] bytes of callers' files read by host cores, [8] registrations dropped
+ * because the buffer's contents were no longer the file they were made for (the fingerprint check).  Fills at most n
+ * entries, returns how many exist. */
 int  jga_pipeline_counters(const jga_pipeline *pl, long long *out, int n);
 void jga_pipeline_destroy(jga_pipeline *pl);
 
