@@ -29,8 +29,13 @@ Rank 0 prints ONE JSON line.  Beside the contract keys:
                 algorithmic bytes / launch time from HIP events on the launch stream
                 (`kernel_Mpixel_s` is that kernel's pixel rate — NOT the end-to-end value);
                 `traffic` from rocprofv3 --pmc child passes of this run when the tool is here
-  per_rank      every rank's own rate, GPU, NUMA node, CPUs and scan clean-up route (+ min / max)
-  configs       (N = 1) every BASELINE.json config beside its CPU path (tools/configs_bench.py)
+  per_rank      every rank's own rate, GPU, NUMA node, CPUs, scan clean-up route, H2D GB/s and CPU ms per
+                image (+ min / max)
+  scale_proxy   (N = 1) the headline repeated by a child confined to the CPUs ONE rank of 8 gets, and
+                `concurrent`: eight such children alive at once on the one GPU, each on its own CPUs
+  configs       (N = 1) every BASELINE.json config beside its CPU path (tools/configs_bench.py): one-frame
+                latency, a short job's rate, a steady state of >= 0.5 s with its share of the link's
+                ceiling; config 4's shard as median and best of 15 runs
   e2e           the same end-to-end measurement with the other transports: the north-star
                 design (host Huffman threads + pinned hipMemcpyAsync + kernel), with the pixels
                 copied back to host RAM, PACK words over PCIe
