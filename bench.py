@@ -914,12 +914,21 @@ def main():
         if proxy_concurrent:
             pc = proxy_concurrent
             pc["vs_value"] = {leg: round(pc[leg]["sum_Mpixel_s"] * 1e6 / rate, 3) for leg in ("pageable", "pinned")}
+            # what the host side would have to give N ranks that each run at `value`: the slowest child's CPU time
+            # per image x `value`'s images per second x N, against the grant
+            per_s = rate / world / (W * H)
+            pc["host_cpus_needed_at_value"] = {
+                leg: round(pc["children"] * per_s * pc[leg]["cpu_ms_per_image_min_max"][1] / 1e3, 1) for leg in ("pageable", "pinned")}
+            pc["host_cpus_granted"] = quota if quota else len(orig_cpus)
             pc["note"] = ("the same %d children ALIVE AT ONCE on this one GPU, each confined to its own share of the cores "
                           "(input cache on, first sights inside the timed regions, which the children enter together): "
                           "sum_Mpixel_s = all their pixels / the slowest child's time - the device and the link are "
-                          "shared, so it compares with `value`, not with %d x `value`; what it adds to the single "
-                          "child: %d processes registering buffers, parsing markers and polling at once on the grant"
-                          % (pc["children"], pc["children"], pc["children"]))
+                          "shared, so it compares with `value`, not with %d x `value` - and %d PROCESSES time-slice the one device "
+                          "(their kernels do not overlap the way one process's lanes do), which is why the sum stays below "
+                          "`value` however idle the host is; what it adds to the single child: %d processes registering "
+                          "buffers, parsing markers and polling at once on the grant - `host_cpus_needed_at_value` = the CPUs "
+                          "that many ranks at full rate would keep busy at the slowest child's CPU time per image"
+                          % (pc["children"], pc["children"], pc["children"], pc["children"]))
             sp["concurrent"] = pc
         out["scale_proxy"] = sp
 
