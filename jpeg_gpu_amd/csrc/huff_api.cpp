@@ -74,6 +74,8 @@ struct jga_huff_batch {
   hipEvent_t arrived;          // the event that says "the last prepare()'s bytes are on the device"
   bool qtab_on_device;         // the last prepare() put the quantisers into the blob (jga_huff_qtabs_device)
   size_t off_qtab;
+  bool wide;                   // the last prepare() built and uploaded the 12-bit AC tables (a small batch on a device of its own)
+  size_t off_wide;
   // a decode in two halves (jga_huff_decode_split_begin / _end): what _begin queued
   struct {
     bool active, with_tail;
@@ -115,6 +117,14 @@ static bool same_geometry(const jga_geom &a, const jga_geom &b) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1)/a*a; }
 
+// The 12-bit AC tables (hj_wide_ac, huff_common.h) are for batches that leave most of the device empty and have it
+// to themselves: a few images whose first round is at most one workgroup per CU (82 KB of LDS each).
+#define HJ_WIDE_MAX_IMAGES 4
+static bool wants_wide(const jga_huff_batch *b, int n, uint64_t scan_bytes, int sub_log2) {
+  if (b->device_shared || n > HJ_WIDE_MAX_IMAGES || jga_tune("JGA_HUFF_NO_WIDE")) return false;
+  return (scan_bytes >> sub_log2) + 256u*(uint64_t)n <= 256u*256u;     // <= 256 workgroups of 256 subsequences: one per CU
+}
+
 extern "C" {
 
 JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_bytes) {
@@ -134,7 +144,7 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
   b->blob_cap = align_up(sizeof(hj_image)*max_images, 256) + align_up(sizeof(hj_segment)*seg_cap, 256)
    + align_up(4*b->sub_cap, 256) + align_up(sizeof(hj_tables)*max_images, 256)
    + align_up(8*(b->sub_cap + seg_cap), 256) + align_up((size_t)max_scan_bytes + 64*max_images, 256)
-   + align_up(384*(size_t)max_images, 256);
+   + align_up(384*(size_t)max_images, 256) + align_up(sizeof(hj_wide_ac)*HJ_WIDE_MAX_IMAGES, 256);
   bool ok = hipHostMalloc((void **)&b->h_blob, b->blob_cap, hipHostMallocDefault) == hipSuccess
    && hipMalloc((void **)&b->d_blob, b->blob_cap) == hipSuccess
    && hipMalloc((void **)&b->d_last_in, 8*b->sub_cap) == hipSuccess
@@ -227,13 +237,14 @@ struct phase_barrier {
 }  // namespace
 
 
-// The launch arguments of the synchronisation rounds (what a decode and a piece's early start share).
+// The launch arguments of the synchronisation rounds.
 static void fill_sync_args(const jga_huff_batch *b, hj_args &A) {
   memset(&A, 0, sizeof(A));
   A.images = (const hj_image *)(b->d_blob + b->off_images);
   A.segs = (const hj_segment *)(b->d_blob + b->off_segs);
   A.sub_seg = (const uint32_t *)(b->d_blob + b->off_subseg);
   A.tables = (const hj_tables *)(b->d_blob + b->off_tables);
+  A.wide = b->wide ? (const hj_wide_ac *)(b->d_blob + b->off_wide) : NULL;
   A.scan = b->d_blob + b->off_scan;
   A.S = (uint64_t *)(b->d_blob + b->off_S);
   A.last_in = b->d_last_in;
@@ -337,6 +348,8 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     uint64_t raw_total = 0;
     for (int i = 0; i < n; i++) raw_total += prep[i].avail;
     b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(raw_total, prep[0].im.nslots, prep[0].geom.restart_interval);
+    b->wide = wants_wide(b, n, raw_total, b->sub_log2);
+    for (int i = 0; i < n && b->wide; i++) hj_prepare_wide(&prep[i]);
   }
   std::vector<hj_unstuff_image> uimg((size_t)n);
   std::vector<uint32_t> sub0v((size_t)n), seg0v((size_t)n);
@@ -379,6 +392,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->off_info = q; q += align_up(sizeof(hj_unstuff_info)*n, 256);
   b->off_perr = q; q += align_up(4*(size_t)n, 256);
   b->off_qtab = q; q += align_up(384*(size_t)n, 256);
+  b->off_wide = q; q += b->wide ? align_up(sizeof(hj_wide_ac)*(size_t)n, 256) : 0;
   b->upload_size = q;                                        // what crosses PCIe
   b->off_scan = q; q += raw_bytes;                           // the clean streams, same offsets as the raw ones
   b->off_segs = q; q += align_up(sizeof(hj_segment)*total_seg, 256);
@@ -437,6 +451,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
       p.im.scan_len = 0;
       images[i] = p.im;
       tables[i] = p.tabs;
+      if (b->wide) memcpy(b->h_blob + b->off_wide + sizeof(hj_wide_ac)*(size_t)i, p.wide.data(), sizeof(hj_wide_ac));
       memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
     }
   };
@@ -513,6 +528,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
   b->unstuffed_on_device = 0;
   b->host_bytes = 0;
   b->qtab_on_device = false;
+  b->wide = false;
   const auto t_p0 = std::chrono::steady_clock::now();
   std::vector<hj_prepared> prep((size_t)n);
   std::vector<uint32_t> scan_off((size_t)n), sub0v((size_t)n), seg0v((size_t)n);
@@ -552,6 +568,8 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       // subsequence length of this batch (the stuffed length is close enough to the clean one)
       b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o, prep[0].im.nslots, prep[0].geom.restart_interval);
       for (int i = 0; i < n; i++) prep[i].sub_log2 = b->sub_log2;
+      b->wide = wants_wide(b, n, o, b->sub_log2);
+      for (int i = 0; i < n && b->wide; i++) hj_prepare_wide(&prep[i]);
       b->off_scan = 0;
       b->scan_bytes = align_up(o, 256);
       if (fatal.load()) stop.store(1);
@@ -594,6 +612,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
       b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
       b->off_qtab = o; o += align_up(384*(size_t)n, 256);
+      b->off_wide = o; o += b->wide ? align_up(sizeof(hj_wide_ac)*(size_t)n, 256) : 0;
       b->upload_size = o;           // what crosses PCIe; the rest is written by hj_init_states
       b->off_subseg = o; o += align_up(4*total_sub, 256);
       b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
@@ -618,6 +637,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       p.im.scan_off = scan_off[i];
       images[i] = p.im;
       tables[i] = p.tabs;
+      if (b->wide) memcpy(b->h_blob + b->off_wide + sizeof(hj_wide_ac)*(size_t)i, p.wide.data(), sizeof(hj_wide_ac));
       memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
       for (size_t si = 0; si < p.segs.size(); si++) segs[seg0 + si] = p.segs[si];
     }

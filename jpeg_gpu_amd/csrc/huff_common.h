@@ -173,6 +173,7 @@ struct hj_reader {
   }
   HJ_HD bool before_stop() const { return p < stop; }
   HJ_HD bool room9() const { return p + 9u <= stop; }                     // nine more bits end at or before the stop
+  HJ_HD bool room(int n) const { return p + (uint32_t)n <= stop; }
   HJ_HD uint32_t window() const { return src.window32(p); }
   HJ_HD void skip(int n) { p += (uint32_t)n; }
   HJ_HD uint64_t tell() const { return p; }
@@ -200,6 +201,37 @@ struct hj_ltables {
   uint32_t tab[4][1 << HJ_FAST_BITS];        // dc[0], dc[1], ac[0], ac[1]
   uint16_t l2[HJ_L2_BLOCKS*128];
 };
+// WIDE packs (round 5), for batches that leave most of the device empty — a lone frame waits for nine runs one
+// after the other at the speed of ONE lane, so what counts there is symbols per step, not LDS per workgroup: the AC
+// tables are indexed with the next 12 bits and their packs hold what those hold — 1.89 whole symbols per step on the
+// bench's frames instead of 1.42 (counted: tools/archive/r5_packsim.py), a quarter fewer steps per run.  32 KB per
+// image on top of hj_tables (built by the host, hj_prepare_head), 40 KB in LDS as hj_ltables_wide: one or two
+// workgroups per CU instead of three, which is why batches that fill the device keep the 9-bit tables.  A pack is
+// taken under the same two conditions as ever (no symbol but the last completes the block; all of it lies before
+// the run's stop — the loops now ask for HJ_WIDE_BITS bits of room), so a run ends in the same state whichever
+// tables decoded it: the host's walk over unsettled stretches (hj_walk_unsettled, 9-bit tables) and the write pass
+// need not know.
+#define HJ_WIDE_BITS 12
+struct hj_wide_ac {
+  uint32_t ac[2][1 << HJ_WIDE_BITS];         // low half: the ENTRY of the first symbol (= hj_tables::ac[..][index >> 3]), high half: the PACK
+};
+struct hj_ltables_wide {
+  uint32_t dc[2][1 << HJ_FAST_BITS];
+  uint32_t ac[2][1 << HJ_WIDE_BITS];
+  uint16_t l2[HJ_L2_BLOCKS*128];
+};
+static_assert(sizeof(hj_ltables_wide) == 4u*((2u << HJ_FAST_BITS) + (2u << HJ_WIDE_BITS)) + 2u*HJ_L2_BLOCKS*128u, "dc and ac back to back");
+// bits of look-ahead a table's packs may take: what a run asks for before it takes one whole
+template <class Tab> struct hj_pack_bits { static constexpr int value = HJ_FAST_BITS; };
+template <> struct hj_pack_bits<hj_ltables_wide> { static constexpr int value = HJ_WIDE_BITS; };
+HJ_HD uint32_t hj_lookup(const hj_ltables_wide *T, int isdc, int tbl, uint32_t w) {
+  // (dc and ac lie back to back: one read from a selected index)
+  const uint32_t idx = isdc ? ((uint32_t)(tbl & 1) << HJ_FAST_BITS) | (w >> (32 - HJ_FAST_BITS))
+   : (2u << HJ_FAST_BITS) + (((uint32_t)(tbl >> 1) << HJ_WIDE_BITS) | (w >> (32 - HJ_WIDE_BITS)));
+  uint32_t e = (&T->dc[0][0])[idx];
+  if ((e & 31u) == 0u) e = T->l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+  return e;
+}
 HJ_HD uint32_t hj_lookup(const hj_ltables *T, int isdc, int tbl, uint32_t w) {
   const uint32_t t = isdc ? (uint32_t)(tbl & 1) : 2u + (uint32_t)(tbl >> 1);
   uint32_t e = (&T->tab[0][0])[(t << HJ_FAST_BITS) | (w >> (32 - HJ_FAST_BITS))];
@@ -264,7 +296,7 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
     // the run: a run ends at the FIRST symbol boundary at or past its stop bit whichever way it
     // got there (runs that have fallen into step must hand on identical states), so a pack is
     // only taken whole if all of it lies before the stop
-    const bool packed = HJ_P_BITS(e) != 0 && k + HJ_P_PREFIX(e) < 64 && br.room9();
+    const bool packed = HJ_P_BITS(e) != 0 && k + HJ_P_PREFIX(e) < 64 && br.room(hj_pack_bits<Tab>::value);
     br.skip(packed ? HJ_P_BITS(e) : HJ_E_TOT(e));
     const int kn = k + (packed ? HJ_P_ADV(e) : HJ_E_ADV(e));   // DC: 1; AC: past the run(s); EOB: >= 64
     const int done = kn >= 64;

@@ -11,6 +11,7 @@ typedef struct hj_args {
   const hj_segment *segs;      /* all images' segments, image-major */
   const uint32_t *sub_seg;     /* per subsequence: segment index local to its image */
   const hj_tables *tables;     /* [nimages] */
+  const hj_wide_ac *wide;      /* [nimages] 12-bit AC tables, or NULL: the dense rounds then run with the 9-bit ones */
   const uint8_t *scan;         /* all images' entropy-coded bytes */
   uint64_t *S;                 /* states: nsub + nseg entries per image */
   uint64_t *last_in;           /* start state of each lane's latest run */

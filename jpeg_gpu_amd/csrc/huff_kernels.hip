@@ -69,6 +69,7 @@ struct hj_lds_src {
     }
     __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
     __device__ __forceinline__ bool room9() const { return r1 + 9 <= stop1; }
+    __device__ __forceinline__ bool room(int n) const { return r1 + n <= stop1; }
     __device__ __forceinline__ uint32_t window() const {
       const uint32_t *q = base + (r1 >> 5);                  // r1 = -1: the dword before (unused bits)
       return __builtin_amdgcn_alignbit(q[0], q[1], ~(uint32_t)r1);
@@ -102,6 +103,7 @@ struct hj_lds_reg_src {
     }
     __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
     __device__ __forceinline__ bool room9() const { return r1 + 9 <= stop1; }
+    __device__ __forceinline__ bool room(int n) const { return r1 + n <= stop1; }
     __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w0, w1, ~(uint32_t)r1); }
     __device__ __forceinline__ void skip(int n) {
       r1 += n;
@@ -147,6 +149,7 @@ struct hj_gmem_src {
     }
     __device__ __forceinline__ bool before_stop() const { return r1 < stop1; }
     __device__ __forceinline__ bool room9() const { return r1 + 9 <= stop1; }
+    __device__ __forceinline__ bool room(int n) const { return r1 + n <= stop1; }
     __device__ __forceinline__ uint32_t window() const { return __builtin_amdgcn_alignbit(w0, w1, ~(uint32_t)r1); }
     __device__ __forceinline__ void skip(int n) {
       r1 += n;
@@ -192,9 +195,25 @@ static __device__ __forceinline__ void hj_stage_tables(hj_ltables *dst, const hj
   for (int k = threadIdx.x; k < (int)(sizeof(src->l2)/16); k += NB) l2d[k] = l2s[k];
 }
 
-template <bool STAGE_ROWS = true, int NB = HJ_BLOCK>
+// hj_tables + the image's wide AC tables (hj_wide_ac) -> hj_ltables_wide in LDS: 40 KB, sixteen bytes per lane and trip
+template <int NB>
+static __device__ __forceinline__ void hj_stage_tables(hj_ltables_wide *dst, const hj_tables *src, const hj_wide_ac *wide) {
+  for (int k = threadIdx.x; k < 2 << HJ_FAST_BITS; k += NB) (&dst->dc[0][0])[k] = (&src->dc[0][0])[k];
+  const uint4 *ws = reinterpret_cast<const uint4 *>(wide->ac);
+  uint4 *wd = reinterpret_cast<uint4 *>(dst->ac);
+  for (int k = threadIdx.x; k < (int)(sizeof(wide->ac)/16); k += NB) wd[k] = ws[k];
+  const uint4 *l2s = reinterpret_cast<const uint4 *>(src->l2);
+  uint4 *l2d = reinterpret_cast<uint4 *>(dst->l2);
+  for (int k = threadIdx.x; k < (int)(sizeof(src->l2)/16); k += NB) l2d[k] = l2s[k];
+}
+template <int NB>
+static __device__ __forceinline__ void hj_stage_tables(hj_ltables *dst, const hj_tables *src, const hj_wide_ac *) {
+  hj_stage_tables<NB>(dst, src);
+}
+
+template <bool STAGE_ROWS = true, int NB = HJ_BLOCK, class Tab = hj_ltables>
 static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_image &im,
- hj_ltables *lds_tabs, uint32_t *lds_win, uint16_t *lds_start, uint32_t *lds_start0, hj_lane_ctx &L) {
+ Tab *lds_tabs, uint32_t *lds_win, uint16_t *lds_start, uint32_t *lds_start0, hj_lane_ctx &L) {
   const uint32_t li = blockIdx.x*NB + threadIdx.x;
   const bool in_range = li < im.nsub;
   L.g = 0; L.si = 0; L.i = 0; L.stop_byte = 0;
@@ -215,7 +234,7 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
   // LDS this saves keep the round at three workgroups per CU)
   const uint32_t base0 = (uint32_t)__shfl((int)my_start, 0);   // wave 0 holds lane 0 of the group
   if (threadIdx.x == 0) *lds_start0 = base0;
-  hj_stage_tables<NB>(lds_tabs, A.tables + blockIdx.y);
+  hj_stage_tables<NB>(lds_tabs, A.tables + blockIdx.y, A.wide ? A.wide + blockIdx.y : nullptr);
   __syncthreads();
   lds_start[threadIdx.x] = in_range ? (uint16_t)(my_start - *lds_start0) : (uint16_t)0;
   __syncthreads();
@@ -246,9 +265,9 @@ static __device__ __forceinline__ RowSrc hj_source(const uint32_t *lds_win,
 }
 
 
-template <class RowSrc>
+template <class RowSrc, class Tab = hj_ltables>
 __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int round, int max_iters, int lite_first) {
-  __shared__ __attribute__((aligned(16))) hj_ltables lds_tabs;
+  __shared__ __attribute__((aligned(16))) Tab lds_tabs;
   __shared__ uint32_t lds_win_mem[1 + HJ_WIN_DWORDS];      // [0]: the dword "before" row 0 (hj_lds_src::reader)
   uint32_t *lds_win = lds_win_mem + 1;
   __shared__ uint64_t lds_S[HJ_BLOCK + 1];       // start state of each subsequence of the group
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
   }
   hj_stage_image(&s_im, A.images + blockIdx.y);
   hj_lane_ctx L;
-  const bool on = hj_prologue(A, im, &lds_tabs, lds_win, lds_start, &lds_start0, L);
+  const bool on = hj_prologue<true, HJ_BLOCK, Tab>(A, im, &lds_tabs, lds_win, lds_start, &lds_start0, L);
   const uint32_t start0 = lds_start0;
   const uint32_t sidx = L.g + im.seg0 + L.si;          // this subsequence's entry of S
   {
@@ -328,13 +347,13 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
         uint64_t from = hj_pos(start);
         uint64_t skip = (uint64_t)(lite_first - 1)*8;
         if (from + 2*skip > stop_bit) skip = from < stop_bit ? (stop_bit - from)/2 : 0;
-        r = hj_sync_decode<RowSrc, true, hj_ltables>(hj_source<RowSrc>(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
+        r = hj_sync_decode<RowSrc, true, Tab>(hj_source<RowSrc>(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs,
          hj_pack(from + skip, hj_slot(start), hj_k(start)), stop_bit, (sb >> 31) == 0u, slot_tables);
         lds_ran[sub] = 2;                                    // ran, but nothing to publish
         lds_dirty[sub] = 1;                                  // (its own flag: no other lane writes it now)
       }
       else {
-        r = hj_sync_decode<RowSrc, false, hj_ltables>(hj_source<RowSrc>(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
+        r = hj_sync_decode<RowSrc, false, Tab>(hj_source<RowSrc>(lds_win, lds_start, start0, sub, hj_sub_dwords(A)), s_im, &lds_tabs, start,
          (uint64_t)(sb & 0x7fffffffu)*8, (sb >> 31) == 0u, slot_tables);
         lds_R[sub] = (uint16_t)r.nblocks;
         lds_ran[sub] = 1;
@@ -1107,6 +1126,9 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
   if (sparse > 0) {
     const dim3 sgrid((grid.x + HJ_SPARSE_GROUPS - 1)/HJ_SPARSE_GROUPS, grid.y);
     hipLaunchKernelGGL(hj_sync_sparse, sgrid, dim3(64*HJ_SPARSE_GROUPS), 0, (hipStream_t)stream, *A, round, max_iters);
+  }
+  else if (sparse < 0 && A->wide) {              // ... and with the 12-bit AC tables (small batches: hj_wide_ac)
+    hipLaunchKernelGGL((hj_sync_round<hj_lds_reg_src, hj_ltables_wide>), grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
   }
   else if (sparse < 0) {                         // dense, rows read through registers
     hipLaunchKernelGGL(hj_sync_round<hj_lds_reg_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);

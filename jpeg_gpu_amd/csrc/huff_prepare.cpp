@@ -108,6 +108,31 @@ static void build_packs(uint32_t *ac, const uint16_t *l1) {
   }
 }
 
+// The wide AC table of one slot (hj_wide_ac): for every 12-bit pattern the entry of its first symbol (as the 9-bit
+// table holds it) and the pack of the whole symbols the pattern holds — up to three, an EOB only as the last, none
+// if fewer than two.  Symbols are looked up in the 9-bit table `ac9` (codes of more than nine bits end a pack).
+static void build_wide(uint32_t *wide, const uint32_t *ac9) {
+  for (unsigned v = 0; v < (1u << HJ_WIDE_BITS); v++) {
+    int rem = HJ_WIDE_BITS, n = 0, bits = 0, adv = 0, prefix = 0;
+    unsigned val = v;
+    while (n < 3 && rem > 0) {
+      const unsigned idx = rem >= HJ_FAST_BITS ? (val >> (rem - HJ_FAST_BITS)) : (val << (HJ_FAST_BITS - rem));   // zero padded: decides
+      const uint16_t e = (uint16_t)ac9[idx & ((1u << HJ_FAST_BITS) - 1u)];                                        // nothing unless the code fits
+      if (HJ_IS_ESCAPE(e)) break;
+      const int tot = HJ_E_TOT(e), a = HJ_E_ADV(e);
+      if (HJ_E_LEN(e) > 16 || tot > rem || adv > 31) break;
+      prefix = adv;
+      adv += a;
+      bits += tot;
+      rem -= tot;
+      val &= (1u << rem) - 1u;
+      n++;
+      if (a == 64) break;
+    }
+    wide[v] = (ac9[v >> (HJ_WIDE_BITS - HJ_FAST_BITS)] & 0xffffu) | (n >= 2 ? HJ_PACK(bits, adv, prefix) << 16 : 0u);
+  }
+}
+
 hj_prepared::~hj_prepared() { free(desc); }
 
 int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
@@ -233,6 +258,22 @@ int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out) {
   im.w0_blocks = g.w0/8;
   out->avail = (uint32_t)(size - d->scan_off);
   return EXIT_SUCCESS;
+}
+
+void hj_prepare_wide(hj_prepared *out) {
+  // (per thread, beside the 9-bit AC tables they were built from: a stream of lone frames from one encoder builds
+  // them once — 8 192 entries, ~40 us)
+  struct wide_memo { uint32_t ac9[2][1 << HJ_FAST_BITS]; std::vector<uint32_t> wide; };
+  static thread_local std::unique_ptr<wide_memo> memo;
+  if (memo && memcmp(memo->ac9, out->tabs.ac, sizeof(memo->ac9)) == 0) { out->wide = memo->wide; return; }
+  out->wide.resize(2u << HJ_WIDE_BITS);
+  build_wide(out->wide.data(), out->tabs.ac[0]);
+  build_wide(out->wide.data() + (1u << HJ_WIDE_BITS), out->tabs.ac[1]);
+  if (!memo) memo.reset(new (std::nothrow) wide_memo());
+  if (memo) {
+    memcpy(memo->ac9, out->tabs.ac, sizeof(memo->ac9));
+    memo->wide = out->wide;
+  }
 }
 
 int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsigned char *dst) {

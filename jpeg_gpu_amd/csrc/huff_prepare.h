@@ -11,6 +11,7 @@ struct hj_prepared {
   jga_geom geom;
   std::vector<hj_segment> segs;
   hj_tables tabs;                   // two-level LUTs, [2*comp] DC, [2*comp+1] AC
+  std::vector<uint32_t> wide;       // the 12-bit AC tables (hj_wide_ac: 2 << HJ_WIDE_BITS entries), after hj_prepare_wide
   unsigned short qtab[3*64];        // per plane, natural order
   std::vector<unsigned char> clean; // (hj_prepare_image only) clean bytes + 16 pad
   uint32_t scan_len;                // clean length (without the pad)
@@ -35,6 +36,8 @@ struct hj_prepared {
 // plane offsets of the kernels (the caller may then use the host entropy stage).
 #define HJ_PREPARE_IRREGULAR 2
 int hj_prepare_head(const unsigned char *jpeg, int size, hj_prepared *out);
+// After hj_prepare_head: the wide AC tables of out->tabs into out->wide (for batches that take them: huff_common.h).
+void hj_prepare_wide(hj_prepared *out);
 int hj_prepare_scan(const unsigned char *jpeg, int size, hj_prepared *out, unsigned char *dst);
 // Both steps, clean stream kept in out->clean (emulation / tests).
 int hj_prepare_image(const unsigned char *jpeg, int size, hj_prepared *out);

@@ -98,6 +98,16 @@ int huff_emul_pack_mismatches(const unsigned char *jpeg, int size, const unsigne
     for (int j = 0; j < (1 << HJ_FAST_BITS); j++) { packs += (plain.ac[t][j] >> 16) != 0; plain.ac[t][j] &= 0xffffu; }
   }
   if (packed_steps) *packed_steps = packs;
+  // the same tables with the 12-bit packs of small batches (hj_ltables_wide, as the kernel stages them in LDS)
+  hj_prepare_wide(&P);
+  std::vector<hj_ltables_wide> wide(1);
+  for (int j = 0; j < (2 << HJ_FAST_BITS); j++) (&wide[0].dc[0][0])[j] = (&P.tabs.dc[0][0])[j];
+  memcpy(wide[0].ac, P.wide.data(), sizeof(wide[0].ac));
+  memcpy(wide[0].l2, P.tabs.l2, sizeof(wide[0].l2));
+  for (int t = 0; t < 2; t++) for (int j = 0; j < (1 << HJ_WIDE_BITS); j++) {
+    // the first symbol of a wide entry is the 9-bit table's
+    if ((wide[0].ac[t][j] & 0xffffu) != (P.tabs.ac[t][j >> (HJ_WIDE_BITS - HJ_FAST_BITS)] & 0xffffu)) return -1;
+  }
   std::vector<unsigned char> buf(data, data + ndata);
   buf.resize((size_t)ndata + 16, 0xFF);
   hj_mem_src src;
@@ -110,6 +120,8 @@ int huff_emul_pack_mismatches(const unsigned char *jpeg, int size, const unsigne
     const hj_run a = hj_sync_decode(src, P.im, &P.tabs, hj_pack(p, c, k), stop, (i & 1) != 0);
     const hj_run b = hj_sync_decode(src, P.im, &plain, hj_pack(p, c, k), stop, (i & 1) != 0);
     if (a.end_state != b.end_state || a.nblocks != b.nblocks) bad++;
+    const hj_run w = hj_sync_decode(src, P.im, &wide[0], hj_pack(p, c, k), stop, (i & 1) != 0);
+    if (w.end_state != b.end_state || w.nblocks != b.nblocks) bad++;
   }
   return bad;
 }
