@@ -77,6 +77,15 @@ def _device_only(lib, jpegs, n, reps=5):
             "Mpixel_s": round(n * g.width * g.height / best / 1e6, 1)}
 
 
+def _settle(lib):
+    """Before a leg that times single milliseconds: let the leg before it finish dying.  Freeing a job's buffers (6 GB
+    of outputs after config 4's 1024-file job) leaves the driver work that runs on for ~0.1-0.2 s and shares the copy
+    engines: the 128-file shard timed right behind it measures 4.3-4.4 ms median, after 0.3 s of nothing 3.6
+    (tools/archive/r5_shard_aging.py, profiles/r5_short_runs.md)."""
+    lib.check(lib.L.jga_stream_sync(None))
+    time.sleep(0.3)
+
+
 def _plugin(lib, abi, jpeg, reps):
     """reset -> header -> decode_image(RGB) per frame, pixels in img->pixels (host)."""
     with lib.Decoder(jpeg) as d:
@@ -114,6 +123,8 @@ def _pipeline_stream(lib, abi, np, orc, jpegs, order, nthreads, group, lanes, re
                       batch=group, depth=lanes)
     jobs = lib.Pipeline.make_jobs([src[i] for i in order], dev_outs=[out.ptr + k * ostride for k in range(n)],
                                   pinned=pinned)
+    if reps >= 10:
+        _settle(lib)
     ok = pl.run_jobs(jobs) == 0                                   # warm: every lane sized for its groups
     # (a short job timed many times: a fresh pipeline's first runs pay for the runtime bringing up its copy engines
     # and queues — ~9 ms per lane a few times, tools/archive/r3_shard_runs.py — which a median of 15 must not hold)
