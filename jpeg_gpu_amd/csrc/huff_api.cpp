@@ -151,12 +151,12 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipMalloc((void **)&b->d_R, 4*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_B, 4*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_part, hj_scan_part_bytes(b->sub_cap, b->sub_cap)) == hipSuccess
-   && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS) == hipSuccess
-   && hipMalloc((void **)&b->d_errors, 4*(size_t)max_images) == hipSuccess
+   && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images) == hipSuccess    // (+ d_errors: one copy brings both back)
    && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_wait, hipEventDisableTiming) == hipSuccess
    && hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) == hipSuccess;
   b->arrived = b->ev_up;
+  if (ok) b->d_errors = b->d_ran + HJ_MAX_ROUNDS;
   if (!ok) {
     jga_fail("huff: allocation failed (%d images, %lld scan bytes)", max_images, max_scan_bytes);
     jga_huff_destroy(b);
@@ -177,8 +177,7 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_part) (void)hipFree(b->d_part);
   if (b->d_dc) (void)hipFree(b->d_dc);
   if (b->d_dcpart) (void)hipFree(b->d_dcpart);
-  if (b->d_ran) (void)hipFree(b->d_ran);
-  if (b->d_errors) (void)hipFree(b->d_errors);
+  if (b->d_ran) (void)hipFree(b->d_ran);                       // (d_errors lies in it)
   if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
   if (b->ev_up) (void)hipEventDestroy(b->ev_up);
   delete b;
@@ -903,9 +902,8 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
   P.speculate = b->speculate >= 0 && !b->assist_hint;
   return EXIT_SUCCESS;
 }
-// What the write pass needs cleared (DC arrays, padding slots): one launch on the decode's stream (hj_clear).
-static int queue_clear(jga_huff_batch *b, const hj_args &A, hipStream_t st) {
-  hj_clear_args C;
+// What the write pass needs cleared (DC arrays, padding slots): workgroups of the decode's first launch (hj_init_states).
+static void clear_regions(jga_huff_batch *b, const hj_args &A, hj_clear_args &C) {
   memset(&C, 0, sizeof(C));
   auto add = [&](void *base, uint64_t row_bytes, uint64_t stride, uint32_t rows) {
     hj_clear_region &r = C.region[C.nregions++];
@@ -929,8 +927,6 @@ static int queue_clear(jga_huff_batch *b, const hj_args &A, hipStream_t st) {
   // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
   add(A.dc_diff, sizeof(int16_t)*(uint64_t)A.dc_stride*(uint64_t)b->nimages, 0, 1);
   add(A.dc_val, sizeof(int16_t)*(uint64_t)A.dc_stride*(uint64_t)b->nimages, 0, 1);
-  if (hj_launch_clear(&C, st)) return jga_fail("huff: launch failed");
-  return EXIT_SUCCESS;
 }
 // The tail of a decode: prefix sums, write pass, DC values, the images' verdicts.
 static int queue_tail(jga_huff_batch *b, const hj_args &A, bool split, hipStream_t st) {
@@ -940,16 +936,17 @@ static int queue_tail(jga_huff_batch *b, const hj_args &A, bool split, hipStream
   if (hj_launch_dc(&A, (int)b->total_seg, (int)b->max_seg_mcus, b->d_dcpart, split ? 0 : (int)(b->geom.coef_shorts/64), st)) {
     return jga_fail("huff: launch failed");
   }
-  HOK(hipMemcpyAsync(b->h_ran + HJ_MAX_ROUNDS, b->d_errors, 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
+  // (the rounds' "something moved" flags and the images' verdicts lie back to back on both sides: one copy)
+  HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)b->nimages, hipMemcpyDeviceToHost, st));
   return EXIT_SUCCESS;
 }
-static int queue_rounds(jga_huff_batch *b, const decode_plan &P, int &round, int count, hipStream_t st) {
+static int queue_rounds(jga_huff_batch *b, const decode_plan &P, int &round, int count, hipStream_t st, bool tail_follows = false) {
   for (int k = 0; k < count && round < HJ_MAX_ROUNDS; k++, round++) {
     if (hj_launch_round(&P.A, (int)b->max_nsub, round, round ? P.it1 : P.it0, round >= P.sparse_from ? 1 : P.lean ? -1 : 0, st)) {
       return jga_fail("huff: launch failed");
     }
   }
-  HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
+  if (!tail_follows) HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));   // (else the tail's copy brings them)
   return EXIT_SUCCESS;
 }
 
@@ -967,8 +964,11 @@ static int decode_begin(jga_huff_batch *b, short *d_coef, long long coef_stride,
   if (make_plan(b, d_coef, coef_stride, d_dc, dc_stride, P) != EXIT_SUCCESS) return EXIT_FAILURE;
   // reset: states back to the guesses, "never ran"
   // (on-device unstuffing has already had its say about every image: early end, RSTn counters)
+  // (with it, as extra workgroups of the same launch, what the write pass and the DC pass need cleared)
+  hj_clear_args C;
+  clear_regions(b, P.A, C);
   if (hj_launch_init(&P.A, (int)b->total_seg, (int)b->max_nsub,
-   b->unstuffed_on_device ? (const uint32_t *)(b->d_blob + b->off_perr) : NULL, st)) {
+   b->unstuffed_on_device ? (const uint32_t *)(b->d_blob + b->off_perr) : NULL, &C, st)) {
     return jga_fail("huff: launch failed");
   }
   b->last_assisted = 0;
@@ -980,10 +980,7 @@ static int decode_begin(jga_huff_batch *b, short *d_coef, long long coef_stride,
   // rounds first (JGA_HUFF_SPECULATE=0: never).
   if (b->spec_rounds < P.group) b->spec_rounds = P.group;
   int round = 0;
-  if (queue_rounds(b, P, round, P.speculate ? b->spec_rounds : P.group, st) != EXIT_SUCCESS) return EXIT_FAILURE;
-  // (the clears are queued behind the first burst of rounds — their launch would otherwise stand between a lone
-  // frame's upload and its first round — and in front of the tail that needs them)
-  if (queue_clear(b, P.A, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+  if (queue_rounds(b, P, round, P.speculate ? b->spec_rounds : P.group, st, P.speculate) != EXIT_SUCCESS) return EXIT_FAILURE;
   if (P.speculate && queue_tail(b, P.A, d_dc != NULL, st) != EXIT_SUCCESS) return EXIT_FAILURE;
   b->pend.active = true;
   b->pend.with_tail = P.speculate;

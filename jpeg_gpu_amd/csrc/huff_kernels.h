@@ -31,18 +31,18 @@ typedef struct hj_args {
   int flush_lanes;             /* finished blocks a wave collects before writing them out */
 } hj_args;
 
-/* hj_launch_clear: up to six regions of `rows` runs of `row_bytes` bytes (multiples of 16, 16-byte aligned) at a stride */
+/* regions hj_launch_init clears: up to six, each `rows` runs of `row_bytes` bytes (multiples of 16, 16-byte aligned) at a stride */
 typedef struct hj_clear_region { void *base; uint64_t row_bytes, stride; uint32_t rows, pad_; } hj_clear_region;
 typedef struct hj_clear_args { hj_clear_region region[6]; int nregions; } hj_clear_args;
 
 #ifdef __cplusplus
 extern "C" {
 #endif
-int hj_launch_clear(const hj_clear_args *C, void *stream);
 /* sparse != 0: the one-wave-per-group variant for rounds in which few lanes still move */
 /* fills sub_seg and the start states S (guesses) on the device */
 /* ... and clears ran[] and sets errors[] (to verdicts0[], device memory, or to 0) */
-int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream);
+/* (C: regions cleared by extra workgroups of the same launch, or NULL) */
+int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, const hj_clear_args *C, void *stream);
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);

@@ -1053,7 +1053,30 @@ __global__ __launch_bounds__(256) void hj_dc_apply(const hj_args A, int slots_pe
 // uploaded (12 bytes per 128 bytes of scan): lane 0 of a segment starts in its known state
 // (segment start, k = 0, slot 0, xjpeg.c:612-618), the others at a GUESS — a symbol starts on
 // their first byte.  A workgroup takes 4096 subsequences of one segment.
-__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg, const uint32_t *verdicts0) {
+// What the write pass and the DC pass need cleared before they run — the two DC arrays (blocks a damaged stream never
+// reaches, slots that hold no block) and the slots at the end of a decimated plane that hold no block.  (Rounds 2-4
+// queued these as three or four memsets on a side stream, round 5 first as one launch of their own on the decode's
+// stream, then as workgroups of hj_init_states.)
+static __device__ __forceinline__ void hj_clear_regions(const hj_clear_args &C, uint64_t me, uint64_t nblocks) {
+  typedef __attribute__((address_space(1))) hj_v4u global_v4u;
+  const hj_v4u zero = {0u, 0u, 0u, 0u};
+  for (int q = 0; q < C.nregions; q++) {
+    const hj_clear_region r = C.region[q];
+    const uint64_t per_row = r.row_bytes >> 4, total = per_row*r.rows;
+    for (uint64_t u = me*256u + threadIdx.x; u < total; u += nblocks*256u) {
+      const uint64_t row = per_row == total ? 0 : u/per_row, col = u - row*per_row;
+      *(global_v4u *)((uintptr_t)r.base + row*r.stride + (col << 4)) = zero;
+    }
+  }
+}
+// (round 5: the clears of a decode — hj_clear_regions — ride this launch as extra workgroups, blockIdx.x >= nsegs:
+// one launch less in every decode's chain, ~5 us of a lone frame's)
+__global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t *sub_seg, const uint32_t *verdicts0,
+ const hj_clear_args C, uint32_t nsegs) {
+  if (blockIdx.x >= nsegs) {
+    hj_clear_regions(C, (uint64_t)(blockIdx.x - nsegs)*gridDim.y + blockIdx.y, (uint64_t)(gridDim.x - nsegs)*gridDim.y);
+    return;
+  }
   const uint32_t gs = blockIdx.x;
   // (also the decode's bookkeeping words, instead of two memsets in front of it: "did anything
   // run in round r", and every image's verdict — what the on-device scan clean-up already
@@ -1083,36 +1106,19 @@ __global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t 
   }
   if (k1 == sg.nsub && threadIdx.x == 0) S[sg.nsub] = 0;
 }
-// What the write pass and the DC pass need cleared before they run — the two DC arrays (blocks a damaged stream never
-// reaches, slots that hold no block) and the slots at the end of a decimated plane that hold no block — in ONE
-// launch on the decode's own stream.  (Rounds 2-4 queued these as three or four memsets on a side stream, for free
-// beside the LDS-bound first round; with eight lanes' side streams sharing four hardware queues with their main
-// streams "beside" was rarely what happened, and the events around them cost every decode three more calls.)
-__global__ __launch_bounds__(256) void hj_clear(const hj_clear_args C) {
-  const hj_clear_region r = C.region[blockIdx.y];
-  const uint64_t per_row = r.row_bytes >> 4, total = per_row*r.rows;
-  typedef __attribute__((address_space(1))) hj_v4u global_v4u;
-  const hj_v4u zero = {0u, 0u, 0u, 0u};
-  for (uint64_t u = (uint64_t)blockIdx.x*256u + threadIdx.x; u < total; u += (uint64_t)gridDim.x*256u) {
-    const uint64_t row = per_row == total ? 0 : u/per_row, col = u - row*per_row;
-    *(global_v4u *)((uintptr_t)r.base + row*r.stride + (col << 4)) = zero;
-  }
-}
-extern "C" int hj_launch_clear(const hj_clear_args *C, void *stream) {
-  if (C->nregions < 1) return 0;
-  uint64_t most = 1;
-  for (int k = 0; k < C->nregions; k++) {
-    const uint64_t units = (C->region[k].row_bytes >> 4)*C->region[k].rows;
-    if (units > most) most = units;
-  }
-  const uint64_t want = (most + 1023)/1024;                     // four units per lane
-  hipLaunchKernelGGL(hj_clear, dim3((unsigned)(want < 4096 ? want : 4096), C->nregions), dim3(256), 0, (hipStream_t)stream, *C);
-  return (int)hipGetLastError();
-}
-
-extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, void *stream) {
-  hipLaunchKernelGGL(hj_init_states, dim3(total_segs, (max_nsub + 4095) >> 12), dim3(256), 0, (hipStream_t)stream, *A,
-   const_cast<uint32_t *>(A->sub_seg), verdicts0);
+extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0,
+ const hj_clear_args *C, void *stream) {
+  const unsigned gy = (unsigned)((max_nsub + 4095) >> 12);
+  // workgroups for the clears: four 16-byte units per lane, at most 4096 of them
+  uint64_t units = 0;
+  for (int k = 0; C && k < C->nregions; k++) units += (C->region[k].row_bytes >> 4)*C->region[k].rows;
+  uint64_t want = (units + 1023)/1024;
+  if (want > 4096) want = 4096;
+  const unsigned cx = (unsigned)((want + gy - 1)/gy);
+  hj_clear_args none;
+  none.nregions = 0;
+  hipLaunchKernelGGL(hj_init_states, dim3(total_segs + cx, gy), dim3(256), 0, (hipStream_t)stream, *A,
+   const_cast<uint32_t *>(A->sub_seg), verdicts0, C ? *C : none, (uint32_t)total_segs);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,
