@@ -246,8 +246,12 @@ static long long block_off(const frame *f, int p, int bx, int by) {
 #define JGS_FLAT_AC    8   /* AC tables with all 162 symbols on 10-bit codes: valid, wasteful, and
                             * 81 distinct 9-bit prefixes of long codes (the Annex K tables have 5) */
 static const unsigned char FLAT_AC_BITS[16] = {0,0,0,0,0,0,0,0,0,162,0,0,0,0,0,0};
-#define AC_LUMA_BITS(flags) (((flags) & JGS_FLAT_AC) ? FLAT_AC_BITS : K5_AC_LUMA_BITS)
-#define AC_CHROMA_BITS(flags) (((flags) & JGS_FLAT_AC) ? FLAT_AC_BITS : K6_AC_CHROMA_BITS)
+#define JGS_SWAP_AC   16   /* luma coded with the Annex K CHROMA AC table and chroma with the luma one: valid,
+                            * regular, and not the tables every other file of a batch brings */
+#define AC_LUMA_BITS(flags) (((flags) & JGS_FLAT_AC) ? FLAT_AC_BITS : ((flags) & JGS_SWAP_AC) ? K6_AC_CHROMA_BITS : K5_AC_LUMA_BITS)
+#define AC_CHROMA_BITS(flags) (((flags) & JGS_FLAT_AC) ? FLAT_AC_BITS : ((flags) & JGS_SWAP_AC) ? K5_AC_LUMA_BITS : K6_AC_CHROMA_BITS)
+#define AC_LUMA_VALS(flags) (((flags) & JGS_SWAP_AC) ? K6_AC_CHROMA_VALS : K5_AC_LUMA_VALS)
+#define AC_CHROMA_VALS(flags) (((flags) & JGS_SWAP_AC) ? K5_AC_LUMA_VALS : K6_AC_CHROMA_VALS)
 
 static void put_headers(writer *w, const frame *f,
  const unsigned short q[3][64], int nq, int restart_interval, int flags) {
@@ -284,10 +288,10 @@ static void put_headers(writer *w, const frame *f,
   }
   if (flags & JGS_SPLIT_DHT) {
     put_dht(w, 0x00, K3_DC_LUMA_BITS, K_DC_VALS);
-    put_dht(w, 0x10, AC_LUMA_BITS(flags), K5_AC_LUMA_VALS);
+    put_dht(w, 0x10, AC_LUMA_BITS(flags), AC_LUMA_VALS(flags));
     if (f->ncomps == 3) {
       put_dht(w, 0x01, K4_DC_CHROMA_BITS, K_DC_VALS);
-      put_dht(w, 0x11, AC_CHROMA_BITS(flags), K6_AC_CHROMA_VALS);
+      put_dht(w, 0x11, AC_CHROMA_BITS(flags), AC_CHROMA_VALS(flags));
     }
   }
   else {
@@ -300,14 +304,14 @@ static void put_headers(writer *w, const frame *f,
     for (i = 0; i < 12; i++) put8(w, K_DC_VALS[i]);
     put8(w, 0x10);
     for (i = 0; i < 16; i++) put8(w, AC_LUMA_BITS(flags)[i]);
-    for (i = 0; i < 162; i++) put8(w, K5_AC_LUMA_VALS[i]);
+    for (i = 0; i < 162; i++) put8(w, AC_LUMA_VALS(flags)[i]);
     if (f->ncomps == 3) {
       put8(w, 0x01);
       for (i = 0; i < 16; i++) put8(w, K4_DC_CHROMA_BITS[i]);
       for (i = 0; i < 12; i++) put8(w, K_DC_VALS[i]);
       put8(w, 0x11);
       for (i = 0; i < 16; i++) put8(w, AC_CHROMA_BITS(flags)[i]);
-      for (i = 0; i < 162; i++) put8(w, K6_AC_CHROMA_VALS[i]);
+      for (i = 0; i < 162; i++) put8(w, AC_CHROMA_VALS(flags)[i]);
     }
   }
   if (restart_interval) {
@@ -340,9 +344,9 @@ static long encode_levels(const frame *f, const short *levels,
   w.out = out;
   w.cap = cap;
   build_huff(&dcl, K3_DC_LUMA_BITS, K_DC_VALS);
-  build_huff(&acl, AC_LUMA_BITS(flags), K5_AC_LUMA_VALS);
+  build_huff(&acl, AC_LUMA_BITS(flags), AC_LUMA_VALS(flags));
   build_huff(&dcc, K4_DC_CHROMA_BITS, K_DC_VALS);
-  build_huff(&acc, AC_CHROMA_BITS(flags), K6_AC_CHROMA_VALS);
+  build_huff(&acc, AC_CHROMA_BITS(flags), AC_CHROMA_VALS(flags));
   put_headers(&w, f, q, nq, restart_interval, flags);
   for (mby = 0; mby < f->nvmb; mby++) {
     for (mbx = 0; mbx < f->nhmb; mbx++) {

@@ -14,7 +14,7 @@ if not os.path.exists(_PATH):
     raise ImportError("%s missing: run `python -m jpeg_gpu_amd.build`" % _PATH)
 S = C.CDLL(_PATH)
 
-DQT16, NO_JFIF, SPLIT_DHT, FLAT_AC = 1, 2, 4, 8
+DQT16, NO_JFIF, SPLIT_DHT, FLAT_AC, SWAP_AC = 1, 2, 4, 8, 16
 # luma sampling factors (hs, vs) by name
 SAMPLING = {"444": (1, 1), "422": (2, 1), "420": (2, 2), "440": (1, 2), "411": (4, 1),
             "grey": (1, 1)}

@@ -819,11 +819,11 @@ def test_gpu_huffman_several_symbols_per_lookup_edges(gpu, orc, synth, sampling,
 @pytest.mark.parametrize("sampling", ["420", "444"])
 def test_gpu_huffman_small_and_large_batches_with_mixed_tables(gpu, orc, synth, sampling):
     """Batches of at most four images decode their synchronisation rounds with 12-bit AC packs (hj_wide_ac, round 5),
-    larger ones with the 9-bit tables; every image brings its own tables.  The same files — the Annex-K tables and
-    the encoder's flat AC table (every code 8 bits: no two symbols in 12 bits, long codes everywhere), mixed in one
-    batch — as batches of 1, 2, 4 (wide) and 5, 7 (9-bit): the oracle's QUANT planes every time."""
+    larger ones with the 9-bit tables; every image brings its own tables.  The same files — the Annex-K tables, and
+    the same two AC tables the other way round (luma coded with the chroma table: another set of packs) — mixed in
+    one batch, as batches of 1, 2, 4 (wide) and 5, 7 (9-bit): the oracle's QUANT planes every time."""
     files = [synth.synthetic_jpeg(640, 360, sampling, quality=q, restart_interval=ri, seed=q, flags=fl)
-             for q, ri, fl in ((90, 0, 0), (60, 0, synth.FLAT_AC), (35, 7, 0), (90, 0, synth.FLAT_AC), (75, 0, 0))]
+             for q, ri, fl in ((90, 0, 0), (60, 0, synth.SWAP_AC), (35, 7, 0), (90, 0, synth.SWAP_AC), (75, 0, 0))]
     want = [oracle_quant(orc, f) for f in files]
     for n in (1, 2, 4, 5, 7):
         order = [(3 * k + n) % len(files) for k in range(n)]

@@ -139,13 +139,14 @@ def test_frames_beyond_32_bit_offsets_are_handed_to_the_host_stage(emul, synth):
 
 def test_ac_packs_change_nothing_on_any_bit_string(emul, synth, golden_jpegs):
     """hj_tables' AC entries carry PACKS (several whole symbols of the next 9 bits taken in one
-    step).  A run with them must compute what the symbols one by one would — for real scans and
-    for arbitrary bytes (runs that start out of step decode garbage): end state, block count
-    and DC sums of 20 000 runs per table set, with the packs and with them stripped."""
+    step; small batches: of the next 12, hj_wide_ac).  A run with them must compute what the symbols one by one
+    would — for real scans and for arbitrary bytes (runs that start out of step decode garbage): end state and
+    block count of 20 000 runs per table set, with the 9-bit packs, with the 12-bit ones and with them stripped."""
     emul.huff_emul_pack_mismatches.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                                C.POINTER(C.c_longlong)]
     rng = np.random.default_rng(12)
     files = [synth.synthetic_jpeg(64, 48, s, quality=q, seed=q) for s, q in (("420", 90), ("444", 35), ("grey", 75))]
+    files.append(synth.synthetic_jpeg(64, 48, "420", quality=80, seed=3, flags=synth.SWAP_AC))   # luma on the chroma AC table
     files += [golden_jpegs.jpeg(n) for n in golden_jpegs.names[:4]]          # Pillow's optimised tables too
     for f in files:
         real = synth.synthetic_jpeg(640, 480, "420", quality=88, seed=5)
