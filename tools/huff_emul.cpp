@@ -228,3 +228,131 @@ int huff_emul_decode(const unsigned char *jpeg, int size, short *coef, long long
   if (runs_out) *runs_out = runs;
   return 0;
 }
+
+// ---- hypothesis pass (round 5 study): a guess of every subsequence's start state from runs that start at the
+// subsequence's first byte in every MCU-slot phase, linked by equality of their states at a checkpoint `margin`
+// bytes into the next subsequence.  Reports how good the guess is: wrong start states, breaks of the chain, and
+// the Jacobi rounds the synchronisation needs from the guess (against the rounds from the plain guess).
+extern "C" __attribute__((visibility("default")))
+int huff_emul_hypotheses(const unsigned char *jpeg, int size, int margin, int *out /* [9] */) {
+  hj_prepared P;
+  P.sub_log2 = g_sub_log2;
+  if (hj_prepare_image(jpeg, size, &P) != EXIT_SUCCESS) return 1;
+  const uint32_t nsub = P.im.nsub;
+  const int H = P.im.nslots;
+  hj_mem_src src; src.s = P.clean.data();
+  std::vector<uint64_t> truth(nsub + P.segs.size()), guess(nsub + P.segs.size());
+  std::vector<uint32_t> sub_seg(nsub);
+  long wrong = 0, breaks = 0, voted = 0, longest = 0, avoidable = 0;
+  for (size_t si = 0; si < P.segs.size(); si++) {
+    const hj_segment &sg = P.segs[si];
+    // truth: in order
+    uint64_t st = hj_pack((uint64_t)sg.start*8, 0, 0);
+    for (uint32_t i = 0; i < sg.nsub; i++) {
+      sub_seg[sg.sub0 + i] = (uint32_t)si;
+      truth[sg.sub0 + si + i] = st;
+      uint32_t stop_byte = sg.start + ((i + 1) << g_sub_log2);
+      if (stop_byte > sg.end) stop_byte = sg.end;
+      st = hj_sync_decode(src, P.im, &P.tabs, st, (uint64_t)stop_byte*8, i + 1 >= sg.nsub).end_state;
+    }
+    truth[sg.sub0 + si + sg.nsub] = 0;
+    // hypotheses
+    std::vector<uint64_t> Y((size_t)sg.nsub*H), A((size_t)sg.nsub*H), X((size_t)sg.nsub*H);
+    for (uint32_t i = 0; i < sg.nsub; i++) {
+      const uint32_t b0 = sg.start + (i << g_sub_log2);
+      uint32_t b1 = sg.start + ((i + 1) << g_sub_log2);
+      if (b1 > sg.end) b1 = sg.end;
+      uint32_t by = b0 + (uint32_t)margin < b1 ? b0 + (uint32_t)margin : b1;
+      uint32_t bx = b1 + (uint32_t)margin < sg.end ? b1 + (uint32_t)margin : sg.end;
+      for (int h = 0; h < H; h++) {
+        uint64_t s0 = hj_pack((uint64_t)b0*8, i == 0 ? 0 : h, 0);
+        const uint64_t y = hj_sync_decode(src, P.im, &P.tabs, s0, (uint64_t)by*8, false).end_state;
+        const uint64_t a = hj_pos(y) >= (uint64_t)b1*8 ? y : hj_sync_decode(src, P.im, &P.tabs, y, (uint64_t)b1*8, false).end_state;
+        const uint64_t x = hj_pos(a) >= (uint64_t)bx*8 ? a : hj_sync_decode(src, P.im, &P.tabs, a, (uint64_t)bx*8, false).end_state;
+        Y[(size_t)i*H + h] = y; A[(size_t)i*H + h] = a; X[(size_t)i*H + h] = x;
+      }
+    }
+    // link
+    int cur = 0;
+    long run_wrong = 0;
+    guess[sg.sub0 + si] = truth[sg.sub0 + si];
+    for (uint32_t i = 0; i + 1 < sg.nsub; i++) {
+      const uint64_t a = A[(size_t)i*H + cur];
+      guess[sg.sub0 + si + i + 1] = a;
+      if (a != truth[sg.sub0 + si + i + 1]) {
+        wrong++; run_wrong++; if (run_wrong > longest) longest = run_wrong;
+        bool existed = false;
+        for (int h = 0; h < H; h++) existed = existed || A[(size_t)i*H + h] == truth[sg.sub0 + si + i + 1];
+        if (existed) avoidable++;
+      }
+      else run_wrong = 0;
+      const uint64_t x = X[(size_t)i*H + cur];
+      int next = -1;
+      for (int h = 0; h < H && next < 0; h++) if (Y[(size_t)(i + 1)*H + h] == x) next = h;
+      if (next < 0) {
+        breaks++;
+        // a hypothesis of the next subsequence that is on the true parse by ITS checkpoint links on (its state there is
+        // some hypothesis's of the subsequence after it); garbage rarely does.  Among those that link on, the most
+        // common state wins.
+        int best = -1, bestn = 0;
+        if (i + 2 < sg.nsub) {
+          for (int h = 0; h < H; h++) {
+            bool links = false;
+            for (int g = 0; g < H && !links; g++) links = X[(size_t)(i + 1)*H + h] == Y[(size_t)(i + 2)*H + g];
+            if (!links) continue;
+            int n = 0;
+            for (int g = 0; g < H; g++) n += X[(size_t)(i + 1)*H + g] == X[(size_t)(i + 1)*H + h];
+            if (n > bestn) { bestn = n; best = h; }
+          }
+        }
+        if (best >= 0) { next = best; voted++; }
+        else {
+          // the phase of the block the next subsequence's first byte lies in
+          int ph = hj_slot(a);
+          if (hj_k(a) == 0 && hj_pos(a) > (uint64_t)(sg.start + ((i + 1) << g_sub_log2))*8) ph = (ph + H - 1) % H;
+          next = ph;
+        }
+      }
+      cur = next;
+    }
+    guess[sg.sub0 + si + sg.nsub] = 0;
+  }
+  // Jacobi rounds from the guess and from the plain start
+  auto rounds_from = [&](std::vector<uint64_t> S, long long *runs) {
+    std::vector<uint64_t> last_in(nsub, ~0ull);
+    int rounds = 0;
+    *runs = 0;
+    for (;;) {
+      bool ran = false;
+      std::vector<uint64_t> snap = S;
+      for (uint32_t g = 0; g < nsub; g++) {
+        const uint32_t si = sub_seg[g];
+        const hj_segment &sg = P.segs[si];
+        const uint32_t i = g - sg.sub0;
+        const uint64_t start = snap[g + si];
+        if (start == last_in[g]) continue;
+        uint32_t stop_byte = sg.start + ((i + 1) << g_sub_log2);
+        if (stop_byte > sg.end) stop_byte = sg.end;
+        const hj_run r = hj_sync_decode(src, P.im, &P.tabs, start, (uint64_t)stop_byte*8, i + 1 >= sg.nsub);
+        last_in[g] = start;
+        if (i + 1 < sg.nsub) S[g + si + 1] = r.end_state;
+        ran = true;
+        (*runs)++;
+      }
+      if (!ran) break;
+      rounds++;
+      if (rounds > (int)nsub + 4) break;
+    }
+    return rounds;
+  };
+  std::vector<uint64_t> plain(nsub + P.segs.size());
+  for (size_t si = 0; si < P.segs.size(); si++) {
+    const hj_segment &sg = P.segs[si];
+    for (uint32_t i = 0; i < sg.nsub; i++) plain[sg.sub0 + si + i] = hj_pack((uint64_t)(sg.start + (i << g_sub_log2))*8, 0, 0);
+  }
+  long long runs_g = 0, runs_p = 0;
+  const int rg = rounds_from(guess, &runs_g), rp = rounds_from(plain, &runs_p);
+  out[0] = (int)nsub; out[1] = (int)wrong; out[2] = (int)breaks; out[3] = (int)voted; out[4] = (int)longest;
+  out[5] = rg; out[6] = rp; out[7] = (int)(runs_g*100/(nsub ? nsub : 1)); out[8] = (int)avoidable;
+  return 0;
+}
