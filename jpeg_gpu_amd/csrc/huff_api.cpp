@@ -36,6 +36,8 @@ struct jga_huff_batch {
   uint64_t *d_last_in;
   uint32_t *d_R;
   uint32_t *d_B;
+  uint32_t *d_list;            // work lists of the list rounds: two parities of sub_cap entries
+  uint32_t *d_lcount;          // [4][max_images] their lengths, HJ_LIST_CSTRIDE words apart
   int16_t *d_dc;               // DC differences (scan order) | DC values (by buffer slot) of the current batch
   size_t dc_cap;               // entries of each half
   uint32_t *d_dcpart;          // chunk totals of the DC prefix sums
@@ -93,6 +95,7 @@ struct jga_huff_batch {
   std::vector<unsigned char> copied;        // last prepare(), per image: 1 if a host core copied its scan into the blob
   std::vector<unsigned char> input_flags;   // per image: buffer pinned / registered (jga_huff_set_input_flags); empty: inputs_pinned for all
   int last_rounds;
+  int list_state;              // work lists of the list rounds: 0 valid, 1 to be built (counters zero), 2 to be reset and built
 };
 
 // Same frame as far as every kernel is concerned: everything in a jga_geom but the restart
@@ -150,6 +153,8 @@ JGA_EXPORT jga_huff_batch *jga_huff_create(int max_images, long long max_scan_by
    && hipMalloc((void **)&b->d_last_in, 8*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_R, 4*b->sub_cap) == hipSuccess
    && hipMalloc((void **)&b->d_B, 4*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_list, 8*b->sub_cap) == hipSuccess
+   && hipMalloc((void **)&b->d_lcount, 16*HJ_LIST_CSTRIDE*(size_t)max_images) == hipSuccess
    && hipMalloc((void **)&b->d_part, hj_scan_part_bytes(b->sub_cap, b->sub_cap)) == hipSuccess
    && hipMalloc((void **)&b->d_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images) == hipSuccess    // (+ d_errors: one copy brings both back)
    && hipHostMalloc((void **)&b->h_ran, 4*HJ_MAX_ROUNDS + 4*(size_t)max_images, hipHostMallocDefault) == hipSuccess
@@ -174,6 +179,8 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_last_in) (void)hipFree(b->d_last_in);
   if (b->d_R) (void)hipFree(b->d_R);
   if (b->d_B) (void)hipFree(b->d_B);
+  if (b->d_list) (void)hipFree(b->d_list);
+  if (b->d_lcount) (void)hipFree(b->d_lcount);
   if (b->d_part) (void)hipFree(b->d_part);
   if (b->d_dc) (void)hipFree(b->d_dc);
   if (b->d_dcpart) (void)hipFree(b->d_dcpart);
@@ -193,11 +200,13 @@ static bool grow_batch(jga_huff_batch *b, size_t need_sub, size_t need_blob) {
     if (b->d_last_in) (void)hipFree(b->d_last_in);
     if (b->d_R) (void)hipFree(b->d_R);
     if (b->d_B) (void)hipFree(b->d_B);
+    if (b->d_list) (void)hipFree(b->d_list);
     if (b->d_part) (void)hipFree(b->d_part);
-    b->d_last_in = NULL; b->d_R = NULL; b->d_B = NULL; b->d_part = NULL; b->sub_cap = 0;
+    b->d_last_in = NULL; b->d_R = NULL; b->d_B = NULL; b->d_list = NULL; b->d_part = NULL; b->sub_cap = 0;
     if (hipMalloc((void **)&b->d_last_in, 8*cap) != hipSuccess
      || hipMalloc((void **)&b->d_R, 4*cap) != hipSuccess
      || hipMalloc((void **)&b->d_B, 4*cap) != hipSuccess
+     || hipMalloc((void **)&b->d_list, 8*cap) != hipSuccess
      || hipMalloc((void **)&b->d_part, hj_scan_part_bytes(cap, cap)) != hipSuccess) {
       return false;
     }
@@ -249,6 +258,9 @@ static void fill_sync_args(const jga_huff_batch *b, hj_args &A) {
   A.last_in = b->d_last_in;
   A.R = b->d_R;
   A.B = b->d_B;
+  A.list = b->d_list;
+  A.list_stride = (uint32_t)b->sub_cap;
+  A.list_count = b->d_lcount;
   A.scan_part = b->d_part;
   A.ran = b->d_ran;
   A.errors = b->d_errors;
@@ -258,7 +270,7 @@ static void fill_sync_args(const jga_huff_batch *b, hj_args &A) {
 // tuning knobs of the rounds, read once (thread-safe: several pipeline lanes decode at the same time)
 namespace {
 struct round_knobs {
-  int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1;
+  int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1, list_from = -1, it_list = 8;
   round_knobs() {
     const char *e = jga_tune("JGA_HUFF_ITERS");     // "first,later,group": in-group iterations, rounds per host check
     if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
@@ -267,6 +279,12 @@ struct round_knobs {
     if (group < 1) group = 1;
     e = jga_tune("JGA_HUFF_SPARSE_FROM");            // first round run by the sparse kernel (default: by batch size)
     if (e) sparse_from = atoi(e);
+    e = jga_tune("JGA_HUFF_LIST");                   // "first list round[,steps inside a workgroup]"; 0: no list rounds (A/B knob)
+    if (e) {
+      sscanf(e, "%d,%d", &list_from, &it_list);
+      if (list_from <= 0) list_from = HJ_MAX_ROUNDS;
+      if (it_list < 1) it_list = 1;
+    }
     e = jga_tune("JGA_HUFF_LEAN");                   // 0: the dense kernel's stateless row reader (A/B knob)
     if (e) lean = atoi(e) != 0;
     e = jga_tune("JGA_HUFF_FLUSH");                  // write-pass batching
@@ -816,6 +834,7 @@ static int assist_chains(jga_huff_batch *b, hipStream_t st) {
     for (auto &th : pool) th.join();
   }
   b->last_assisted += walked.load();
+  b->list_state = 2;                                         // the lists are made afresh from the corrected states
   HOK(hipMemcpyAsync(b->d_blob + b->off_S, S, 8*ns, hipMemcpyHostToDevice, st));
   return EXIT_SUCCESS;
 }
@@ -846,7 +865,7 @@ static double thread_cpu_ms() {
 // write pass and it — and asks decode_end() whether what it queued saw the final planes (`*valid_behind`).
 struct decode_plan {
   hj_args A;
-  int it0, it1, group, sparse_from, assist_after, lean;
+  int it0, it1, group, sparse_from, assist_after, lean, list_from, it_list;
   bool speculate;
 };
 static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride, decode_plan &P) {
@@ -897,6 +916,13 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
   // in groups of 32 ran 22.5 ms with the sparse kernel and 24.2 with the dense one)
   const bool small_batch = !b->device_shared && b->total_sub <= 200u*1024u;
   P.sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from : small_batch ? HJ_MAX_ROUNDS : 1;
+  // Batches that fill the device (or share it): from the second launch on only the subsequences that still move run,
+  // from work lists (hj_sync_list) — one step of the chain per launch, several inside a workgroup once an image's list
+  // fits one; 48 x 4K: 400 us of list rounds where the sparse kernel took 500, on a tenth of its instructions.  A small
+  // batch alone on the device keeps the dense kernel for every round: its in-group steps are ~10 us shorter than a
+  // list step's (no list to read, rows already staged), and nothing else wants the CUs its idle lanes hold.
+  P.list_from = long_subs ? HJ_MAX_ROUNDS : K.list_from >= 0 ? K.list_from : small_batch ? HJ_MAX_ROUNDS : 1;
+  P.it_list = K.it_list;
   A.flush_lanes = K.flush_lanes;
   A.sub_log2 = b->sub_log2;
   P.speculate = b->speculate >= 0 && !b->assist_hint;
@@ -942,9 +968,27 @@ static int queue_tail(jga_huff_batch *b, const hj_args &A, bool split, hipStream
 }
 static int queue_rounds(jga_huff_batch *b, const decode_plan &P, int &round, int count, hipStream_t st, bool tail_follows = false) {
   for (int k = 0; k < count && round < HJ_MAX_ROUNDS; k++, round++) {
+    if (round >= P.list_from) {
+      if (hj_launch_list_round(&P.A, (int)b->max_nsub, round, P.it_list, b->list_state, st)) return jga_fail("huff: launch failed");
+      b->list_state = 0;
+      if (jga_tune("JGA_HUFF_LIST_STATS")) {                   // (tuning build: what the round ran and what it left, synchronously)
+        std::vector<uint32_t> c((size_t)4*HJ_LIST_CSTRIDE*(size_t)b->nimages);
+        HOK(hipStreamSynchronize(st));
+        HOK(hipMemcpy(c.data(), b->d_lcount, 4*c.size(), hipMemcpyDeviceToHost));
+        unsigned long long in = 0, out = 0, mx = 0, solo = 0;
+        for (int i = 0; i < b->nimages; i++) {
+          const uint32_t x = c[((size_t)(round & 3)*b->nimages + i)*HJ_LIST_CSTRIDE], y = c[((size_t)((round + 1) & 3)*b->nimages + i)*HJ_LIST_CSTRIDE];
+          in += x; out += y; mx = x > mx ? x : mx; solo += x <= 256;
+        }
+        fprintf(stderr, "  list round %d: %llu entries (largest list %llu, %llu of %d images in one workgroup), %llu left for the next\n",
+         round, in, mx, solo, b->nimages, out);
+      }
+      continue;
+    }
     if (hj_launch_round(&P.A, (int)b->max_nsub, round, round ? P.it1 : P.it0, round >= P.sparse_from ? 1 : P.lean ? -1 : 0, st)) {
       return jga_fail("huff: launch failed");
     }
+    if (b->list_state == 0) b->list_state = 2;
   }
   if (!tail_follows) HOK(hipMemcpyAsync(b->h_ran, b->d_ran, 4*HJ_MAX_ROUNDS, hipMemcpyDeviceToHost, st));   // (else the tail's copy brings them)
   return EXIT_SUCCESS;
@@ -972,6 +1016,7 @@ static int decode_begin(jga_huff_batch *b, short *d_coef, long long coef_stride,
     return jga_fail("huff: launch failed");
   }
   b->last_assisted = 0;
+  b->list_state = 1;                                         // (hj_init_states zeroed the lists' counters)
   // A photograph settles in 4-6 rounds, so the tail is queued SPECULATIVELY behind the first
   // group of rounds: one host round trip per decode instead of two (a lone 1080p frame: ~60 us of
   // its ~700).  If the last of those rounds still moved something, the tail ran on unsettled

@@ -5,6 +5,7 @@
 #include "huff_common.h"
 
 #define HJ_MAX_ROUNDS 256
+#define HJ_LIST_CSTRIDE 64       /* words between two list counters: a 256-byte line each */
 
 typedef struct hj_args {
   const hj_image *images;      /* [nimages] */
@@ -22,7 +23,11 @@ typedef struct hj_args {
   long long dc_stride;         /* entries per image (>= coef_shorts/64) */
   int dc_chunks_per_image;     /* hj_dc_chunks_per_image() */
   uint32_t *scan_part;         /* chunk totals of the prefix-sum pass (hj_scan_part_bytes) */
-  uint32_t *ran;               /* [HJ_MAX_ROUNDS] non-zero if any lane ran in that round */
+  uint32_t *ran;               /* [HJ_MAX_ROUNDS] non-zero if any lane ran in that round (a list round: if it left work for the next) */
+  uint32_t *list;              /* work lists of the list rounds (hj_sync_list): image-local subsequence numbers; round r reads the
+                                * entries list[(r & 1)*list_stride + image.sub0 ...] and appends to those of parity (r + 1) & 1 */
+  uint32_t list_stride;        /* entries per parity (>= the batch's subsequences) */
+  uint32_t *list_count;        /* entries of round r's list of image i at [((r & 3)*nimages + i)*HJ_LIST_CSTRIDE] */
   uint32_t *errors;            /* [nimages] bit0 inconsistent stream, bit1 bad coefficient index */
   int16_t *coef;               /* image i at coef + i*coef_stride */
   long long coef_stride;
@@ -44,6 +49,10 @@ extern "C" {
 /* (C: regions cleared by extra workgroups of the same launch, or NULL) */
 int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, const hj_clear_args *C, void *stream);
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
+/* A LIST round: only the subsequences whose start state moved run, packed into dense waves from a work list per image
+ * (rebuild != 0: the lists are made afresh from the states first — the first list round of a decode, or after the host
+ * changed states).  An image whose list fits one workgroup is iterated inside it, up to max_iters steps. */
+int hj_launch_list_round(const hj_args *A, int max_nsub, int round, int max_iters, int rebuild, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);
 int hj_launch_write(const hj_args *A, int max_nsub, void *stream);

@@ -526,6 +526,183 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
 }
 
 typedef uint32_t hj_v4u __attribute__((ext_vector_type(4)));
+// ---- list rounds (round 5) ---------------------------------------------------------------------------
+// After the first round's in-group iterations 6-7 % of a photograph's subsequences still move, a quarter of those
+// a step later, and so on down a chain of five or six more steps (4:2:0: the MCU slot has to fall into step as
+// well).  hj_sync_sparse walks that tail with one wave per 256 subsequences: sixteen of its lanes busy in the
+// first step, four in the second, and every wave of the batch resident for three steps' time — 19 000 vector
+// instructions per wave for what three or four lanes do.  A LIST round runs exactly the subsequences that moved:
+//   hj_list_build   one lane per subsequence: those whose start state differs from the one their latest run
+//                   began in go onto their image's work list (wave-aggregated append);
+//   hj_sync_list    a workgroup takes 256 list entries of one image (tables in LDS, the entries' rows staged
+//                   in LDS like the dense kernel's — any 140 bytes of the scan), runs them, and appends every
+//                   successor whose start state it changed to the NEXT round's list.  One launch = one step
+//                   of the chain, at the speed of a lane with a SIMD almost to itself (~30 us), on a few
+//                   hundred waves instead of 4 608.
+// An image whose whole list fits one workgroup ("solo") is iterated inside it: successors and their states stay in
+// LDS, step after step without a launch in between, up to max_iters; what still moves then goes to the next
+// round's list.  Nobody else touches a solo image in that launch, and in a shared image every subsequence is on
+// the list at most once (its one predecessor is the only lane that can put it there), so no two lanes ever run
+// the same subsequence in one launch.  A lane that reads a start state its predecessor is just replacing runs
+// from the old or the new one — and is on the next list in both cases.
+// Counters: list_count[(r & 3)][image] is round r's list length; round r zeroes the counter of round r + 2.
+// (every image's counter has a 256-byte line to itself — HJ_LIST_CSTRIDE words: device-wide atomics on one line are
+// served one after the other by one memory channel, ~8 ns each: 18 000 wave-level appends to 48 neighbouring counters
+// took hj_list_build 157 us; one append per workgroup onto a line per image takes it ~10)
+#define HJ_LIST_BLOCK 256
+static __device__ __forceinline__ uint32_t *hj_list_counter(const hj_args &A, int round, uint32_t img) {
+  return A.list_count + ((uint32_t)(round & 3)*(uint32_t)A.nimages + img)*HJ_LIST_CSTRIDE;
+}
+__global__ __launch_bounds__(256) void hj_list_build(const hj_args A, int round) {
+  __shared__ uint32_t wcnt[4], wbase;
+  const hj_image *im = A.images + blockIdx.y;
+  const uint32_t li = blockIdx.x*256u + threadIdx.x, nsub = im->nsub, sub0 = im->sub0;
+  bool dirty = false;
+  if (li < nsub) {
+    const uint32_t g = sub0 + li;
+    dirty = A.S[g + im->seg0 + A.sub_seg[g]] != A.last_in[g];
+  }
+  const unsigned long long m = __ballot(dirty);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    wbase = total ? atomicAdd(hj_list_counter(A, round, blockIdx.y), total) : 0u;
+  }
+  __syncthreads();
+  if (!dirty) return;
+  uint32_t pos = wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  for (uint32_t w = 0; w < wave; w++) pos += wcnt[w];
+  A.list[(size_t)(round & 1)*A.list_stride + sub0 + pos] = li;
+}
+
+// An entry's row in LDS: the bytes from (first byte of its subsequence & ~15) on — its lane loads them itself, sixteen
+// at a time and all of them in flight at once (a loop of dependent dword loads over scattered rows cost a step 15-20 us)
+// — as big-endian dwords at an odd stride: 4 x loads + 3 (43, 27, 19 for subsequences of 128, 64, 32 bytes).
+#define HJ_LIST_MAX_LOADS 10
+#define HJ_LIST_ROW_MAX (4*HJ_LIST_MAX_LOADS + 3)
+static __device__ __forceinline__ uint32_t hj_list_loads(const hj_args &A) { return ((1u << A.sub_log2) + 15u + 12u + 15u) >> 4; }
+
+// ROWS: the entries' rows in LDS (hj_lds_reg_src: a step of the chain at its shortest) or read from global memory as
+// the run goes (hj_gmem_src: 12 KB of LDS per workgroup instead of 56, for the FIRST list round of a batch that fills
+// the device — a fifth of all subsequences, bound by how many waves a CU holds, not by one lane's speed).
+template <class Tab, bool ROWS>
+__global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_sync_list(const hj_args A, int round, int max_iters) {
+  constexpr int NB = HJ_LIST_BLOCK;
+  __shared__ __attribute__((aligned(16))) Tab lds_tabs;
+  __shared__ uint32_t lds_win_mem[ROWS ? 1 + NB*HJ_LIST_ROW_MAX + 8 : 1];      // [0]: the dword "before" row 0
+  uint32_t *lds_win = lds_win_mem + 1;
+  __shared__ hj_image s_im;
+  const uint32_t img = blockIdx.y, t = threadIdx.x, lane = t & 63u;
+  if (blockIdx.x == 0 && t == 0) *hj_list_counter(A, round + 2, img) = 0;
+  const uint32_t n_in = *hj_list_counter(A, round, img);
+  if (blockIdx.x*NB >= n_in) return;
+  uint32_t *cnt_out = hj_list_counter(A, round + 1, img);
+  const hj_image im = A.images[img];             // scalar fields only; indexed ones via s_im
+  const uint32_t *list_in = A.list + (size_t)(round & 1)*A.list_stride + im.sub0;
+  uint32_t *list_out = A.list + (size_t)((round + 1) & 1)*A.list_stride + im.sub0;
+  // solo: the image's whole list is this workgroup's — its lanes walk their chains on, step after step
+  const int steps = n_in <= (uint32_t)NB ? max_iters : 1;
+  const uint8_t *scan = A.scan + im.scan_off;
+  const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;
+  const uint32_t sub = 1u << A.sub_log2;
+  const uint32_t nload = hj_list_loads(A), sdw = 4u*nload + 3u;
+  typedef hj_v4u __attribute__((may_alias)) v4u_alias;
+  hj_v4u v[ROWS ? HJ_LIST_MAX_LOADS : 1];
+  auto load_row = [&](uint32_t first) {          // sixteen-byte loads: every image's scan starts on a multiple of 16 and is followed by its pad
+#pragma unroll
+    for (uint32_t j = 0; j < HJ_LIST_MAX_LOADS; j++) {
+      if (ROWS && j < nload) {
+        uint32_t a = (first & ~15u) + 16u*j;
+        if (a + 16u > padded) a = padded - 16u;
+        v[j] = *reinterpret_cast<const v4u_alias *>(scan + a);
+      }
+    }
+  };
+  // what the first chunk's lanes run: looked up while the tables are on their way into LDS
+  uint32_t chunk = blockIdx.x;
+  uint32_t li = 0, g = 0, sidx = 0, first = 0, seg_end = 0, left = 0;   // left: subsequences of the segment behind this one
+  uint64_t start = 0;
+  auto describe = [&](uint32_t c) -> bool {
+    if (c*NB + t >= n_in) return false;
+    li = list_in[c*NB + t];
+    g = im.sub0 + li;
+    const uint32_t si = A.sub_seg[g];
+    const hj_segment sg = A.segs[im.seg0 + si];
+    const uint32_t i = li - sg.sub0;
+    first = sg.start + (i << A.sub_log2);
+    seg_end = sg.end;
+    left = sg.nsub - 1u - i;
+    sidx = g + im.seg0 + si;
+    start = A.S[sidx];
+    load_row(first);
+    return true;
+  };
+  bool active = describe(chunk);
+  hj_stage_image(&s_im, A.images + img);
+  hj_stage_tables<NB>(&lds_tabs, A.tables + img, A.wide ? A.wide + img : nullptr);
+  __syncthreads();
+  const uint32_t slot_tables = hj_slot_tables(s_im);
+  bool left_work = false;
+  for (;;) {
+    for (int it = 0; ; it++) {
+      bool moved = false;
+      if (active) {
+        const bool last = left == 0u;
+        uint32_t stop = first + sub;
+        if (stop > seg_end) stop = seg_end;
+        const uint64_t next_in = last ? 0ull : A.S[sidx + 1];       // (this lane is the only one that ever writes it)
+        hj_run r;
+        if (ROWS) {
+          uint32_t *row = lds_win + t*sdw;
+#pragma unroll
+          for (uint32_t j = 0; j < HJ_LIST_MAX_LOADS; j++) {
+            if (j < nload) {
+              row[4*j] = __builtin_bswap32(v[j].x); row[4*j + 1] = __builtin_bswap32(v[j].y);
+              row[4*j + 2] = __builtin_bswap32(v[j].z); row[4*j + 3] = __builtin_bswap32(v[j].w);
+            }
+          }
+          if (!last && it + 1 < steps) load_row(first + sub);       // the successor's row, on its way while this one is decoded
+          hj_lds_reg_src src;
+          src.base = row;
+          src.bit0 = (first & ~15u) << 3;
+          r = hj_sync_decode<hj_lds_reg_src, false, Tab>(src, s_im, &lds_tabs, start, (uint64_t)stop*8, last, slot_tables);
+        }
+        else {
+          hj_gmem_src src;
+          src.scan32 = reinterpret_cast<const uint32_t *>(scan);
+          src.dw0 = first >> 2;
+          src.ndw = padded >> 2;
+          r = hj_sync_decode<hj_gmem_src, false, Tab>(src, s_im, &lds_tabs, start, (uint64_t)stop*8, last, slot_tables);
+        }
+        A.R[g] = r.nblocks;
+        A.last_in[g] = start;
+        if (!last && next_in != r.end_state) { A.S[sidx + 1] = r.end_state; moved = true; }
+        // on to the successor: the same segment, the next 2^sub_log2 bytes
+        start = r.end_state;
+        li++; g++; sidx++; first += sub; left--;
+      }
+      active = moved;
+      if (it + 1 >= steps) break;
+      if (!__syncthreads_or(active)) break;                  // (also orders a step's stores before the next step's loads)
+    }
+    // chains that still move go onto the next round's list
+    const unsigned long long m = __ballot(active);
+    if (m != 0ull) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(cnt_out, (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (active) list_out[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = li;
+      left_work = true;
+    }
+    chunk += gridDim.x;
+    if (chunk*NB >= n_in) break;
+    active = describe(chunk);                                // (solo: one chunk; otherwise one step per chunk, rows are private)
+  }
+  if (left_work && lane == 0) atomicOr(&A.ran[round], 1u);
+}
+
 #define HJ_SCAN_BLOCK 1024          /* threads per chunk */
 #define HJ_SCAN_ITEMS 4             /* consecutive lanes summed by one thread */
 #define HJ_SCAN_CHUNK_LOG2 12       /* HJ_SCAN_BLOCK*HJ_SCAN_ITEMS lanes per workgroup */
@@ -1083,6 +1260,7 @@ __global__ __launch_bounds__(256) void hj_init_states(const hj_args A, uint32_t 
   // found, or nothing)
   if (blockIdx.x == 0 && blockIdx.y == 0) {
     for (int i = threadIdx.x; i < HJ_MAX_ROUNDS; i += 256) A.ran[i] = 0;
+    if (A.list_count) for (int i = threadIdx.x; i < 4*A.nimages; i += 256) A.list_count[i*HJ_LIST_CSTRIDE] = 0;
     for (int i = threadIdx.x; i < A.nimages; i += 256) A.errors[i] = verdicts0 ? verdicts0[i] : 0u;
   }
   int lo = 0, hi = A.nimages - 1;                           // image of this (batch-global) segment
@@ -1140,6 +1318,27 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
     hipLaunchKernelGGL(hj_sync_round<hj_lds_reg_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
   }
   else hipLaunchKernelGGL(hj_sync_round<hj_lds_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
+  return (int)hipGetLastError();
+}
+extern "C" int hj_launch_list_round(const hj_args *A, int max_nsub, int round, int max_iters, int rebuild, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned groups = (unsigned)((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK);
+  if (rebuild) {
+    // (the lists are made from the states; rebuild == 2: whatever an earlier round left on them is dropped first —
+    // hj_init_states has zeroed the counters of a decode's first list round)
+    if (rebuild > 1 && hipMemsetAsync(A->list_count, 0, 4*sizeof(uint32_t)*HJ_LIST_CSTRIDE*(size_t)A->nimages, st) != hipSuccess) return 1;
+    hipLaunchKernelGGL(hj_list_build, dim3(groups, A->nimages), dim3(256), 0, st, *A, round);
+  }
+  // A fifth of the lanes still moves after the first round's three steps, a third of those a step later: the first
+  // list round of a batch that fills the device gets a workgroup per 4 groups and reads its rows from global memory,
+  // the later ones one per 8 groups (grid-stride beyond that) with the rows in LDS.
+  const bool crowded = rebuild == 1 && !A->wide && (size_t)groups*(size_t)A->nimages >= 1024;
+  unsigned gx = crowded ? (groups + 3)/4 : (groups + 7)/8;
+  if (gx > 64 && !crowded) gx = 64;
+  const dim3 grid(gx, A->nimages);
+  if (A->wide) hipLaunchKernelGGL((hj_sync_list<hj_ltables_wide, true>), grid, dim3(HJ_LIST_BLOCK), 0, st, *A, round, max_iters);
+  else if (crowded) hipLaunchKernelGGL((hj_sync_list<hj_ltables, false>), grid, dim3(HJ_LIST_BLOCK), 0, st, *A, round, max_iters);
+  else hipLaunchKernelGGL((hj_sync_list<hj_ltables, true>), grid, dim3(HJ_LIST_BLOCK), 0, st, *A, round, max_iters);
   return (int)hipGetLastError();
 }
 extern "C" int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream) {
