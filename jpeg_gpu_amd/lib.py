@@ -631,11 +631,15 @@ def gpu_unpack(g, packs, indexes, pack_words=None):
         d_pack.free(); d_idx.free(); d_coef.free()
 
 
-def gpu_entropy_decode(jpegs, device_unstuff=None):
-    """Decode the scans of same-geometry JPEGs on the GPU -> (geom, (n, coef_shorts) int16, rounds)."""
+def gpu_entropy_decode(jpegs, device_unstuff=None, shared=0):
+    """Decode the scans of same-geometry JPEGs on the GPU -> (geom, (n, coef_shorts) int16, rounds).
+    shared=1: the batch is told that other decodes share the device (jga_huff_set_device_shared) — whatever its size
+    it then takes the kernels of a batch that fills the device: the list rounds from the second launch on."""
     hb = HuffBatch(len(jpegs), sum(len(j) for j in jpegs) + 4096, device_unstuff)
     try:
         g = hb.prepare(jpegs)
+        if shared:
+            L.jga_huff_set_device_shared(hb.ptr, 1)
         stride = _align(g.coef_shorts * 2) // 2
         d = DeviceBuffer(stride * 2 * len(jpegs))
         try:
