@@ -278,20 +278,60 @@ HJ_HD uint32_t hj_slot_tables(const hj_image &im) {
   for (int q = 0; q < im.nslots; q++) bits |= (uint32_t)im.comp_tbl[im.slot_comp[q]] << (2*q);
   return bits;
 }
+// The lookup with the table NUMBER already chosen (0, 1: the DC tables, 2, 3: the AC tables).
+HJ_HD uint32_t hj_lookup_t(const hj_tables *T, uint32_t t, uint32_t w) {
+  const uint32_t idx = w >> (32 - HJ_FAST_BITS);
+  uint32_t e = t < 2u ? (uint32_t)T->dc[t][idx] : T->ac[t - 2u][idx];
+  if ((e & 31u) == 0u) e = T->l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+  return e;
+}
+HJ_HD uint32_t hj_lookup_t(const hj_ltables *T, uint32_t t, uint32_t w) {
+  uint32_t e = (&T->tab[0][0])[(t << HJ_FAST_BITS) | (w >> (32 - HJ_FAST_BITS))];
+  if ((e & 31u) == 0u) e = T->l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+  return e;
+}
+HJ_HD uint32_t hj_lookup_t(const hj_ltables_wide *T, uint32_t t, uint32_t w) {
+  const uint32_t idx = t < 2u ? (t << HJ_FAST_BITS) | (w >> (32 - HJ_FAST_BITS))
+   : (2u << HJ_FAST_BITS) + (((t - 2u) << HJ_WIDE_BITS) | (w >> (32 - HJ_WIDE_BITS)));
+  uint32_t e = (&T->dc[0][0])[idx];
+  if ((e & 31u) == 0u) e = T->l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+  return e;
+}
+// The table numbers of every MCU slot as two words of 2-bit fields — the DC table's number (0, 1) and the AC table's
+// (2, 3) of slot c at bits [2c, 2c + 1] — so that a symbol's table is one select and one bit-field extract (round 5:
+// seven vector instructions of the run's ~41 per step were spent on getting it out of hj_slot_tables' bits).
+struct hj_slot_words { uint32_t dc, ac; };
+HJ_HD hj_slot_words hj_slot_table_words(const hj_image &im) {
+  hj_slot_words W;
+  W.dc = 0; W.ac = 0;
+  for (int q = 0; q < im.nslots; q++) {
+    const uint32_t two = im.comp_tbl[im.slot_comp[q]];
+    W.dc |= (two & 1u) << (2*q);
+    W.ac |= (2u | ((two >> 1) & 1u)) << (2*q);
+  }
+  return W;
+}
+HJ_HD uint32_t hj_field2(uint32_t word, uint32_t at) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ubfe(word, at, 2u);
+#else
+  return (word >> at) & 3u;
+#endif
+}
 template <class Src, bool LITE = false, class Tab = hj_tables>
 HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
- uint64_t start, uint64_t stop_bit, bool last, uint32_t slot_tbl_bits) {
-  const int nslots = im.nslots;
+ uint64_t start, uint64_t stop_bit, bool last, const hj_slot_words &W) {
+  const uint32_t c2end = 2u*(uint32_t)im.nslots;
   typename hj_reader_of<Src>::type br;
   hj_run r;
-  int k = hj_k(start), c = hj_slot(start);
+  int k = hj_k(start);
+  uint32_t c2 = 2u*(uint32_t)hj_slot(start);               // twice the MCU slot: where its fields lie in wdc / wac
   uint32_t nblocks = 0;
+  const uint32_t wdc = W.dc, wac = W.ac;
   br.init(src, hj_pos(start), stop_bit);
-  int tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
   while (br.before_stop()) {
     const uint32_t w = br.window();
-    const int isdc = k == 0;
-    const uint32_t e = hj_lookup(T, isdc, tbl, w);
+    const uint32_t e = hj_lookup_t(T, hj_field2(k == 0 ? wdc : wac, c2), w);
     // several AC symbols at once, unless one of them (other than the last) ends the block — or
     // the run: a run ends at the FIRST symbol boundary at or past its stop bit whichever way it
     // got there (runs that have fallen into step must hand on identical states), so a pack is
@@ -301,21 +341,20 @@ HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
     const int kn = k + (packed ? HJ_P_ADV(e) : HJ_E_ADV(e));   // DC: 1; AC: past the run(s); EOB: >= 64
     const int done = kn >= 64;
     if (!LITE) nblocks += (uint32_t)done;
-    c = done ? (c + 1 == nslots ? 0 : c + 1) : c;
-    tbl = (int)((slot_tbl_bits >> (2*c)) & 3u);
+    c2 = done ? (c2 + 2u == c2end ? 0u : c2 + 2u) : c2;
     k = done ? 0 : kn;
   }
   // (k == 0 with a block counted: the run's final symbol completed it)
   if (last && k == 0 && nblocks > 0 && br.tell() > stop_bit) nblocks--;   // ...with bits the segment does not have
   r.nblocks = nblocks;
-  r.end_state = hj_pack(br.tell(), c, k);
+  r.end_state = hj_pack(br.tell(), (int)(c2 >> 1), k);
   return r;
 }
 
 template <class Src, bool LITE = false, class Tab = hj_tables>
 HJ_HD hj_run hj_sync_decode(const Src &src, const hj_image &im, const Tab *T,
  uint64_t start, uint64_t stop_bit, bool last = false) {
-  return hj_sync_decode<Src, LITE, Tab>(src, im, T, start, stop_bit, last, hj_slot_tables(im));
+  return hj_sync_decode<Src, LITE, Tab>(src, im, T, start, stop_bit, last, hj_slot_table_words(im));
 }
 
 // The final pass as the HOST states it (tools/huff_emul.cpp, tests/test_huff_emul.py): every

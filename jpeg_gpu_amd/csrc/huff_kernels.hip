@@ -310,7 +310,7 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
   // moved into dense waves (any lane can decode any subsequence of the staged window),
   // so the work follows the number of runs, not iterations x 256.
   const uint32_t lane = t & 63, wave = t >> 6;
-  const uint32_t slot_tables = hj_slot_tables(s_im);
+  const hj_slot_words slot_tables = hj_slot_table_words(s_im);
   // (only a few iterations: the long, thin tail of the propagation is left to later
   // launches, which cost one short run each instead of keeping this group resident)
   for (int it = 0; it < max_iters; it++) {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_a
   if (__ballot(any) == 0ull) return;
   const uint8_t *scan = A.scan + im.scan_off;
   const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;
-  const uint32_t slot_tables = hj_slot_tables(s_im);
+  const hj_slot_words slot_tables = hj_slot_table_words(s_im);
   for (int it = 0; it < max_iters; it++) {
     // the lanes that moved, in order
     uint32_t total = 0;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_sync_list(const hj_args A, i
   hj_stage_image(&s_im, A.images + img);
   hj_stage_tables<NB>(&lds_tabs, A.tables + img, A.wide ? A.wide + img : nullptr);
   __syncthreads();
-  const uint32_t slot_tables = hj_slot_tables(s_im);
+  const hj_slot_words slot_tables = hj_slot_table_words(s_im);
   bool left_work = false;
   for (;;) {
     for (int it = 0; ; it++) {

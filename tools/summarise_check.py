@@ -1,4 +1,4 @@
-"""gpurun_out/<tag>/ (tools/archive/r2_check.sh, tools/archive/r3_check.sh, tools/r4_check.sh) -> profiles/<name>_rocprof_summary.md,
+"""gpurun_out/<tag>/ (tools/archive/r2_check.sh, tools/archive/r3_check.sh, tools/round_check.sh) -> profiles/<name>_rocprof_summary.md,
 profiles/<name>_bench.json, profiles/pmc_latest.json (+ round 3: <name>_configs_bench.txt,
 <name>_huffman_kernels.txt, <name>_huffman_pmc.md, <name>_harness_fps.txt).
 Usage: python tools/summarise_check.py r3c r3"""
@@ -42,7 +42,7 @@ if roof:
                     dc["write_GBps"], dc["read_GBps"] + dc["write_GBps"], dc.get("kernel_copy_GBps_by_grid"), dc.get("torch_copy_GBps"), rf["device_copy_GBps"]), ""]
 out += ["## a short bench run", "",
        "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 12 --warmup 3 --batch 128 --no-cpu --no-e2e "
-       "--no-pack --no-other --no-gpu-entropy --no-configs --no-measure-traffic --scale-proxy 0` (tools/r4_check.sh; rounds 2-3: "
+       "--no-pack --no-other --no-gpu-entropy --no-configs --no-measure-traffic --scale-proxy 0` (tools/round_check.sh; rounds 2-3: "
        "tools/archive/r2_check.sh, r3_check.sh without `--batch`): the end-to-end pipeline legs (12 steps of 128 files through 8 lanes in groups "
        "of 32, pageable then pinned files, plus set-up and warm-up batches) followed by the roofline leg "
        "(launches of the fused kernel on 48 resident images).  Under the pipeline several groups' kernels "
