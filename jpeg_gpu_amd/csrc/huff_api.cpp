@@ -76,7 +76,9 @@ struct jga_huff_batch {
   hipEvent_t arrived;          // the event that says "the last prepare()'s bytes are on the device"
   bool qtab_on_device;         // the last prepare() put the quantisers into the blob (jga_huff_qtabs_device)
   size_t off_qtab;
-  bool wide;                   // the last prepare() built and uploaded the 12-bit AC tables (a small batch on a device of its own)
+  bool wide;                   // the last prepare() built and uploaded the 12-bit AC tables: one set per image (a small batch on a
+  bool wide_shared;            // device of its own: every round takes them), or ONE set for a batch whose images all bring the same
+                               // Huffman tables (the list rounds of a batch that fills or shares the device take it)
   size_t off_wide;
   // a decode in two halves (jga_huff_decode_split_begin / _end): what _begin queued
   struct {
@@ -126,6 +128,24 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1)/a*a; }
 static bool wants_wide(const jga_huff_batch *b, int n, uint64_t scan_bytes, int sub_log2) {
   if (b->device_shared || n > HJ_WIDE_MAX_IMAGES || jga_tune("JGA_HUFF_NO_WIDE")) return false;
   return (scan_bytes >> sub_log2) + 256u*(uint64_t)n <= 256u*256u;     // <= 256 workgroups of 256 subsequences: one per CU
+}
+
+// ... and for every other batch whose images all bring the same tables (one encoder: the usual case) ONE set goes up
+// with the descriptors (32 KB) for the list rounds, whose workgroups are few: a quarter fewer look-ups per step of the
+// chain.  Decides b->wide / b->wide_shared and builds what is wanted.
+static void choose_wide(jga_huff_batch *b, std::vector<hj_prepared> &prep, int n, uint64_t scan_bytes) {
+  b->wide = wants_wide(b, n, scan_bytes, b->sub_log2);
+  b->wide_shared = false;
+  if (b->wide) {
+    for (int i = 0; i < n; i++) hj_prepare_wide(&prep[(size_t)i]);
+    return;
+  }
+  if (b->sub_log2 > HJ_SUB_LOG2_MAX || jga_tune("JGA_HUFF_NO_WIDE") || jga_tune("JGA_HUFF_NO_SHARED_WIDE")) return;
+  for (int i = 1; i < n; i++) {
+    if (memcmp(&prep[(size_t)i].tabs, &prep[0].tabs, sizeof(hj_tables)) != 0) return;
+  }
+  hj_prepare_wide(&prep[0]);
+  b->wide = b->wide_shared = true;
 }
 
 extern "C" {
@@ -253,6 +273,7 @@ static void fill_sync_args(const jga_huff_batch *b, hj_args &A) {
   A.sub_seg = (const uint32_t *)(b->d_blob + b->off_subseg);
   A.tables = (const hj_tables *)(b->d_blob + b->off_tables);
   A.wide = b->wide ? (const hj_wide_ac *)(b->d_blob + b->off_wide) : NULL;
+  A.wide_shared = b->wide && b->wide_shared;
   A.scan = b->d_blob + b->off_scan;
   A.S = (uint64_t *)(b->d_blob + b->off_S);
   A.last_in = b->d_last_in;
@@ -365,8 +386,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     uint64_t raw_total = 0;
     for (int i = 0; i < n; i++) raw_total += prep[i].avail;
     b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(raw_total, prep[0].im.nslots, prep[0].geom.restart_interval);
-    b->wide = wants_wide(b, n, raw_total, b->sub_log2);
-    for (int i = 0; i < n && b->wide; i++) hj_prepare_wide(&prep[i]);
+    choose_wide(b, prep, n, raw_total);
   }
   std::vector<hj_unstuff_image> uimg((size_t)n);
   std::vector<uint32_t> sub0v((size_t)n), seg0v((size_t)n);
@@ -409,7 +429,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   b->off_info = q; q += align_up(sizeof(hj_unstuff_info)*n, 256);
   b->off_perr = q; q += align_up(4*(size_t)n, 256);
   b->off_qtab = q; q += align_up(384*(size_t)n, 256);
-  b->off_wide = q; q += b->wide ? align_up(sizeof(hj_wide_ac)*(size_t)n, 256) : 0;
+  b->off_wide = q; q += b->wide ? align_up(sizeof(hj_wide_ac)*(size_t)(b->wide_shared ? 1 : n), 256) : 0;
   b->upload_size = q;                                        // what crosses PCIe
   b->off_scan = q; q += raw_bytes;                           // the clean streams, same offsets as the raw ones
   b->off_segs = q; q += align_up(sizeof(hj_segment)*total_seg, 256);
@@ -468,7 +488,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
       p.im.scan_len = 0;
       images[i] = p.im;
       tables[i] = p.tabs;
-      if (b->wide) memcpy(b->h_blob + b->off_wide + sizeof(hj_wide_ac)*(size_t)i, p.wide.data(), sizeof(hj_wide_ac));
+      if (b->wide && (!b->wide_shared || i == 0)) memcpy(b->h_blob + b->off_wide + sizeof(hj_wide_ac)*(size_t)i, p.wide.data(), sizeof(hj_wide_ac));
       memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
     }
   };
@@ -585,8 +605,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       // subsequence length of this batch (the stuffed length is close enough to the clean one)
       b->sub_log2 = b->force_sub_log2 ? b->force_sub_log2 : hj_choose_sub_log2(o, prep[0].im.nslots, prep[0].geom.restart_interval);
       for (int i = 0; i < n; i++) prep[i].sub_log2 = b->sub_log2;
-      b->wide = wants_wide(b, n, o, b->sub_log2);
-      for (int i = 0; i < n && b->wide; i++) hj_prepare_wide(&prep[i]);
+      choose_wide(b, prep, n, o);
       b->off_scan = 0;
       b->scan_bytes = align_up(o, 256);
       if (fatal.load()) stop.store(1);
@@ -629,7 +648,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       b->off_segs = o; o += align_up(sizeof(hj_segment)*total_seg, 256);
       b->off_tables = o; o += align_up(sizeof(hj_tables)*n, 256);
       b->off_qtab = o; o += align_up(384*(size_t)n, 256);
-      b->off_wide = o; o += b->wide ? align_up(sizeof(hj_wide_ac)*(size_t)n, 256) : 0;
+      b->off_wide = o; o += b->wide ? align_up(sizeof(hj_wide_ac)*(size_t)(b->wide_shared ? 1 : n), 256) : 0;
       b->upload_size = o;           // what crosses PCIe; the rest is written by hj_init_states
       b->off_subseg = o; o += align_up(4*total_sub, 256);
       b->off_S = o; o += align_up(8*(total_sub + total_seg), 256);
@@ -654,7 +673,7 @@ JGA_EXPORT int jga_huff_prepare(jga_huff_batch *b, const unsigned char *const *j
       p.im.scan_off = scan_off[i];
       images[i] = p.im;
       tables[i] = p.tabs;
-      if (b->wide) memcpy(b->h_blob + b->off_wide + sizeof(hj_wide_ac)*(size_t)i, p.wide.data(), sizeof(hj_wide_ac));
+      if (b->wide && (!b->wide_shared || i == 0)) memcpy(b->h_blob + b->off_wide + sizeof(hj_wide_ac)*(size_t)i, p.wide.data(), sizeof(hj_wide_ac));
       memcpy(&b->qtab[(size_t)i*192], p.qtab, sizeof(p.qtab));
       for (size_t si = 0; si < p.segs.size(); si++) segs[seg0 + si] = p.segs[si];
     }
@@ -969,7 +988,7 @@ static int queue_tail(jga_huff_batch *b, const hj_args &A, bool split, hipStream
 static int queue_rounds(jga_huff_batch *b, const decode_plan &P, int &round, int count, hipStream_t st, bool tail_follows = false) {
   for (int k = 0; k < count && round < HJ_MAX_ROUNDS; k++, round++) {
     if (round >= P.list_from) {
-      if (hj_launch_list_round(&P.A, (int)b->max_nsub, round, P.it_list, b->list_state, st)) return jga_fail("huff: launch failed");
+      if (hj_launch_list_round(&P.A, (int)b->max_nsub, round, round - P.list_from, P.it_list, b->list_state, st)) return jga_fail("huff: launch failed");
       b->list_state = 0;
       if (jga_tune("JGA_HUFF_LIST_STATS")) {                   // (tuning build: what the round ran and what it left, synchronously)
         std::vector<uint32_t> c((size_t)4*HJ_LIST_CSTRIDE*(size_t)b->nimages);

@@ -12,7 +12,8 @@ typedef struct hj_args {
   const hj_segment *segs;      /* all images' segments, image-major */
   const uint32_t *sub_seg;     /* per subsequence: segment index local to its image */
   const hj_tables *tables;     /* [nimages] */
-  const hj_wide_ac *wide;      /* [nimages] 12-bit AC tables, or NULL: the dense rounds then run with the 9-bit ones */
+  const hj_wide_ac *wide;      /* 12-bit AC tables, or NULL: [nimages] of them (every round takes them), or — wide_shared — ONE set */
+  int wide_shared;             /* for all images, which only the list rounds take (the dense rounds then run with the 9-bit ones) */
   const uint8_t *scan;         /* all images' entropy-coded bytes */
   uint64_t *S;                 /* states: nsub + nseg entries per image */
   uint64_t *last_in;           /* start state of each lane's latest run */
@@ -51,8 +52,9 @@ int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_
 int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
 /* A LIST round: only the subsequences whose start state moved run, packed into dense waves from a work list per image
  * (rebuild != 0: the lists are made afresh from the states first — the first list round of a decode, or after the host
- * changed states).  An image whose list fits one workgroup is iterated inside it, up to max_iters steps. */
-int hj_launch_list_round(const hj_args *A, int max_nsub, int round, int max_iters, int rebuild, void *stream);
+ * changed states; ordinal: how many list rounds of this decode came before).  An image whose list fits one workgroup is
+ * iterated inside it, up to max_iters steps. */
+int hj_launch_list_round(const hj_args *A, int max_nsub, int round, int ordinal, int max_iters, int rebuild, void *stream);
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);
 int hj_launch_write(const hj_args *A, int max_nsub, void *stream);

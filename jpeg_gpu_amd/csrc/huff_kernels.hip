@@ -234,7 +234,7 @@ static __device__ __forceinline__ bool hj_prologue(const hj_args &A, const hj_im
   // LDS this saves keep the round at three workgroups per CU)
   const uint32_t base0 = (uint32_t)__shfl((int)my_start, 0);   // wave 0 holds lane 0 of the group
   if (threadIdx.x == 0) *lds_start0 = base0;
-  hj_stage_tables<NB>(lds_tabs, A.tables + blockIdx.y, A.wide ? A.wide + blockIdx.y : nullptr);
+  hj_stage_tables<NB>(lds_tabs, A.tables + blockIdx.y, A.wide && !A.wide_shared ? A.wide + blockIdx.y : nullptr);
   __syncthreads();
   lds_start[threadIdx.x] = in_range ? (uint16_t)(my_start - *lds_start0) : (uint16_t)0;
   __syncthreads();
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_sync_list(const hj_args A, i
   };
   bool active = describe(chunk);
   hj_stage_image(&s_im, A.images + img);
-  hj_stage_tables<NB>(&lds_tabs, A.tables + img, A.wide ? A.wide + img : nullptr);
+  hj_stage_tables<NB>(&lds_tabs, A.tables + img, A.wide ? A.wide + (A.wide_shared ? 0u : img) : nullptr);
   __syncthreads();
   const hj_slot_words slot_tables = hj_slot_table_words(s_im);
   bool left_work = false;
@@ -1311,7 +1311,7 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
     const dim3 sgrid((grid.x + HJ_SPARSE_GROUPS - 1)/HJ_SPARSE_GROUPS, grid.y);
     hipLaunchKernelGGL(hj_sync_sparse, sgrid, dim3(64*HJ_SPARSE_GROUPS), 0, (hipStream_t)stream, *A, round, max_iters);
   }
-  else if (sparse < 0 && A->wide) {              // ... and with the 12-bit AC tables (small batches: hj_wide_ac)
+  else if (sparse < 0 && A->wide && !A->wide_shared) {   // ... and with the 12-bit AC tables (small batches: hj_wide_ac)
     hipLaunchKernelGGL((hj_sync_round<hj_lds_reg_src, hj_ltables_wide>), grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
   }
   else if (sparse < 0) {                         // dense, rows read through registers
@@ -1320,7 +1320,7 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
   else hipLaunchKernelGGL(hj_sync_round<hj_lds_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
   return (int)hipGetLastError();
 }
-extern "C" int hj_launch_list_round(const hj_args *A, int max_nsub, int round, int max_iters, int rebuild, void *stream) {
+extern "C" int hj_launch_list_round(const hj_args *A, int max_nsub, int round, int ordinal, int max_iters, int rebuild, void *stream) {
   hipStream_t st = (hipStream_t)stream;
   const unsigned groups = (unsigned)((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK);
   if (rebuild) {
@@ -1332,11 +1332,21 @@ extern "C" int hj_launch_list_round(const hj_args *A, int max_nsub, int round, i
   // A fifth of the lanes still moves after the first round's three steps, a third of those a step later: the first
   // list round of a batch that fills the device gets a workgroup per 4 groups and reads its rows from global memory,
   // the later ones one per 8 groups (grid-stride beyond that) with the rows in LDS.
-  const bool crowded = rebuild == 1 && !A->wide && (size_t)groups*(size_t)A->nimages >= 1024;
+  // The 12-bit tables (85 KB of LDS per workgroup: one per CU) where the expected workgroups — a fifth of the groups,
+  // a third of that per list round since — are at most one per CU; a small batch that brought a set per image takes
+  // them in every round.
+  const size_t all_groups = (size_t)groups*(size_t)A->nimages;
+  const bool crowded = rebuild == 1 && (!A->wide || A->wide_shared) && all_groups >= 1024;
+  bool wide = A->wide != nullptr;
+  if (wide && A->wide_shared) {
+    double expect = 0.205*(double)all_groups;
+    for (int k = 0; k < ordinal && k < 8; k++) expect /= 3.1;
+    wide = !crowded && expect <= 256.0;
+  }
   unsigned gx = crowded ? (groups + 3)/4 : (groups + 7)/8;
   if (gx > 64 && !crowded) gx = 64;
   const dim3 grid(gx, A->nimages);
-  if (A->wide) hipLaunchKernelGGL((hj_sync_list<hj_ltables_wide, true>), grid, dim3(HJ_LIST_BLOCK), 0, st, *A, round, max_iters);
+  if (wide) hipLaunchKernelGGL((hj_sync_list<hj_ltables_wide, true>), grid, dim3(HJ_LIST_BLOCK), 0, st, *A, round, max_iters);
   else if (crowded) hipLaunchKernelGGL((hj_sync_list<hj_ltables, false>), grid, dim3(HJ_LIST_BLOCK), 0, st, *A, round, max_iters);
   else hipLaunchKernelGGL((hj_sync_list<hj_ltables, true>), grid, dim3(HJ_LIST_BLOCK), 0, st, *A, round, max_iters);
   return (int)hipGetLastError();
