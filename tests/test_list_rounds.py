@@ -114,3 +114,22 @@ def test_list_rounds_and_dense_rounds_give_the_same_planes_on_a_full_size_batch(
     assert np.array_equal(alone, shared)
     for i in range(3):
         assert np.array_equal(shared[i], oracle_quant(orc, datas[i])), i
+
+
+@pytest.mark.parametrize("sampling", ["420", "444"])
+def test_list_rounds_with_shared_and_with_mixed_tables(gpu, orc, synth, sampling):
+    """Batches of five and seven frames (beyond the per-image 12-bit tables of small batches): all with the Annex-K
+    tables — ONE set of 12-bit AC tables goes up and the later list rounds take it — and mixed with files that code
+    luma with the chroma AC table (no shared set: 9-bit tables throughout).  The oracle's QUANT planes every time,
+    with the scan cleaned up on the host and on the device."""
+    files = [synth.synthetic_jpeg(1280, 720, sampling, quality=q, restart_interval=ri, seed=q, flags=fl)
+             for q, ri, fl in ((90, 0, 0), (60, 0, synth.SWAP_AC), (35, 7, 0), (90, 0, synth.SWAP_AC), (75, 0, 0),
+                               (50, 0, 0), (82, 0, 0))]
+    want = [oracle_quant(orc, f) for f in files]
+    same = [0, 4, 5, 6, 0, 4, 5]                 # the Annex-K tables only, no restart markers
+    mixed = [0, 1, 4, 3, 5, 6, 1]
+    for order in (same[:5], same, mixed[:5], mixed):
+        for unstuff in (False, True):
+            _, coefs, _ = gpu.gpu_entropy_decode([files[i] for i in order], device_unstuff=unstuff, shared=1)
+            for k, i in enumerate(order):
+                assert np.array_equal(coefs[k], want[i]), (sampling, order, unstuff, k)
