@@ -40,6 +40,8 @@ struct jga_huff_batch {
   uint32_t *d_lcount;          // [4][max_images] their lengths, HJ_LIST_CSTRIDE words apart
   int16_t *d_dc;               // DC differences (scan order) | DC values (by buffer slot) of the current batch
   size_t dc_cap;               // entries of each half
+  uint32_t *d_blkpos;          // small batches: where every block starts (hj_block_starts -> hj_write_blocks), dc_cap entries
+  size_t blkpos_cap;
   uint32_t *d_dcpart;          // chunk totals of the DC prefix sums
   size_t dcpart_cap;           // entries (uint32)
   uint32_t max_seg_mcus, max_segs_image;
@@ -203,6 +205,7 @@ JGA_EXPORT void jga_huff_destroy(jga_huff_batch *b) {
   if (b->d_lcount) (void)hipFree(b->d_lcount);
   if (b->d_part) (void)hipFree(b->d_part);
   if (b->d_dc) (void)hipFree(b->d_dc);
+  if (b->d_blkpos) (void)hipFree(b->d_blkpos);
   if (b->d_dcpart) (void)hipFree(b->d_dcpart);
   if (b->d_ran) (void)hipFree(b->d_ran);                       // (d_errors lies in it)
   if (b->ev_wait) (void)hipEventDestroy(b->ev_wait);
@@ -291,7 +294,7 @@ static void fill_sync_args(const jga_huff_batch *b, hj_args &A) {
 // tuning knobs of the rounds, read once (thread-safe: several pipeline lanes decode at the same time)
 namespace {
 struct round_knobs {
-  int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1, list_from = -1, it_list = 8;
+  int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1, list_from = -1, it_list = 8, by_block_subs = 64*1024;
   round_knobs() {
     const char *e = jga_tune("JGA_HUFF_ITERS");     // "first,later,group": in-group iterations, rounds per host check
     if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
@@ -306,6 +309,8 @@ struct round_knobs {
       if (list_from <= 0) list_from = HJ_MAX_ROUNDS;
       if (it_list < 1) it_list = 1;
     }
+    e = jga_tune("JGA_HUFF_BY_BLOCK");               // largest batch (subsequences) whose write pass runs one lane per block; 0: none (A/B knob)
+    if (e) by_block_subs = atoi(e);
     e = jga_tune("JGA_HUFF_LEAN");                   // 0: the dense kernel's stateless row reader (A/B knob)
     if (e) lean = atoi(e) != 0;
     e = jga_tune("JGA_HUFF_FLUSH");                  // write-pass batching
@@ -885,7 +890,7 @@ static double thread_cpu_ms() {
 struct decode_plan {
   hj_args A;
   int it0, it1, group, sparse_from, assist_after, lean, list_from, it_list;
-  bool speculate;
+  bool speculate, by_block;
 };
 static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride, decode_plan &P) {
   hj_args &A = P.A;
@@ -914,6 +919,20 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
     A.dc_diff = b->d_dc;
     A.dc_val = d_dc ? (int16_t *)d_dc : b->d_dc + b->dc_cap;
     A.dc_stride = (long long)stride;
+    // A small batch alone on the device writes its planes one lane per BLOCK (hj_block_starts + hj_write_blocks): what a
+    // lone frame waits for in hj_write is one lane's ~206 symbols, 90 us of a 1080p frame's 410.
+    const round_knobs &K0 = the_round_knobs();
+    P.by_block = !b->device_shared && b->sub_log2 <= HJ_SUB_LOG2_MAX && b->total_sub <= (uint32_t)K0.by_block_subs;
+    if (P.by_block) {
+      const size_t bneed = stride*(size_t)b->nimages;
+      if (bneed > b->blkpos_cap) {
+        if (b->d_blkpos) (void)hipFree(b->d_blkpos);
+        b->d_blkpos = NULL; b->blkpos_cap = 0;
+        HOK(hipMalloc((void **)&b->d_blkpos, sizeof(uint32_t)*bneed));
+        b->blkpos_cap = bneed;
+      }
+      A.blk_pos = b->d_blkpos;
+    }
   }
   A.coef = (int16_t *)d_coef;
   A.coef_stride = coef_stride;
@@ -972,11 +991,16 @@ static void clear_regions(jga_huff_batch *b, const hj_args &A, hj_clear_args &C)
   // (so are the DC arrays: blocks a damaged stream never reaches, slots that hold no block)
   add(A.dc_diff, sizeof(int16_t)*(uint64_t)A.dc_stride*(uint64_t)b->nimages, 0, 1);
   add(A.dc_val, sizeof(int16_t)*(uint64_t)A.dc_stride*(uint64_t)b->nimages, 0, 1);
+  // (and the block starts of a batch written one lane per block: 0 = "no such block")
+  if (A.blk_pos) add(A.blk_pos, sizeof(uint32_t)*(uint64_t)A.dc_stride*(uint64_t)b->nimages, 0, 1);
 }
 // The tail of a decode: prefix sums, write pass, DC values, the images' verdicts.
 static int queue_tail(jga_huff_batch *b, const hj_args &A, bool split, hipStream_t st) {
   if (hj_launch_scan(&A, (int)b->total_seg, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
-  if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
+  if (A.blk_pos) {
+    if (hj_launch_write_blocks(&A, (int)b->max_nsub, (int)b->geom.coef_blocks, st)) return jga_fail("huff: launch failed");
+  }
+  else if (hj_launch_write(&A, (int)b->max_nsub, st)) return jga_fail("huff: launch failed");
   // DC differences -> DC values; into the planes too unless the caller takes the array itself
   if (hj_launch_dc(&A, (int)b->total_seg, (int)b->max_seg_mcus, b->d_dcpart, split ? 0 : (int)(b->geom.coef_shorts/64), st)) {
     return jga_fail("huff: launch failed");
@@ -1082,6 +1106,7 @@ static int decode_end(jga_huff_batch *b, int *valid_behind) {
       // (the planes: every line the final write pass touches is rewritten or zeroed first)
       HOK(hipMemsetAsync(P.A.dc_diff, 0, sizeof(int16_t)*(size_t)P.A.dc_stride*(size_t)b->nimages, st));
       HOK(hipMemsetAsync(P.A.dc_val, 0, sizeof(int16_t)*(size_t)P.A.dc_stride*(size_t)b->nimages, st));
+      if (P.A.blk_pos) HOK(hipMemsetAsync(P.A.blk_pos, 0, sizeof(uint32_t)*(size_t)P.A.dc_stride*(size_t)b->nimages, st));
     }
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
     // (a batch object whose previous decode needed the walk — the same camera, the same

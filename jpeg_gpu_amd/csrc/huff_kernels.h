@@ -22,6 +22,7 @@ typedef struct hj_args {
   int16_t *dc_diff;            /* image i at dc_diff + i*dc_stride: DC difference of every block, scan order */
   int16_t *dc_val;             /* image i at dc_val + i*dc_stride: DC value of every block, by coefficient-buffer slot */
   long long dc_stride;         /* entries per image (>= coef_shorts/64) */
+  uint32_t *blk_pos;           /* small batches: image i at blk_pos + i*dc_stride, bit position + 1 of every block start, scan order */
   int dc_chunks_per_image;     /* hj_dc_chunks_per_image() */
   uint32_t *scan_part;         /* chunk totals of the prefix-sum pass (hj_scan_part_bytes) */
   uint32_t *ran;               /* [HJ_MAX_ROUNDS] non-zero if any lane ran in that round (a list round: if it left work for the next) */
@@ -58,6 +59,8 @@ int hj_launch_list_round(const hj_args *A, int max_nsub, int round, int ordinal,
 int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, void *stream);
 size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs);
 int hj_launch_write(const hj_args *A, int max_nsub, void *stream);
+/* The write pass of a small batch: block starts (A->blk_pos, zeroed beforehand), then one lane per block. */
+int hj_launch_write_blocks(const hj_args *A, int max_nsub, int blocks_per_image, void *stream);
 /* DC differences (A->dc_diff, left by the write pass) -> DC values by buffer slot (A->dc_val);
  * apply_slots > 0: also written into the planes' DC positions (slots per image).  `part`:
  * 12 bytes x nimages x hj_dc_chunks_per_image(). */

@@ -1107,6 +1107,221 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
   if ((errbits & HJ_W_NOCODE) || errm > 64) atomicOr(&A.errors[blockIdx.y], 2u);
 }
 
+// ---- the write pass of a SMALL batch: one lane per BLOCK (round 5) ---------------------------------------
+// A lone frame's write pass is what ONE lane takes for the ~206 symbols of its subsequence and its ~8 write-outs:
+// 90 us of a 1080p frame's 410 with most of the device idle.  Once the states are settled the places where blocks
+// start are as good as known — a synchronisation run passes every one of them — so a small batch takes two launches
+// instead of hj_write:
+//   hj_block_starts  one lane per subsequence: the counted run once more (12-bit packs when the batch brought them,
+//                    its row in LDS), storing the bit position of every block start it passes at
+//                    blk_pos[block number in scan order] (+ 1: 0 = "no such block", what hj_init_states leaves there);
+//   hj_write_blocks  one lane per block: ~25 symbols from blk_pos, every block whole in its lane's LDS buffer, the
+//                    wave's 64 blocks written out together as 128-byte lines, DC differences as consecutive 2-byte
+//                    stores.  No block is shared between lanes, so nothing is stored piecewise.
+// Same symbols decoded, same error tests (a bit pattern that is no code, a run past coefficient 63) as hj_write.
+template <class Tab>
+__global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_block_starts(const hj_args A) {
+  constexpr int NB = HJ_LIST_BLOCK;
+  __shared__ __attribute__((aligned(16))) Tab lds_tabs;
+  __shared__ uint32_t lds_win_mem[1 + NB*HJ_LIST_ROW_MAX + 8];
+  uint32_t *lds_win = lds_win_mem + 1;
+  __shared__ hj_image s_im;
+  const uint32_t img = blockIdx.y, t = threadIdx.x;
+  const hj_image im = A.images[img];
+  if (blockIdx.x*NB >= im.nsub) return;
+  hj_stage_image(&s_im, A.images + img);
+  hj_stage_tables<NB>(&lds_tabs, A.tables + img, A.wide && !A.wide_shared ? A.wide + img : nullptr);
+  const uint32_t li = blockIdx.x*NB + t;
+  const bool on = li < im.nsub;
+  const uint8_t *scan = A.scan + im.scan_off;
+  const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;
+  const uint32_t nload = hj_list_loads(A), sdw = 4u*nload + 3u;
+  typedef hj_v4u __attribute__((may_alias)) v4u_alias;
+  uint32_t g = 0, si = 0, first = 0, seg_block0 = 0, total = 0, b0 = 0;
+  uint64_t start = 0, stop = 0;
+  bool live = false;
+  if (on) {
+    g = im.sub0 + li;
+    si = A.sub_seg[g];
+    const hj_segment sg = A.segs[im.seg0 + si];
+    const uint32_t i = li - sg.sub0;
+    first = sg.start + (i << A.sub_log2);
+    seg_block0 = sg.mcu0*(uint32_t)im.nslots;
+    total = sg.nmcu*(uint32_t)im.nslots;
+    b0 = A.B[g];
+    live = b0 < total;
+    const uint32_t sidx = g + im.seg0 + si;
+    start = A.S[sidx];
+    stop = i + 1 < sg.nsub ? hj_pos(A.S[sidx + 1]) : (uint64_t)sg.end*8;
+    uint32_t *row = lds_win + t*sdw;
+    hj_v4u v[HJ_LIST_MAX_LOADS];                             // (all of the row's loads in flight before the first is used)
+#pragma unroll
+    for (uint32_t j = 0; j < HJ_LIST_MAX_LOADS; j++) {
+      if (j < nload) {
+        uint32_t a = (first & ~15u) + 16u*j;
+        if (a + 16u > padded) a = padded - 16u;
+        v[j] = *reinterpret_cast<const v4u_alias *>(scan + a);
+      }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < HJ_LIST_MAX_LOADS; j++) {
+      if (j < nload) {
+        row[4*j] = __builtin_bswap32(v[j].x); row[4*j + 1] = __builtin_bswap32(v[j].y);
+        row[4*j + 2] = __builtin_bswap32(v[j].z); row[4*j + 3] = __builtin_bswap32(v[j].w);
+      }
+    }
+  }
+  __syncthreads();                                           // tables, s_im
+  if (!live) return;
+  uint32_t *pos = A.blk_pos + (size_t)img*(size_t)A.dc_stride + seg_block0;
+  const hj_slot_words W = hj_slot_table_words(s_im);
+  const uint32_t c2end = 2u*(uint32_t)im.nslots;
+  hj_lds_reg_src src;
+  src.base = lds_win + t*sdw;
+  src.bit0 = (first & ~15u) << 3;
+  hj_lds_reg_src::reader br;
+  br.init(src, hj_pos(start), stop);
+  int k = hj_k(start);
+  uint32_t c2 = 2u*(uint32_t)hj_slot(start), n = b0;
+  if (k == 0) pos[n] = (uint32_t)hj_pos(start) + 1u;          // the lane starts where a block starts
+  while (br.before_stop()) {                                 // hj_sync_decode's loop, with a store where a block ends
+    const uint32_t w = br.window();
+    const uint32_t e = hj_lookup_t(&lds_tabs, hj_field2(k == 0 ? W.dc : W.ac, c2), w);
+    const bool packed = HJ_P_BITS(e) != 0 && k + HJ_P_PREFIX(e) < 64 && br.room(hj_pack_bits<Tab>::value);
+    br.skip(packed ? HJ_P_BITS(e) : HJ_E_TOT(e));
+    const int kn = k + (packed ? HJ_P_ADV(e) : HJ_E_ADV(e));
+    const bool done = kn >= 64;
+    if (done) {
+      n++;
+      if (n < total) pos[n] = (uint32_t)br.tell() + 1u;      // (the block behind the segment's last one is nobody's)
+    }
+    c2 = done ? (c2 + 2u == c2end ? 0u : c2 + 2u) : c2;
+    k = done ? 0 : kn;
+  }
+}
+
+#define HJ_WB_BLOCK 256
+__global__ __launch_bounds__(HJ_WB_BLOCK) void hj_write_blocks(const hj_args A, uint32_t blocks_per_image) {
+  constexpr int NB = HJ_WB_BLOCK;
+  __shared__ __attribute__((aligned(16))) hj_wtables lds_tabs;
+  __shared__ uint32_t lds_blk[NB*HJ_BLK_STRIDE];
+  __shared__ hj_image s_im;
+  __shared__ uint32_t s_dezz[HJ_DEZZ_EXT];
+  __shared__ uint2 s_slotd[HJ_MAX_SLOTS];
+  const uint32_t img = blockIdx.y, t = threadIdx.x, lane = t & 63u;
+  const hj_image im0 = A.images[img];
+  hj_stage_image(&s_im, A.images + img);
+  if (t < (uint32_t)im0.nslots) s_slotd[t] = hj_block_out::describe(A.images[img], (int)t);
+  if (t < HJ_DEZZ_EXT) s_dezz[t] = t < 64 ? 2u*HJ_DEZZ[t] : 128u;
+  {
+    const hj_tables *T = A.tables + img;
+    for (int i = t; i < 2 << HJ_FAST_BITS; i += NB) {
+      (&lds_tabs.dc[0][0])[i] = hj_wentry((&T->dc[0][0])[i]);
+      (&lds_tabs.ac[0][0])[i] = hj_wentry((&T->ac[0][0])[i] & 0xffffu);
+    }
+    for (int i = t; i < HJ_L2_BLOCKS*128; i += NB) {
+      const uint32_t e = T->l2[i];
+      lds_tabs.l2[i] = (uint16_t)(HJ_E_ADV(e) == 64 ? e | (127u << 5) : e);
+    }
+  }
+  uint32_t *blk = lds_blk + t*HJ_BLK_STRIDE;
+#pragma unroll
+  for (int q = 0; q < 32; q++) blk[q] = 0;
+  const uint32_t b = blockIdx.x*NB + t;                      // block number in scan order
+  const uint32_t nslots = (uint32_t)im0.nslots;
+  uint32_t pos1 = 0, mcu = 0, c = 0;
+  uint64_t stop = 0;
+  if (b < blocks_per_image) {
+    pos1 = A.blk_pos[(size_t)img*(size_t)A.dc_stride + b];
+    mcu = b/nslots;
+    c = b - mcu*nslots;
+    // its restart interval: every segment but an image's last holds as many MCUs as the first
+    const uint32_t per = A.segs[im0.seg0].nmcu;
+    const uint32_t si = im0.nseg > 1u ? mcu/per : 0u;
+    stop = (uint64_t)A.segs[im0.seg0 + (si < im0.nseg ? si : im0.nseg - 1u)].end*8;
+  }
+  __syncthreads();                                           // tables, s_im, s_dezz, s_slotd
+  const bool live = pos1 != 0u;
+  const hj_image &im = s_im;
+  const uint32_t slot_tbl_bits = hj_slot_tables(im);
+  const int tbl = (int)((slot_tbl_bits >> (2u*c)) & 3u);
+  const uint32_t *tb_dc = lds_tabs.dc[tbl & 1], *tb_ac = lds_tabs.ac[tbl >> 1];
+  hj_gmem_src gsrc;
+  gsrc.scan32 = reinterpret_cast<const uint32_t *>(A.scan + im0.scan_off);
+  gsrc.ndw = ((im0.scan_len + 16 + 15) & ~15u) >> 2;
+  gsrc.dw0 = live ? (pos1 - 1u) >> 5 : 0u;
+  hj_gmem_src::reader br;
+  br.init(gsrc, live ? (uint64_t)(pos1 - 1u) : 0ull, live ? stop : 0ull);
+  uint8_t *blk8 = reinterpret_cast<uint8_t *>(blk);
+  int k = 0, dcv = 0, pv = 0, errm = 0;
+  uint32_t pz = 128, errbits = 0;
+  bool done = !live;
+  for (;;) {
+    bool running = !done && br.before_stop();
+    if (__ballot(running) == 0ull) break;
+#pragma unroll
+    for (int u = 0; u < HJ_WRITE_UNROLL; u++) {
+      if (u) running = !done && br.before_stop();
+      if (!running) continue;
+      const uint32_t w = br.window();
+      const bool isdc = k == 0;
+      const uint32_t *tb = isdc ? tb_dc : tb_ac;
+      uint32_t e = tb[w >> (32 - HJ_FAST_BITS)];
+      if ((e & 31u) == 0u) {                                 // a code longer than 9 bits
+        e = lds_tabs.l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+        if (HJ_E_LEN(e) > 16) e |= HJ_W_NOCODE;
+      }
+      const uint32_t tot = e & 31u, s = (e >> 12) & 15u;
+      const uint32_t off = 32u - tot;
+      const int vu = (int)__builtin_amdgcn_ubfe(w, off, s);
+      const int vs = __builtin_amdgcn_sbfe((int)w, off, s);
+      const int v = vu - (vs < 0 ? 0 : (int)((1u << s) - 1u));   // T.81 F.2.2.1 EXTEND; s = 0 gives 0
+      dcv = isdc ? v : dcv;
+      const int kn = k + (int)((e >> 5) & 127u);
+      *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;   // (the previous symbol's value)
+      pz = s_dezz[kn - 1];
+      pv = v;
+      errbits |= e;
+      errm = max(errm, kn & 127);
+      br.skip((int)tot);
+      done = kn >= 64;
+      k = done ? 0 : kn;
+    }
+  }
+  *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;       // the store still owed
+  const bool whole = live && done;
+  blk[32] = ~0u;                                             // "nothing to write out" (the half-dword behind the buffer took the stores that go nowhere)
+  if (whole) {
+    hj_block_out out;
+    out.im = &im;
+    out.slotd = s_slotd;
+    out.rs = (uint32_t)im0.w0_blocks*64u;
+    out.init(mcu);
+    blk[32] = out.offset((int)c)*2u;                         // byte offset of the block (a multiple of 128)
+    A.dc_diff[(long long)img*A.dc_stride + b] = (int16_t)dcv;
+  }
+  // a block that ran out of data before its last coefficient: hj_scan has said so already (blocks it did not count
+  // have no entry in blk_pos); kept as a second line of defence
+  if (live && !done) atomicOr(&A.errors[img], 1u);
+  if ((errbits & HJ_W_NOCODE) || errm > 64) atomicOr(&A.errors[img], 2u);
+  // the wave's blocks leave together: lanes 8k..8k+7 of a pass write block k's 128 bytes, 16 each
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  typedef __attribute__((address_space(1))) hj_v4u global_v4u;
+  int16_t *coef = A.coef + (long long)img*A.coef_stride;
+  const uint32_t *wave_blk = lds_blk + (t & ~63u)*HJ_BLK_STRIDE;
+  const uint32_t part = lane & 7u;
+  for (uint32_t q = lane >> 3; q < 64u; q += 8u) {
+    const uint32_t *srcb = wave_blk + q*HJ_BLK_STRIDE;
+    const uint32_t off = srcb[32];
+    if (off == ~0u) continue;
+    hj_v4u v;
+    v.x = srcb[4*part]; v.y = srcb[4*part + 1]; v.z = srcb[4*part + 2]; v.w = srcb[4*part + 3];
+    __builtin_nontemporal_store(v, (global_v4u *)((uintptr_t)coef + off) + part);
+  }
+}
+
 // ---- DC prediction (xjpeg.c:480), after the fact ------------------------------------------------------
 // dc_diff[b] = the DC difference of block b of the image in scan order (MCU by MCU, slot by slot),
 // left there by the write pass.  DC value of a block = sum of the differences of its component's
@@ -1359,6 +1574,15 @@ extern "C" int hj_launch_scan(const hj_args *A, int total_segs, int max_nsub, vo
 }
 extern "C" size_t hj_scan_part_bytes(size_t total_segs, size_t total_subs) {
   return 4*(total_segs + (total_subs >> HJ_SCAN_CHUNK_LOG2) + 2);
+}
+extern "C" int hj_launch_write_blocks(const hj_args *A, int max_nsub, int blocks_per_image, void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((max_nsub + HJ_LIST_BLOCK - 1)/HJ_LIST_BLOCK, A->nimages);
+  if (A->wide && !A->wide_shared) hipLaunchKernelGGL(hj_block_starts<hj_ltables_wide>, grid, dim3(HJ_LIST_BLOCK), 0, st, *A);
+  else hipLaunchKernelGGL(hj_block_starts<hj_ltables>, grid, dim3(HJ_LIST_BLOCK), 0, st, *A);
+  hipLaunchKernelGGL(hj_write_blocks, dim3((blocks_per_image + HJ_WB_BLOCK - 1)/HJ_WB_BLOCK, A->nimages), dim3(HJ_WB_BLOCK), 0, st, *A,
+   (uint32_t)blocks_per_image);
+  return (int)hipGetLastError();
 }
 extern "C" int hj_launch_write(const hj_args *A, int max_nsub, void *stream) {
   dim3 grid((max_nsub + HJ_WRITE_BLOCK - 1)/HJ_WRITE_BLOCK, A->nimages);

@@ -29,7 +29,7 @@ import csv,glob
 fn=glob.glob("$OUT/hprof/**/h_kernel_trace.csv", recursive=True)[0]
 rows=list(csv.DictReader(open(fn)))
 print("# tools/hbench.py (48 x 4K 4:2:0 q90) under rocprofv3 --kernel-trace: us per launch, last launches")
-for name in ("hj_init","hj_sync_round","hj_sync_sparse","hj_list_build","hj_sync_list","hj_scan","hj_write","hj_dc_scan","hj_dc_apply","jga_idct","fillBuffer"):
+for name in ("hj_init","hj_sync_round","hj_sync_sparse","hj_list_build","hj_sync_list","hj_scan","hj_write(","hj_block_starts","hj_write_blocks","hj_dc_scan","hj_dc_apply","jga_idct","fillBuffer"):
     r=[x for x in rows if name in x["Kernel_Name"]]
     if r: print(name,[round((int(x["End_Timestamp"])-int(x["Start_Timestamp"]))/1e3) for x in r][-14:], set((x["VGPR_Count"],x["LDS_Block_Size"]) for x in r))
 PY
