@@ -956,10 +956,13 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
   P.sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from : small_batch ? HJ_MAX_ROUNDS : 1;
   // Batches that fill the device (or share it): from the second launch on only the subsequences that still move run,
   // from work lists (hj_sync_list) — one step of the chain per launch, several inside a workgroup once an image's list
-  // fits one; 48 x 4K: 400 us of list rounds where the sparse kernel took 500, on a tenth of its instructions.  A small
+  // fits one; 48 x 4K: 370 us of list rounds where the sparse kernel took 500, on a tenth of its instructions.  A small
   // batch alone on the device keeps the dense kernel for every round: its in-group steps are ~10 us shorter than a
   // list step's (no list to read, rows already staged), and nothing else wants the CUs its idle lanes hold.
-  P.list_from = long_subs ? HJ_MAX_ROUNDS : K.list_from >= 0 ? K.list_from : small_batch ? HJ_MAX_ROUNDS : 1;
+  // (alone on the device: lists from 64 k subsequences on unless the batch brought 12-bit tables per image — 16 x 1080p
+  // 0.543 -> 0.522 ms, 8 x 4K 0.612 -> 0.592, but 4 x 4K with its own tables 0.522 -> 0.536: tools/r5_list_boundary.sh)
+  const bool dense_only = small_batch && ((b->wide && !b->wide_shared) || b->total_sub <= 64u*1024u);
+  P.list_from = long_subs ? HJ_MAX_ROUNDS : K.list_from >= 0 ? K.list_from : dense_only ? HJ_MAX_ROUNDS : 1;
   P.it_list = K.it_list;
   A.flush_lanes = K.flush_lanes;
   A.sub_log2 = b->sub_log2;
