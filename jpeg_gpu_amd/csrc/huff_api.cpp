@@ -961,7 +961,9 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
   // list step's (no list to read, rows already staged), and nothing else wants the CUs its idle lanes hold.
   // (alone on the device: lists from 64 k subsequences on unless the batch brought 12-bit tables per image — 16 x 1080p
   // 0.543 -> 0.522 ms, 8 x 4K 0.612 -> 0.592, but 4 x 4K with its own tables 0.522 -> 0.536: tools/r5_list_boundary.sh)
-  const bool dense_only = small_batch && ((b->wide && !b->wide_shared) || b->total_sub <= 64u*1024u);
+  // (... or restart intervals: their chains end at the next marker, six in-group steps cover most of them — the 8K
+  // frame of BASELINE config 5 alone: 0.66 ms dense, 0.69 with lists)
+  const bool dense_only = small_batch && ((b->wide && !b->wide_shared) || b->total_sub <= 64u*1024u || b->geom.restart_interval > 0);
   P.list_from = long_subs ? HJ_MAX_ROUNDS : K.list_from >= 0 ? K.list_from : dense_only ? HJ_MAX_ROUNDS : 1;
   P.it_list = K.it_list;
   A.flush_lanes = K.flush_lanes;

@@ -1129,8 +1129,6 @@ __global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_block_starts(const hj_args A
   const uint32_t img = blockIdx.y, t = threadIdx.x;
   const hj_image im = A.images[img];
   if (blockIdx.x*NB >= im.nsub) return;
-  hj_stage_image(&s_im, A.images + img);
-  hj_stage_tables<NB>(&lds_tabs, A.tables + img, A.wide && !A.wide_shared ? A.wide + img : nullptr);
   const uint32_t li = blockIdx.x*NB + t;
   const bool on = li < im.nsub;
   const uint8_t *scan = A.scan + im.scan_off;
@@ -1140,7 +1138,8 @@ __global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_block_starts(const hj_args A
   uint32_t g = 0, si = 0, first = 0, seg_block0 = 0, total = 0, b0 = 0;
   uint64_t start = 0, stop = 0;
   bool live = false;
-  if (on) {
+  hj_v4u v[HJ_LIST_MAX_LOADS];                               // the lane's row: all of its loads in flight before the first is used,
+  if (on) {                                                  // and the tables staged while they are on their way
     g = im.sub0 + li;
     si = A.sub_seg[g];
     const hj_segment sg = A.segs[im.seg0 + si];
@@ -1153,8 +1152,6 @@ __global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_block_starts(const hj_args A
     const uint32_t sidx = g + im.seg0 + si;
     start = A.S[sidx];
     stop = i + 1 < sg.nsub ? hj_pos(A.S[sidx + 1]) : (uint64_t)sg.end*8;
-    uint32_t *row = lds_win + t*sdw;
-    hj_v4u v[HJ_LIST_MAX_LOADS];                             // (all of the row's loads in flight before the first is used)
 #pragma unroll
     for (uint32_t j = 0; j < HJ_LIST_MAX_LOADS; j++) {
       if (j < nload) {
@@ -1163,6 +1160,11 @@ __global__ __launch_bounds__(HJ_LIST_BLOCK) void hj_block_starts(const hj_args A
         v[j] = *reinterpret_cast<const v4u_alias *>(scan + a);
       }
     }
+  }
+  hj_stage_image(&s_im, A.images + img);
+  hj_stage_tables<NB>(&lds_tabs, A.tables + img, A.wide && !A.wide_shared ? A.wide + img : nullptr);
+  if (on) {
+    uint32_t *row = lds_win + t*sdw;
 #pragma unroll
     for (uint32_t j = 0; j < HJ_LIST_MAX_LOADS; j++) {
       if (j < nload) {
