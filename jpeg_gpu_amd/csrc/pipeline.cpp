@@ -179,9 +179,17 @@ struct input_cache {
       // the caller (or another pipeline) registered exactly this range and did not say so: the device can address
       // it as it is — if it really covers the whole file
       (void)hipGetLastError();
-      void *dp = nullptr, *de = nullptr;
-      if (hipHostGetDevicePointer(&dp, const_cast<void *>(p), 0) == hipSuccess
-       && hipHostGetDevicePointer(&de, const_cast<unsigned char *>(static_cast<const unsigned char *>(p)) + bytes - 1, 0) == hipSuccess) {
+      // (EVERY page: a range whose two ends lie in other people's registrations — buffers back to back in one malloc
+      // arena share the page at their seam — is not covered by them, and a device read of its middle ends the process)
+      bool covered = true;
+      unsigned char *c = const_cast<unsigned char *>(static_cast<const unsigned char *>(p));
+      for (size_t o = 0; covered && o < bytes; o += 4096) {
+        void *dp = nullptr;
+        covered = hipHostGetDevicePointer(&dp, c + o, 0) == hipSuccess;
+      }
+      void *de = nullptr;
+      covered = covered && hipHostGetDevicePointer(&de, c + bytes - 1, 0) == hipSuccess;
+      if (covered) {
         rc = hipSuccess;
         foreign = true;
       }

@@ -554,6 +554,38 @@ def test_input_cache_never_serves_a_stale_buffer(gpu, orc, synth):
         libc.munmap(addr, n)
 
 
+def test_input_cache_with_callers_buffers_that_share_pages(gpu, orc, synth):
+    """Files that lie back to back in one malloc arena (the reference's caller mallocs its file, src/jpeg_info.c:31-56:
+    under glibc's mmap threshold, or above it once the threshold has grown, neighbours share the page at their seam),
+    registered by the input cache one by one, in any order, by several lanes at once: every file decodes as itself,
+    run after run, and a buffer is only taken as "registered by somebody else" if every page of it answers."""
+    files = [synth.synthetic_jpeg(1280, 720, "420", quality=90, seed=600 + i) for i in range(6)]
+    arena = np.zeros(sum(map(len, files)) + 64, np.uint8)
+    views, o = [], 13                                            # (no alignment whatsoever)
+    for f in files:
+        arena[o:o + len(f)] = np.frombuffer(f, np.uint8)
+        views.append(arena[o:o + len(f)])
+        o += len(f)
+    _, g = gpu.geom_of(files[0])
+    want = [orc.decode_rgb(f)[1].reshape(-1) for f in files]
+    outs = [np.zeros(g.rgb_bytes, np.uint8) for _ in files]
+    from jpeg_gpu_amd import abi
+    pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=3, unstuff=2)
+    try:
+        for rep in range(4):
+            order = [(5 * k + rep) % len(files) for k in range(len(files))]        # (a permutation)
+            for out in outs:
+                out[:] = 0
+            jobs = gpu.Pipeline.make_jobs([views[i] for i in order], host_outs=[outs[i] for i in order])
+            assert pl.run_jobs(jobs) == 0
+            for i in range(len(files)):
+                assert np.array_equal(outs[i], want[i]), (rep, i)
+        c = pl.counters()
+        assert c["registered"] >= 1 and c["stale"] == 0, c
+    finally:
+        pl.close()
+
+
 # ---- PACK wire format expanded on the GPU (SURVEY.md §8f-2) ---------------------------
 
 @pytest.mark.parametrize("sampling", SAMPLINGS)

@@ -342,7 +342,30 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
     return out
 
 
-if __name__ == "__main__":
+def _child_main(spec_path):
+    """bench.py's `configs` leg as a process of its own (bench.py --> python tools/configs_bench.py --child SPEC.json):
+    what it measures is supplementary to the headline, and a fault of the device or the runtime in one of its many
+    short legs must not take the bench line with it.  Prints ONE JSON line: {"configs": {...}, "headline": {...}}."""
+    import json
+    spec = json.load(open(spec_path))
+    from jpeg_gpu_amd import abi, lib
+    lib.check(lib.L.jga_set_device(int(spec.get("gpu", 0))))
+    say = lambda *a: print(*a, file=sys.stderr, flush=True)
+    res = {"configs": run_configs(spec["nthreads"], spec["cpu_threads"], lanes=spec["lanes"], group=spec["group"],
+                                  quick=spec["quick"], log=say, cpu_affinity=spec.get("cpu_affinity")), "headline": {}}
+    if spec.get("headline_file"):                # one frame of the headline's geometry alone, like the single-image configs
+        try:
+            data = open(spec["headline_file"], "rb").read()
+            res["headline"]["latency_ms"] = round(_pipeline_latency(lib, abi, data, spec["nthreads"]) * 1e3, 3)
+            res["headline"]["plugin"] = _plugin(lib, abi, data, 10)
+        except Exception as e:                   # (supplementary)
+            say("configs child: headline latency leg failed: %s" % e)
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--child":
+    _child_main(sys.argv[2])
+elif __name__ == "__main__":
     import json
     import __graft_entry__
     __graft_entry__.build()
