@@ -366,6 +366,15 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       return EXIT_FAILURE;
     }
     int on_gpu = !c->opt.host_entropy;
+    struct call_registration {                                 // the caller's file, registered until this call returns
+      void *p = nullptr;
+      hipStream_t stream = nullptr;
+      ~call_registration() {
+        if (!p) return;
+        (void)hipStreamSynchronize(stream);                    // (no copy out of it may still be in flight, whatever the way out)
+        (void)hipHostUnregister(p);
+      }
+    } file_of_this_call;
     const bool direct = c->opt.register_buffers == 0;         // (1: registered for the life of the context; -1: staged copies)
     const long long dcstride = (g->coef_shorts/64 + 127) & ~127ll;
     if (on_gpu) {
@@ -387,7 +396,22 @@ int hipjpeg_image(jpeg_decode_ctx *dec, image *img, jpeg_decode_out out) {
       // device cleans the scan up — the host's pass over the entropy-coded bytes takes one core
       // 0.2 ms for a 4K file, the four launches of the device's ~0.1 ms whatever the size: a 4K frame
       // 1.15 -> 1.08 ms, 8K 3.5 -> 2.7, a 1080p frame is better off with the host's)
-      const bool file_pinned = c->size >= (3 << 19) && (direct || registered(c, const_cast<unsigned char *>(c->buf), (size_t)c->size));
+      // Without a promise from the caller (register_buffers = 0) the file is registered for the length of THIS call
+      // (round 5; 45 us for 3 MB).  Until then the upload simply named the caller's memory and the runtime pinned what
+      // it touched — read-only, as the source of a copy, and kept that pinning cached: a caller that freed the file
+      // and got the same heap memory back for its PIXELS had the copy back fault ("Memory access fault by GPU ...
+      // Write access to a read-only page", bench.py's configs leg: a 6 MB 4:4:4 file, then a 6 MB 1080p frame).
+      bool file_pinned = c->size >= (3 << 19) && (direct || registered(c, const_cast<unsigned char *>(c->buf), (size_t)c->size));
+      if (file_pinned && direct) {
+        if (hipHostRegister(const_cast<unsigned char *>(c->buf), (size_t)c->size, hipHostRegisterDefault) == hipSuccess) {
+          file_of_this_call.p = const_cast<unsigned char *>(c->buf);
+          file_of_this_call.stream = c->stream;
+        }
+        else {
+          (void)hipGetLastError();
+          file_pinned = false;                                 // (somebody else's registration, or none to be had: the host reads the file)
+        }
+      }
       jga_huff_set_device_unstuff(c->hb, file_pinned);
       jga_huff_set_inputs_pinned(c->hb, file_pinned);
       if (jga_huff_prepare(c->hb, &c->buf, &c->size, 1, &g2, c->stream) != EXIT_SUCCESS) {

@@ -204,3 +204,41 @@ def test_registered_buffers_big_file(gpu, orc, jpg, ri):
     for mode in ("0", "-1"):
         assert out[-1].split()[-1] == run("-o", "yuv", "--frames", "2", "--check", path,
                                           env={"JPEG_GPU_HIP_REGISTER": mode}).stdout.strip().split("\n")[-1].split()[-1]
+
+
+@pytest.mark.gpu
+def test_plugin_when_the_callers_heap_hands_a_files_memory_out_again_for_pixels(gpu, orc, synth):
+    """The reference's caller mallocs its file, decodes, frees (src/jpeg_info.c:31-62) and mallocs its frame
+    (src/image.c:66-95).  Once glibc serves such sizes from the heap, a freed 6 MB file and the next frame's 6 MB of
+    pixels are the same memory.  Round 5: the plugin's upload named the file's ordinary memory, the runtime pinned it
+    READ-ONLY as a copy's source and kept that cached, and the copy back into the pixels that took its place died of
+    "Memory access fault by GPU ... Write access to a read-only page" (bench.py's configs leg, one run in three).
+    The file is now registered for the length of the call.  In a process of its own: a fault ends it."""
+    import subprocess
+    import sys
+    import textwrap
+    prog = textwrap.dedent("""
+        import ctypes as C, gc, sys
+        libc = C.CDLL("libc.so.6")
+        libc.mallopt(-3, 64 << 20)            # M_MMAP_THRESHOLD: the heap serves everything under 64 MB
+        sys.path.insert(0, %r)
+        import numpy as np
+        from jpeg_gpu_amd import abi, lib, synth
+        import oracle
+        orc = oracle.Oracle()
+        big = synth.synthetic_jpeg(3840, 2160, "444", quality=90, seed=7)       # 6 MB: read by the device where it lies
+        frame = synth.synthetic_jpeg(1920, 1080, "420", quality=90, seed=8)     # 6 MB of RGB
+        want_big, want_frame = orc.decode_rgb(big)[1], orc.decode_rgb(frame)[1]
+        for rep in range(6):
+            with lib.Decoder(big) as d:
+                d.read_header(); d.init_image(); d.decode(abi.JPEG_DECODE_RGB)
+                assert np.array_equal(d.pixels(), want_big)
+            gc.collect()
+            with lib.Decoder(frame) as d:
+                d.read_header(); d.init_image(); d.decode(abi.JPEG_DECODE_RGB)
+                assert np.array_equal(d.pixels(), want_frame)
+            gc.collect()
+        print("fine")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fine" in r.stdout, (r.returncode, r.stderr[-600:])

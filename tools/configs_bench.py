@@ -240,6 +240,17 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
     say = log or (lambda *a: None)
     out = {}
 
+    # The CPU paths run AFTER every GPU leg (round 5): they move the process onto all granted CPUs and back, and the
+    # kernel then migrates heap pages between NUMA nodes — pages the device has mapped through registrations and
+    # the runtime's pinning cache.  bench.py's configs leg (which passes cpu_affinity) died twice in three runs with
+    # "Memory access fault by GPU ... Write access to a read-only page" on a host heap address in the legs right
+    # behind a CPU leg; tools/configs_bench.py alone (no affinity change) never did in a dozen runs.
+    deferred = []
+
+    def cpu_rates_later(entry, files, w, h, frames):
+        deferred.append((entry, files, w, h, frames))
+        return None
+
     def cpu_rates(files, w, h, frames):
         """The CPU paths on the whole CPU grant (the pipeline legs run on the rank's own cores)."""
         mine = os.sched_getaffinity(0)
@@ -273,7 +284,8 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
              "device": dict(_kernel_alone(lib, np, files, kernel_n, 5 if quick else 20),
                             one_frame=_device_only(lib, files, 1, 2 if quick else 5)),
              "bit_exact_vs_oracle": ok,
-             "cpu": cpu_rates(files, w, h, cpu_frames)}
+             "cpu": None}
+        cpu_rates_later(e, files, w, h, cpu_frames)
         if ri:
             # (SURVEY §8e's note) the same frame in 8 bands of MCU rows, one per GPU: what ONE of them does —
             # finds its band (host: a pass over the file for the restart markers), writes it as a file of
@@ -316,6 +328,7 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
     for name, order in (("all_%d_on_one_gpu" % n4, list(range(n4))),
                         ("rank3_shard_of_8", list(shard.shard_range(n4, 3, 8)))):
         for kind, pinned in (("pageable_files", False), ("pinned_files", True)):
+            say("configs: config4 %s %s ..." % (name, kind))
             ts = []
             # (a short job's time moves by +-10 % from run to run: the shard is timed 15 times and the MEDIAN quoted
             # — `ms` — with the best beside it; rounds 1-4 quoted the best of three)
@@ -328,17 +341,24 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
                 "images": len(order), "ms": round(med * 1e3, 2), "ms_best": round(dt * 1e3, 2), "runs": len(ts),
                 "Mpixel_s": round(len(order) * px / med / 1e6, 1), "h2d_bytes_per_image": int(h2d),
                 "h2d_GBps": round(len(order) * h2d / med / 1e9, 1)}
+    say("configs: config4 plugin ...")
     e4["to_host_pixels"] = _plugin(lib, abi, files[0], 3 if quick else 10)
+    say("configs: config4 device only ...")
     e4["device"] = dict(_kernel_alone(lib, np, files, n4, 3 if quick else 5),
                         whole_batch=_device_only(lib, files, n4, 1 if quick else 3),
                         shard_128=_device_only(lib, files, min(n4, 128), 1 if quick else 3))
     e4["bit_exact_vs_oracle"] = all(oks)
-    e4["cpu"] = cpu_rates(files, 1920, 1080, max(cpu_frames, 4))
+    e4["cpu"] = None
+    cpu_rates_later(e4, files, 1920, 1080, max(cpu_frames, 4))
     out["config4_batch_1080p_420"] = e4
     say("configs: config4 done in %.1f s" % (time.perf_counter() - t_cfg))
 
     single("config5_8k_420_dri", "7680x4320 4:2:0 q90, DRI = one MCU row (configs[4]: GPU-parallel Huffman variant)",
            7680, 4320, "420", -1, 4 if quick else 32, 2 if quick else 8)
+    t_cpu = time.perf_counter()
+    for entry, files, w, h, frames in deferred:
+        entry["cpu"] = cpu_rates(files, w, h, frames)
+    say("configs: CPU paths of the %d configs in %.1f s" % (len(deferred), time.perf_counter() - t_cpu))
     return out
 
 
