@@ -328,6 +328,10 @@ const round_knobs &the_round_knobs() { static const round_knobs K; return K; }
 static int auto_iters(const jga_huff_batch *b) {
   const bool long_intervals = b->geom.restart_interval > 0 && b->sub_log2 == HJ_SUB_LOG2_MAX - 1
    && b->total_seg > 0 && b->total_sub/b->total_seg >= 64u;
+  // (a small batch with its own 12-bit tables, every round by the dense kernel: four — fewer launches for the same
+  // chain, a lone 1080p frame 0.355 -> 0.350 ms, 4K 0.386 -> 0.378, 4K 4:4:4 0.280 -> 0.269; five helps the 1080p frame
+  // more and costs the 4K one: profiles/r5_lone_frame_chain.md)
+  if (b->wide && !b->wide_shared && !long_intervals) return 4;
   return long_intervals ? 6 : 3;
 }
 // prepare() with the unstuffing left to the device: the host parses the marker segments
