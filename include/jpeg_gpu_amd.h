@@ -551,7 +551,8 @@ void jga_huff_set_blocking_waits(jga_huff_batch *b, int on);
 void jga_huff_set_copy_stream(jga_huff_batch *b, void *copy_stream);
 /* 1: other decodes run on the device at the same time (a pipeline's lanes).  A batch that would
  * leave most of an idle device empty takes the kernels with the shortest chain of steps; told
- * that the device is shared, it takes the ones that leave the most of it to the others. */
+ * that the device is shared, it takes the ones that leave the most of it to the others; 2: ... and for a long
+ * time (a pipeline's long run): nothing that shortens this batch's own chain at the others' expense. */
 void jga_huff_set_device_shared(jga_huff_batch *b, int on);
 /* `fn(arg, bytes, copies)` is called by prepare() right before it queues its upload of `bytes`
  * bytes in `copies` copy calls (a caller that runs several batches may want their uploads to cross

@@ -143,6 +143,11 @@ static void choose_wide(jga_huff_batch *b, std::vector<hj_prepared> &prep, int n
     return;
   }
   if (b->sub_log2 > HJ_SUB_LOG2_MAX || jga_tune("JGA_HUFF_NO_WIDE") || jga_tune("JGA_HUFF_NO_SHARED_WIDE")) return;
+  // (not in a long run of a pipeline, device_shared == 2: there the 85 KB of LDS a list workgroup with these tables
+  // takes are the other lanes' dense and write workgroups' — 1080p in a steady state 130-135 Gpixel/s with them,
+  // 139-141 without; a SHORT run, which waits for its last group's chain, keeps them: the 128-file shard 3.35-3.54 ms
+  // median with, 3.65-3.70 without: tools/archive/r5_shared_wide_pipeline.sh)
+  if (b->device_shared == 2) return;
   for (int i = 1; i < n; i++) {
     if (memcmp(&prep[(size_t)i].tabs, &prep[0].tabs, sizeof(hj_tables)) != 0) return;
   }
@@ -744,7 +749,7 @@ JGA_EXPORT void jga_huff_set_device_unstuff(jga_huff_batch *b, int on) { b->devi
 JGA_EXPORT void jga_huff_set_inputs_pinned(jga_huff_batch *b, int on) { b->inputs_pinned = on != 0; }
 // 1: jga_huff_decode's host waits sleep (blocking event) instead of spinning on a core.
 JGA_EXPORT void jga_huff_set_blocking_waits(jga_huff_batch *b, int on) { b->blocking_waits = on != 0; }
-JGA_EXPORT void jga_huff_set_device_shared(jga_huff_batch *b, int on) { b->device_shared = on != 0; }
+JGA_EXPORT void jga_huff_set_device_shared(jga_huff_batch *b, int on) { b->device_shared = on < 0 ? 0 : on > 2 ? 2 : on; }
 // Wait until the last prepare()'s upload has arrived (its kernels, if it queued any, may still run).
 JGA_EXPORT int jga_huff_wait_upload(jga_huff_batch *b) {
   HOK(b->blocking_waits ? jga_event_wait_sleeping(b->arrived) : hipEventSynchronize(b->arrived));

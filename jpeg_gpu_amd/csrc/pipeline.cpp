@@ -683,7 +683,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     jga_huff_set_inputs_pinned(l.hb, 0);
     jga_huff_set_input_flags(l.hb, in_place.data(), m);
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
-    jga_huff_set_device_shared(l.hb, shared);
+    jga_huff_set_device_shared(l.hb, shared ? (short_run ? 1 : 2) : 0);   // (2: a long run — throughput, not the last chain, is what counts)
     jga_huff_set_copy_stream(l.hb, pl->copy_streams.empty() ? nullptr
      : pl->copy_streams[pl->copy_next.fetch_add(1)%pl->copy_streams.size()]);
   }
