@@ -953,7 +953,8 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
   P.group = K.group;
   P.lean = K.lean;
   P.assist_after = b->assist_after > 0 ? b->assist_after : 12;
-  // Which kernel runs the later rounds.  The sparse one (a wave per 256 subsequences, rows read from
+  // Which kernel runs the later rounds where the list rounds (below) do not: subsequences of 256 / 512 bytes, the tuning
+  // build's JGA_HUFF_LIST=0.  The sparse one (a wave per 256 subsequences, rows read from
   // global memory) is for batches that fill the device: there a dense launch pays staging for
   // every group that still has one moving lane.  Up to ~200k subsequences (8 x 4K, 32 x 1080p) the
   // dense kernel's LDS rows make each step of the chain shorter and nothing else wants the CUs:
