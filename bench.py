@@ -434,6 +434,146 @@ class KeptOutputs:
         self.torch.cuda.empty_cache()
 
 
+
+# ---- what rank 0 prints -------------------------------------------------------------------------
+
+LINE_LIMIT = 4096             # bytes the ONE stdout line may take, at N = 1 and at N = 8 (a 23.7 KB line
+                              # was more than the driver's reader took, and the round's headline went unrecorded)
+DETAILS_FILES = ("bench_details.json", os.path.join("gpurun_out", "bench_details.json"))
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short(s, n=120):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _config_summary(e):
+    """One BASELINE config's entry of the full report -> the handful of figures the line carries."""
+    if not isinstance(e, dict) or "to_rgb_hbm" not in e:
+        return e if not isinstance(e, dict) else _pick(e, "error")
+    t, dev, host = e["to_rgb_hbm"], e.get("device", {}), e.get("to_host_pixels", {})
+    s = {}
+    if "Mpixel_s" in t:
+        s["Mpixel_s"] = t["Mpixel_s"]
+    if "latency_ms" in t:
+        s["latency_ms"] = t["latency_ms"]
+    st = t.get("steady")
+    if st:
+        s["steady"] = st["Mpixel_s"]
+        s["steady_s"] = st["seconds"]
+        s["h2d_GBps"] = st["h2d_GBps"]
+        s["of_link_ceiling"] = st["of_link_ceiling"]
+    for k, v in t.items():                                   # config 4: the whole batch and one rank's shard
+        if isinstance(v, dict) and "pageable_files" in v:
+            pg, pn = v["pageable_files"], v["pinned_files"]
+            s[k] = {"ms": [pg["ms"], pn["ms"]], "ms_best": [pg["ms_best"], pn["ms_best"]]}      # [pageable, pinned files]
+    if "ms_per_frame" in host:
+        s["host_ms_per_frame"] = host["ms_per_frame"]
+    elif isinstance(host.get("plugin"), dict):
+        s["host_ms_per_frame"] = host["plugin"].get("ms_per_frame")
+    if "kernel_hbm_frac" in dev:
+        s["kernel_hbm_frac"] = dev["kernel_hbm_frac"]
+    for k in ("one_frame", "shard_128", "whole_batch"):
+        if k in dev:
+            s["device_ms_" + k] = dev[k]["ms"]
+    for k in ("huffman_ms", "idct_rgb_ms"):
+        if k in dev:
+            s[k] = dev[k]
+    if "bound_by" in e:
+        s["bound_by"] = e["bound_by"]
+    cpu = e.get("cpu") or {}
+    c = [cpu.get(k, {}).get("value") for k in ("reference_xjpeg_yuv", "libjpeg_turbo_rgb")]
+    if any(v is not None for v in c):
+        s["cpu_ref_turbo"] = c
+    s["ok"] = bool(e.get("bit_exact_vs_oracle"))
+    return s
+
+
+def compact_line(full, details_path=None):
+    """The full report -> the ONE line rank 0 prints: the contract keys, `roofline`, `cpu_baseline`, one compact
+    summary per config and per supplementary leg.  Everything else stays in the details file."""
+    o = _pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "value_pinned_ingest")
+    cfg = full.get("config", {})
+    o["config"] = dict(_pick(cfg, "workload", "batch_per_gpu", "images_timed_per_gpu", "images_verified",
+                             "h2d_bytes_per_image", "h2d_GBps_per_gpu_at_value", "scan_cleanup",
+                             "ranks_talk_over", "parallelism", "host_threads_per_gpu", "bit_exact_vs_oracle"))
+    o["config"]["workload"] = _short(o["config"].get("workload", ""), 128)
+    if "host_cpus" in cfg:
+        o["config"]["cpu_budget_per_rank"] = cfg["host_cpus"].get("budget_per_rank")
+    if "device" in cfg:
+        o["config"]["device"] = "%s %s" % (cfg["device"].get("arch", "").split(":")[0], cfg["device"].get("compute_units"))
+    rf = full.get("roofline", {})
+    o["roofline"] = _pick(rf, "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                          "algorithmic_bytes_per_launch", "kernel_ms_per_launch", "launches_timed", "device_copy_GBps")
+    if "traffic_provenance" in rf:
+        o["roofline"]["traffic_measured_in_this_run"] = bool(rf["traffic_provenance"].get("measured_in_this_run"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        o["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind")
+        o["cpu_baseline"]["sample"] = _short(cb.get("sample", ""), 128)
+        for k in ("libjpeg_turbo_rgb", "oracle_port_rgb"):
+            if k in cb:
+                o["cpu_baseline"][k] = cb[k].get("value")
+    pr = full.get("per_rank")
+    if pr:
+        rk = pr["ranks"]
+        o["per_rank"] = {"Mpixel_s": [r["Mpixel_s"] for r in rk], "h2d_GBps": [r.get("h2d_GBps") for r in rk],
+                         "cpus": [r.get("cpus") for r in rk], "numa_node": [r.get("numa_node") for r in rk],
+                         "verified": sum(r.get("images_verified", 0) for r in rk)}
+    e2e = full.get("e2e") or {}
+    if e2e:
+        o["e2e"] = {k: v["value"] for k, v in e2e.items() if isinstance(v, dict) and "value" in v
+                    and k in ("north_star_host_huffman_to_rgb_hbm", "north_star_host_huffman_to_rgb_host",
+                              "pack_transport_to_rgb_hbm", "gpu_entropy_to_rgb_host", "gpu_entropy_to_rgb_pinned_host")}
+    ge = full.get("gpu_entropy")
+    if ge:
+        o["gpu_entropy"] = _pick(ge, "value", "huffman_ms", "idct_rgb_ms", "sync_rounds", "bit_exact_vs_oracle")
+    ps = full.get("pack_stage")
+    if ps:
+        o["pack_stage"] = _pick(ps, "ms_per_launch", "achieved_GBps", "equals_oracle_quant_stage")
+    ok_ = full.get("other_kernels")
+    if ok_:
+        o["other_kernels"] = {k: [v["ms"], v["GBps"]] for k, v in ok_.items()}
+    sp = full.get("scale_proxy")
+    if sp:
+        o["scale_proxy"] = {"as_rank_of": sp.get("as_rank_of"), "cpus": sp.get("cpus"), "vs_value": sp.get("vs_value")}
+    cf = full.get("configs")
+    if cf:
+        o["configs"] = {k: _config_summary(v) for k, v in cf.items() if k != "note"}
+    if details_path:
+        o["details"] = details_path
+    line = json.dumps(o, separators=(",", ":"))
+    # the limit is a contract: shed the supplementary objects, least important first, rather than exceed it
+    for k in ("scale_proxy", "other_kernels", "e2e", "pack_stage", "per_rank", "gpu_entropy", "configs"):
+        if len(line) < LINE_LIMIT:
+            break
+        o.pop(k, None)
+        o.setdefault("dropped_for_size", []).append(k)
+        line = json.dumps(o, separators=(",", ":"))
+    return line
+
+
+def emit(full):
+    """Rank 0: the full report into the details files (repo root and gpurun_out/, whichever can be written), the
+    compact line — alone — on stdout."""
+    written = None
+    for rel in DETAILS_FILES:
+        path = os.path.join(ROOT, rel)
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            written = written or rel
+        except OSError as e:
+            log("bench.py: could not write %s (%s)" % (rel, e))
+    print(compact_line(full, written), flush=True)
+
+
 # ---- main -------------------------------------------------------------------------------------
 
 def main():
@@ -846,14 +986,13 @@ def main():
                                              "registered_in_timed_region", "jobs_dma_in_place")}
                       for v, r_ in (("pageable", page), ("pinned_ingest", pinn))},
         "config": {
-            "workload": "3840x2160 4:2:0 q90 baseline JPEG files in host RAM (ordinary pageable buffers) -> "
-                        "RGB8 in HBM (end to end), every output kept and compared with the oracle; "
-                        "step = one batch of %d images per GPU through the "
-                        "pipelined decoder: host marker parse, scan clean-up (unstuffing) on the host "
-                        "into pinned memory - or, when the rank has 8 cores or fewer, on the GPU - "
-                        "compressed bytes over PCIe, GPU Huffman "
-                        "decode + fused dequant/IDCT/upsample/RGB kernel; %d steps streamed through "
-                        "%d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
+            "workload": "3840x2160 4:2:0 q90 JPEG files in host RAM -> RGB8 in HBM, %d images/step/GPU, "
+                        "all outputs checked vs oracle" % PB,
+            "workload_detail": "files in ordinary pageable buffers, end to end; step = one batch of %d images per GPU "
+                               "through the pipelined decoder: host marker parse, scan clean-up (unstuffing) on the host "
+                               "into pinned memory - or, when the rank has 8 cores or fewer, on the GPU - compressed "
+                               "bytes over PCIe, GPU Huffman decode + fused dequant/IDCT/upsample/RGB kernel; %d steps "
+                               "streamed through %d lanes per GPU in groups of %d" % (PB, K, args.lanes, G),
             # (the library's rule, csrc/pipeline.cpp: the smaller of the CPU grant and nthreads)
             "scan_cleanup": cleanup_route,
             # (pageable files: with the clean-up on the device they go through the pipeline's input cache —
@@ -870,7 +1009,7 @@ def main():
             # what the link carries per GPU at this rate (it sustains ~56 GB/s from pinned memory,
             # tools/h2d_probe.py): `value` sits within ~10 % of the PCIe ceiling for this content
             "h2d_GBps_per_gpu_at_value": round(rate / world / (W * H) * h2d_per_image / 1e9, 1),
-            "parallelism": "image-sharded x%d, one process per GPU, no data-path collective" % world,
+            "parallelism": "image-sharded x%d, one process per GPU, no collective" % world,
             "host_threads_per_gpu": nthreads, "cpu_pinning": pin,
             "host_cpus": {"visible_to_rank": my_cpus, "cgroup_cpu_quota": quota,
                           "budget_per_rank": budget},
@@ -980,6 +1119,7 @@ def main():
                                                   "0.3 s, 50 repetitions between HIP events on the launch stream; device_copy_GBps = the best"}
 
     solo = rank == 0 and world == 1
+    configs_failed = None
     if solo and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(jpegs, args.cpu_rounds, args.cpu_frames, orig_cpus, quota)
 
@@ -1235,6 +1375,7 @@ def main():
             except Exception as e:
                 cfgs = {"error": "the configs process: %s" % e}
         if "error" in cfgs:
+            configs_failed = cfgs["error"]
             log("bench.py: configs leg failed: %s" % cfgs["error"])
         cb = out.get("cpu_baseline", {})
         ge = out.get("gpu_entropy", {})
@@ -1264,9 +1405,12 @@ def main():
                                   % (cpu_threads, time.perf_counter() - t_cfg))
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     lib.L.jga_stream_destroy(stream)
     comm.close()
+    if configs_failed:
+        # (a fault in the configs process must FAIL the run; the line above says what happened)
+        raise SystemExit("bench.py: the configs leg failed: %s" % configs_failed)
 
 
 if __name__ == "__main__":

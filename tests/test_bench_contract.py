@@ -19,7 +19,68 @@ def run_bench(*flags, timeout=900):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout      # ONE line on stdout, and it is the JSON
+    assert len(lines[0]) < 4096, len(lines[0])                          # ... small enough for the driver's reader
     return json.loads(lines[0])
+
+
+def details(line):
+    """The full report the compact line points at (bench.py writes it beside itself and under gpurun_out/)."""
+    with open(os.path.join(ROOT, line["details"])) as f:
+        return json.load(f)
+
+
+def _full_report(n_ranks):
+    """A full report of realistic size: round 5's own (profiles/r5_bench.json, the 23.7 KB line the driver could not
+    read), widened to n_ranks."""
+    import copy
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bench.json")))
+    if n_ranks > 1:
+        full["n_gpus"] = n_ranks
+        full["per_rank"]["ranks"] = [dict(copy.deepcopy(full["per_rank"]["ranks"][0]), rank=i, gpu=i)
+                                     for i in range(n_ranks)]
+        for k in ("cpu_baseline", "configs", "scale_proxy", "other_kernels", "pack_stage", "gpu_entropy"):
+            full.pop(k, None)                                          # (N = 1 only)
+    return full
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 8])
+def test_the_line_stays_under_4_kb_and_parses_alone(n_ranks):
+    """the one line had grown to 23.7 KB and the driver recorded `parsed: null`.  compact_line() of a
+    full-size report — 1 rank with every leg, and the 8-rank shape — is under 4 KB, parses on its own and still
+    carries the contract keys, `roofline`, `cpu_baseline` (N = 1) and a summary of every config."""
+    import bench
+    full = _full_report(n_ranks)
+    line = bench.compact_line(full, "bench_details.json")
+    assert len(line.encode()) < bench.LINE_LIMIT == 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d and d[k] == full[k] or k in ("config", "roofline"), k
+    assert "dropped_for_size" not in d and d["details"] == "bench_details.json"
+    assert len(d["config"]["workload"]) <= 128 and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert d["roofline"][k] == full["roofline"][k]
+    assert len(d["per_rank"]["Mpixel_s"]) == n_ranks
+    if n_ranks == 1:
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in d["cpu_baseline"]
+        assert len(d["cpu_baseline"]["sample"]) <= 128
+        assert set(d["configs"]) == set(full["configs"]) - {"note"}
+        c4 = d["configs"]["config4_batch_1080p_420"]["rank3_shard_of_8"]
+        assert c4["ms"] == [3.3, 3.43]                                  # [pageable, pinned] medians
+        assert d["configs"]["config5_8k_420_dri"]["of_link_ceiling"] == 0.979
+    else:
+        assert "cpu_baseline" not in d
+
+
+def test_an_oversized_report_sheds_objects_instead_of_exceeding_the_limit():
+    import bench
+    full = _full_report(1)
+    full["configs"].update({"extra_%d" % i: full["configs"]["config5_8k_420_dri"] for i in range(40)})
+    line = bench.compact_line(full, "x")
+    d = json.loads(line)
+    assert len(line) < bench.LINE_LIMIT and d["dropped_for_size"]
+    assert d["value"] == full["value"] and "roofline" in d and "cpu_baseline" in d
 
 
 def test_gpus_n_run_plainly_starts_n_ranks():
@@ -122,6 +183,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
                   "--prewarm", "0", "--kernel-reps", "3", "--kernel-batch", "4", "--cpu-rounds", "1", "--cpu-frames", "1",
                   "--no-e2e", "--no-pack", "--no-other", "--no-gpu-entropy", "--quick-configs",
                   "--no-measure-traffic", "--scale-proxy", "8", timeout=1500)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs", "per_rank", "details"):
+        assert k in d, k                                       # the line itself
+    line, d = d, details(d)
+    assert line["value"] == d["value"] and line["roofline"]["frac"] == d["roofline"]["frac"]
+    assert line["cpu_baseline"]["value"] == d["cpu_baseline"]["value"]
+    assert set(line["configs"]) == set(d["configs"]) - {"note"}
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
               "cpu_baseline", "value_pageable", "value_pinned_ingest", "per_rank", "configs", "scale_proxy",
@@ -210,6 +278,24 @@ def test_one_wrong_byte_in_the_timed_regions_outputs_fails_the_bench(gpu):
 
 
 @pytest.mark.gpu
+def test_a_fault_in_the_configs_process_fails_the_bench(gpu):
+    """the per-config legs run in a process of their own; when that process dies (a GPU memory fault
+    aborts it), bench.py still prints its line — with the error in `configs` — and exits NON-ZERO."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["JGA_CONFIGS_FAULT"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--batch", "4",
+                        "--group", "2", "--distinct", "4", "--lanes", "2", "--prewarm", "0", "--no-cpu", "--no-e2e",
+                        "--no-pack", "--no-other", "--no-gpu-entropy", "--quick-configs", "--no-measure-traffic",
+                        "--kernel-reps", "3", "--kernel-batch", "4", "--scale-proxy", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "configs leg failed" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and "error" in d["configs"]
+
+
+@pytest.mark.gpu
 def test_eight_ranks_sharing_the_one_gpu(gpu):
     """The driver's N = 8 launch on a one-GPU box (JGA_BENCH_SHARE_GPUS: the ranks share the device and
     talk over gloo; the rates mean nothing, the code path is the 8-rank one): inputs synthesised once
@@ -221,6 +307,8 @@ def test_eight_ranks_sharing_the_one_gpu(gpu):
                       timeout=1500)
     finally:
         del os.environ["JGA_BENCH_SHARE_GPUS"]
+    assert len(d["per_rank"]["Mpixel_s"]) == 8 and d["per_rank"]["verified"] == 32
+    d = details(d)
     assert d["n_gpus"] == 8 and d["config"]["images_verified"] == 2
     assert d["config"]["ranks_talk_over"] == "gloo" and "once per box" in d["config"]["inputs"]
     ranks = d["per_rank"]["ranks"]
@@ -242,6 +330,7 @@ def test_two_ranks_started_by_bench_itself(gpu):
                       "--lanes", "2", "--prewarm", "0", "--kernel-reps", "3", "--kernel-batch", "4")
     finally:
         del os.environ["JGA_BENCH_SHARE_GPUS"]
+    d = details(d)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["images_timed_per_gpu"] == 8 and d["config"]["bit_exact_vs_oracle"] is True
     # whole-job pixels / max-over-ranks time

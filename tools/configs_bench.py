@@ -369,6 +369,8 @@ def _child_main(spec_path):
     import json
     spec = json.load(open(spec_path))
     from jpeg_gpu_amd import abi, lib
+    if os.environ.get("JGA_CONFIGS_FAULT"):                     # tests: a process that dies the way a GPU fault kills one
+        os.abort()
     lib.check(lib.L.jga_set_device(int(spec.get("gpu", 0))))
     say = lambda *a: print(*a, file=sys.stderr, flush=True)
     res = {"configs": run_configs(spec["nthreads"], spec["cpu_threads"], lanes=spec["lanes"], group=spec["group"],
