@@ -485,6 +485,8 @@ def _config_summary(e):
             s[k] = dev[k]
     if "bound_by" in e:
         s["bound_by"] = e["bound_by"]
+        s["B_per_px"] = e.get("bytes_per_pixel")
+        s["device_ceiling"] = e.get("device_ceiling_Mpixel_s")
     cpu = e.get("cpu") or {}
     c = [cpu.get(k, {}).get("value") for k in ("reference_xjpeg_yuv", "libjpeg_turbo_rgb")]
     if any(v is not None for v in c):

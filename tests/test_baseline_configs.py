@@ -158,3 +158,45 @@ def test_config4_batch_and_shard_through_the_pipeline(gpu, batch_1080p, transpor
             assert zlib.adler32(outs[k].tobytes()) == sums[i], i
     finally:
         pl.close()
+
+
+# ---- photograph-like content ---------------------------------------------------
+
+def test_photo_like_content_lands_where_photographs_do(synth, orc):
+    """The f^-1.5-spectrum recipe at q90 4:2:0: 0.10-0.20 bytes per pixel at 1080p (the SURVEY recipe's sin + N(0,12)
+    noise costs 0.37), deterministic by seed, and a valid baseline file the oracle decodes."""
+    a = synth.photo_like_jpeg(1920, 1080, "420", 90, seed=1)
+    assert 0.10 < len(a) / (1920 * 1080) < 0.20
+    assert a == synth.photo_like_jpeg(1920, 1080, "420", 90, seed=1)
+    assert a != synth.photo_like_jpeg(1920, 1080, "420", 90, seed=2)
+    assert len(synth.synthetic_jpeg(1920, 1080, "420", 90, seed=1)) / (1920 * 1080) > 0.3
+    info, rgb = orc.decode_rgb(a)
+    assert rgb.shape == (1080, 1920, 3) and 20 < rgb.std() < 90          # a picture, not a flat field
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,samp,ri", [(1920, 1080, "420", 0), (3840, 2160, "420", 0), (1920, 1080, "422", 0),
+                                         (1000, 600, "444", -1), (640, 480, "grey", 7)])
+def test_photo_like_content_through_every_gpu_route(gpu, orc, synth, w, h, samp, ri):
+    """Lighter content exercises what the recipe's noise never does: long zero runs and EOBs early in the block,
+    short codes, many blocks per subsequence of the GPU entropy stage.  The plugin (RGB), the batch decoder
+    (transport 2: a group of identical-geometry files, twice, clean-up on host and on device) and the host
+    entropy stage (transport 0) all equal the oracle bit for bit."""
+    from jpeg_gpu_amd import abi
+    files = [synth.photo_like_jpeg(w, h, samp, 90, ri, seed=40 + i) for i in range(3)]
+    want = [orc.decode_rgb(f)[1].reshape(-1) for f in files]
+    with gpu.Decoder(files[0]) as d:
+        d.read_header()
+        d.init_image()
+        d.decode(abi.JPEG_DECODE_RGB)
+        assert np.array_equal(d.pixels().reshape(-1), want[0])
+    for more in ({"transport": 2, "unstuff": 1}, {"transport": 2, "unstuff": 2}, {"transport": 0}):
+        outs = [np.zeros(want[0].size, np.uint8) for _ in range(6)]
+        pl = gpu.Pipeline(device=0, nthreads=3, out=abi.JPEG_DECODE_RGB, copy_back=True, batch=4, **more)
+        try:
+            rc, jobs = pl.run([files[i % 3] for i in range(6)], host_outs=outs)
+            assert rc == 0 and all(j.status == 0 for j in jobs)
+            for i in range(6):
+                assert np.array_equal(outs[i], want[i % 3]), (more, i)
+        finally:
+            pl.close()

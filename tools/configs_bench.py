@@ -77,6 +77,39 @@ def _device_only(lib, jpegs, n, reps=5):
             "Mpixel_s": round(n * g.width * g.height / best / 1e6, 1)}
 
 
+def _device_split(lib, jpegs, n, reps=5):
+    """As _device_only for a batch of n, the two stages timed apart (host clock around synchronous calls, mean of
+    reps after one warm-up): the GPU entropy stage (jga_huff_decode_split) and the fused block-decode kernel."""
+    _, g = lib.geom_of(jpegs[0])
+    cs = (g.coef_shorts * 2 + 255) // 256 * 128
+    os_ = (g.rgb_bytes + 255) // 256 * 256
+    dc, do = lib.DeviceBuffer(cs * 2 * n), lib.DeviceBuffer(os_ * n)
+    jobs = [jpegs[i % len(jpegs)] for i in range(n)]
+    hb = lib.HuffBatch(n, sum(map(len, jobs)) + 4096 * n)
+    hb.prepare(jobs)
+    lib.check(lib.L.jga_stream_sync(None))
+    dcs = (g.coef_shorts // 64 + 127) // 128 * 128
+    ddc = lib.DeviceBuffer(dcs * 2 * n)
+    dq = lib.DeviceBuffer(384 * n)
+    dq.upload(hb.qtabs())
+    th = ti = 0.0
+    rounds = 0
+    for rep in range(reps + 1):
+        t0 = time.perf_counter()
+        rounds = hb.decode_split(dc.ptr, cs, ddc.ptr, dcs)
+        t1 = time.perf_counter()
+        lib.check(lib.L.jga_idct_rgb_batch_dc(C.byref(g), n, dc.ptr, cs, ddc.ptr, dcs, dq.ptr, 1, do.ptr, os_, None))
+        lib.check(lib.L.jga_stream_sync(None))
+        t2 = time.perf_counter()
+        if rep:
+            th += t1 - t0
+            ti += t2 - t1
+    hb.close()
+    dc.free(); do.free(); dq.free(); ddc.free()
+    return {"images": n, "huffman_ms": round(th / reps * 1e3, 3), "idct_rgb_ms": round(ti / reps * 1e3, 3),
+            "sync_rounds": rounds, "scan_MB": round(sum(map(len, jobs)) / 1e6, 1)}
+
+
 def _settle(lib):
     """Before a leg that times single milliseconds: let the leg before it finish dying.  Freeing a job's buffers (6 GB
     of outputs after config 4's 1024-file job) leaves the driver work that runs on for ~0.1-0.2 s and shares the copy
@@ -262,11 +295,15 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
         finally:
             os.sched_setaffinity(0, mine)
 
-    def single(key, what, w, h, samp, ri, stream_n, kernel_n):
+    def single(key, what, w, h, samp, ri, stream_n, kernel_n, photo=False, batch_n=0):
         t_cfg = time.perf_counter()
         n_files = 2 if quick else 4
-        files = [synth.synthetic_jpeg(w, h, samp, quality=90, seed=1234 + i, restart_interval=ri)
-                 for i in range(n_files)]
+        if photo:
+            with ThreadPoolExecutor(max_workers=n_files) as ex:
+                files = list(ex.map(lambda i: synth.photo_like_jpeg(w, h, samp, 90, ri, seed=1 + i), range(n_files)))
+        else:
+            files = [synth.synthetic_jpeg(w, h, samp, quality=90, seed=1234 + i, restart_interval=ri)
+                     for i in range(n_files)]
         px = w * h
         lat = _pipeline_latency(lib, abi, files[0], nthreads)
         order = [i % n_files for i in range(stream_n)]
@@ -286,6 +323,19 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
              "bit_exact_vs_oracle": ok,
              "cpu": None}
         cpu_rates_later(e, files, w, h, cpu_frames)
+        if batch_n:
+            # which of {link, entropy stage, block decode} bounds a stream of such files: per image, the link's
+            # time for its bytes at LINK_GBPS against the two device stages' times in a batch of batch_n (the
+            # stages share the one device: their sum is the device's time per image)
+            sp = _device_split(lib, files, 2 * n_files if quick else batch_n, 2 if quick else 5)
+            nb = sp["images"]
+            e["device"].update(sp, batch=nb)
+            link_ms = h2d / (LINK_GBPS * 1e6)
+            hu, bd = sp["huffman_ms"] / nb, sp["idct_rgb_ms"] / nb
+            e["per_image_ms"] = {"link": round(link_ms, 4), "entropy_stage": round(hu, 4), "block_decode": round(bd, 4)}
+            e["bound_by"] = ("link" if link_ms > hu + bd else "entropy stage" if hu > bd else "block decode")
+            e["device_ceiling_Mpixel_s"] = round(px / (hu + bd) / 1e3, 1)
+            e["bytes_per_pixel"] = round(len(files[0]) / px, 4)
         if ri:
             # (SURVEY §8e's note) the same frame in 8 bands of MCU rows, one per GPU: what ONE of them does —
             # finds its band (host: a pass over the file for the restart markers), writes it as a file of
@@ -355,6 +405,13 @@ def run_configs(nthreads, cpu_threads, lanes=8, group=32, cpu_frames=2, cpu_roun
 
     single("config5_8k_420_dri", "7680x4320 4:2:0 q90, DRI = one MCU row (configs[4]: GPU-parallel Huffman variant)",
            7680, 4320, "420", -1, 4 if quick else 32, 2 if quick else 8)
+    # photograph-like content (README.md:18-22 of the reference: the gain depends on "how much it
+    # is compressed"): a power-law-spectrum synthetic at q90, 0.14-0.17 B/px — the link has room there and the
+    # device's entropy stage + block decode decide the rate
+    single("photo_like_4k_420", "3840x2160 4:2:0 q90, photograph-like content (f^-1.5 spectrum + grain, ~0.14 B/px)",
+           3840, 2160, "420", 0, 8 if quick else 192, 2 if quick else 48, photo=True, batch_n=48)
+    single("photo_like_1080p_420", "1920x1080 4:2:0 q90, photograph-like content (~0.17 B/px)",
+           1920, 1080, "420", 0, 16 if quick else 512, 4 if quick else 128, photo=True, batch_n=128)
     t_cpu = time.perf_counter()
     for entry, files, w, h, frames in deferred:
         entry["cpu"] = cpu_rates(files, w, h, frames)
