@@ -114,9 +114,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-concurrent-proxy", action="store_true",
                     help="skip scale_proxy.concurrent (N children alive at once on the one GPU, each on its own CPUs)")
     ap.add_argument("--input-cache-MB", type=int, default=1024,
-                    help="jga_pipeline_config.input_cache_mb of the headline pipelines (0 = none): pageable "
-                         "files are registered at first sight inside the timed region and DMA'd where they "
-                         "lie from then on - used by the library where the scan clean-up runs on the device")
+                    help="jga_pipeline_config.input_cache_mb of the headline pipelines: > 0 a persistent cache of that "
+                         "many MB (pageable files are registered at first sight inside the timed region and DMA'd "
+                         "where they lie from then on - used by the library where the scan clean-up runs on the "
+                         "device); 0 = the library's default (registrations that live as long as their group); "
+                         "-1 / -2 = none (named copies / host copies)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, report who they are and which CPUs they own, exit "
                          "(gloo; needs no GPU)")
@@ -689,7 +691,7 @@ def main():
     def headline_run(pinned, **kw):
         src = pcyc if pinned else cyc
         mk = lambda n, o, **k2: lib.Pipeline.make_jobs(src(n, o), pinned=pinned, **k2)
-        if not pinned and args.input_cache_MB != 0:
+        if not pinned:
             kw.setdefault("input_cache_mb", args.input_cache_MB)
         pl = lib.Pipeline(device=gpu, nthreads=nthreads, out=abi.JPEG_DECODE_RGB, copy_back=False,
                           transport=2, batch=G, depth=args.lanes, **kw)
@@ -704,7 +706,7 @@ def main():
         if warm_jobs is not None:
             pl.run_jobs(warm_jobs)                                   # W untimed steps
         kept.buf.zero_()
-        if not pinned and kw.get("input_cache_mb", 0) >= 0:
+        if not pinned and kw.get("input_cache_mb", 0) > 0:
             # whatever the warm-up left registered is dropped: every file's FIRST sight — its
             # hipHostRegister — happens inside the timed region
             for v in timed_jobs._keep[0]:

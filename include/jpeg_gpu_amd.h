@@ -408,22 +408,24 @@ typedef struct jga_pipeline_config {
    *  job's first groups — is not configuration: every other value of those fields measured slower or the same in
    *  rounds 3-4, profiles/r4_host_side_steps.md.  Builds made with -DJGA_TUNING still read them from JGA_PIPE_*
    *  environment variables, csrc/jga_tune.h.) */
-  /* --- ingest of caller-owned PAGEABLE buffers without a host copy.  The pipeline keeps up to input_cache_mb MB of
-   *     callers' JPEG buffers registered with the device (hipHostRegister), keyed by address, least recently used
-   *     out first.  A buffer seen for the input_cache_sight-th time (0 = 1: at first sight) is registered — inside
-   *     the run that sees it: 14 us for a 0.77 MB file where copying it costs a core 17 — and from then on the
-   *     device reads its scan where it lies, exactly like a `pinned` job's; until then it is copied as before.
-   *     Only used where the scan clean-up runs on the device (unstuff 2, 0 with few cores, and short runs): a host
-   *     that cleans up reads every byte anyway.
-   *     A registration is only ever used for the file it was made for: every entry carries a FINGERPRINT of its
-   *     buffer (size, the bytes of the first and last 64, a few words of the scan) that the host re-reads at every
-   *     sight; a buffer that was freed and handed out again at the same address with other contents — whose old
-   *     pages the device would still see — fails the check, loses its registration and is registered afresh.
-   *     jga_pipeline_forget_input() drops an entry at once (a caller that re-uses ingest buffers and wants the
-   *     pages unpinned); jga_pipeline_destroy() unregisters everything.
-   *     input_cache_mb = 0 (default): 512 MB.  -1: no cache — the upload's copies name the callers' ordinary buffers
-   *     and the runtime pins what they touch (the pinning is redone per copy).  -2: no cache, and every file that is
-   *     not `pinned` is copied into the group's pinned blob by a host core (rounds 2-3). */
+  /* --- ingest of caller-owned PAGEABLE buffers without a host copy, where the scan clean-up runs on the device
+   *     (unstuff 2, 0 with few cores; a host that cleans up reads every byte anyway).  The pipeline registers the
+   *     callers' JPEG buffers with the device (hipHostRegister: 14 us for a 0.77 MB file where copying it costs a
+   *     core 17) and the copy engine reads their scans where they lie, exactly like a `pinned` job's.
+   *     input_cache_mb = 0 (default): a registration lives as long as the groups that use the buffer and is undone
+   *       by the last of them — NOTHING of the caller's memory is registered once jga_pipeline_run() has returned,
+   *       so the caller may free() or reuse its buffers as it pleases.  (Short runs on a host with cores to spare
+   *       copy small files into the group's pinned blob instead: one copy call per group, see csrc/pipeline.cpp.)
+   *     input_cache_mb > 0: a PERSISTENT cache of that many MB, keyed by address, least recently used out first:
+   *       a buffer seen for the input_cache_sight-th time (0 = 1) is registered and STAYS registered after the run.
+   *       Contract: a buffer the cache may hold must stay allocated until jga_pipeline_forget_input() has been
+   *       called for it or the pipeline is destroyed — freeing registered memory is undefined in HIP.  As a second
+   *       line of defence every entry carries a fingerprint of its file (size, first and last 64 bytes, sixteen
+   *       words of the scan) that is re-read at every sight: a buffer handed out again at the same address with
+   *       other contents loses its registration and is registered afresh.
+   *     -1: no registration — the upload's copies name the callers' ordinary buffers and the runtime pins what they
+   *       touch (per copy).  -2: every file that is not `pinned` is copied into the group's pinned blob by a host
+   *       core (rounds 2-3). */
   int input_cache_mb;
   int input_cache_sight;
   int reserved_[6];            /* zero */
@@ -462,10 +464,10 @@ int  jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int n, int *gr
 /* The same for a whole configuration (its depth and batch): exactly the plan jga_pipeline_run() of a pipeline
  * created from `cfg` makes. */
 int  jga_pipeline_plan_cfg(const jga_pipeline_config *cfg, const jga_job *jobs, int n, int *group_of);
-/* The input cache (on unless input_cache_mb < 0): register [jpeg, jpeg + size) now (a reader that fills its ingest
- * buffers before the first run) / drop it from the cache at once (optional: a stale entry is found by its
- * fingerprint anyway; this unpins the pages now instead of at eviction).  Both return EXIT_SUCCESS or EXIT_FAILURE;
- * forgetting a buffer the cache does not hold is not an error. */
+/* The persistent input cache (input_cache_mb > 0): register [jpeg, jpeg + size) now (a reader that fills its ingest
+ * buffers before the first run) / drop it from the cache at once — REQUIRED before the buffer is freed or reused
+ * for anything the device must not see.  Both return EXIT_SUCCESS or EXIT_FAILURE; forgetting a buffer the cache
+ * does not hold is not an error; registering without a persistent cache is. */
 int  jga_pipeline_register_input(jga_pipeline *pl, const unsigned char *jpeg, int size);
 int  jga_pipeline_forget_input(jga_pipeline *pl, const unsigned char *jpeg);
 /* Counters of the pipeline since it was created: [0] buffers registered, [1] MB registered now, [2] jobs whose
@@ -584,7 +586,8 @@ enum {
   JGA_HUFF_OPT_SUB_BYTES = 1,      /* subsequence length: 32, 64, 128, 256, 512; 0 = by batch */
   JGA_HUFF_OPT_ASSIST_AFTER = 2,   /* rounds before the host walks unsettled stretches (default 12) */
   JGA_HUFF_OPT_SPECULATE = 3,      /* 0 / 1 = the tail is queued behind the first rounds, -1 = never */
-  JGA_HUFF_OPT_TRACE = 4           /* 1: what prepare() and decode() spent where, on stderr */
+  /* 4: retired (round 4's JGA_HUFF_OPT_PIECES): rejected, so that a stale caller does not switch something else on */
+  JGA_HUFF_OPT_TRACE = 5           /* 1: what prepare() and decode() spent where, on stderr */
 };
 int jga_huff_set_option(jga_huff_batch *b, int option, int value);
 

@@ -106,7 +106,7 @@ class jga_band(C.Structure):
                 ("scan_off", C.c_long), ("scan_bytes", C.c_long)]
 
 
-JGA_HUFF_OPT_SUB_BYTES, JGA_HUFF_OPT_ASSIST_AFTER, JGA_HUFF_OPT_SPECULATE, JGA_HUFF_OPT_TRACE = 1, 2, 3, 4
+JGA_HUFF_OPT_SUB_BYTES, JGA_HUFF_OPT_ASSIST_AFTER, JGA_HUFF_OPT_SPECULATE, JGA_HUFF_OPT_TRACE = 1, 2, 3, 5
 
 
 # SURVEY.md §8b ABI numbers (x86-64 SysV)

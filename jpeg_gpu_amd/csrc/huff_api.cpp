@@ -480,13 +480,6 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   // a call per file (0.8 MB files: ~40 GB/s from two batches side by side).  File by file, for as long as the
   // caller's poll says "not yet" (jga_huff_set_upload_poll).
   enum { COPIED_ALREADY = 2 };
-  if (b->upload_poll) {
-    for (int i = 0; i < n && !b->upload_poll(b->before_upload_arg); i++) {
-      if (how[(size_t)i] != NAMED) continue;
-      memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off, prep[i].avail);
-      how[(size_t)i] = COPIED_ALREADY;
-    }
-  }
   memcpy(b->h_blob + b->off_uimg, uimg.data(), sizeof(hj_unstuff_image)*(size_t)n);
   memset(b->h_blob + b->off_info, 0xFF, sizeof(hj_unstuff_info)*(size_t)n);   // (hard_end = "none yet")
   memset(b->h_blob + b->off_perr, 0, 4*(size_t)n);
@@ -514,6 +507,14 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   }
   memcpy(b->h_blob + b->off_qtab, b->qtab.data(), 384*(size_t)n);
   b->qtab_on_device = true;
+  // (the poll comes LAST of the host work: a turn on the link it takes is used at once — ADVICE r5)
+  if (b->upload_poll) {
+    for (int i = 0; i < n && !b->upload_poll(b->before_upload_arg); i++) {
+      if (how[(size_t)i] != NAMED) continue;
+      memcpy(b->h_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off, prep[i].avail);
+      how[(size_t)i] = COPIED_ALREADY;
+    }
+  }
   int ncopies = 1;
   b->copied.assign((size_t)n, 0);
   for (int i = 0; i < n; i++) {

@@ -945,6 +945,9 @@ static __device__ __forceinline__ uint32_t hj_wentry(uint32_t e) {      // e: a 
 #ifndef HJ_WRITE_UNROLL
 #define HJ_WRITE_UNROLL 4
 #endif
+#ifndef HJ_WRITE_PAIRS
+#define HJ_WRITE_PAIRS 0             /* 1: two AC symbols per look-up where nine bits hold both (round 6 A/B: profiles/r6_entropy_ab.md) */
+#endif
 #define HJ_DEZZ_EXT 192              /* k + adv - 1 <= 63 + 127 */
 #define HJ_WRITE_BLOCK 512
 
@@ -966,7 +969,20 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
     const hj_tables *T = A.tables + blockIdx.y;
     for (int i = threadIdx.x; i < 2 << HJ_FAST_BITS; i += NB) {
       (&lds_tabs.dc[0][0])[i] = hj_wentry((&T->dc[0][0])[i]);
-      (&lds_tabs.ac[0][0])[i] = hj_wentry((&T->ac[0][0])[i] & 0xffffu);
+      uint32_t e1 = hj_wentry((&T->ac[0][0])[i] & 0xffffu);
+#if HJ_WRITE_PAIRS
+      // the SECOND AC symbol of the same nine bits, when all of it (code and magnitude) lies inside them:
+      // tot2 | adv2 << 4 | s2 << 11 at bit 17 (0: none).  Taken at run time iff the first one leaves the block open.
+      if (!HJ_IS_ESCAPE(e1) && !(e1 & HJ_W_NOCODE) && HJ_E_ADV(e1) != 127 && HJ_E_TOT(e1) < HJ_FAST_BITS) {
+        const uint32_t t1 = (uint32_t)HJ_E_TOT(e1), tb = (uint32_t)i >> HJ_FAST_BITS, ix = (uint32_t)i & ((1u << HJ_FAST_BITS) - 1u);
+        const uint32_t e2 = T->ac[tb][(ix << t1) & ((1u << HJ_FAST_BITS) - 1u)] & 0xffffu;
+        if (!HJ_IS_ESCAPE(e2) && (uint32_t)HJ_E_TOT(e2) + t1 <= HJ_FAST_BITS) {
+          const uint32_t adv2 = HJ_E_ADV(e2) == 64 ? 127u : (uint32_t)HJ_E_ADV(e2);
+          e1 |= ((uint32_t)HJ_E_TOT(e2) | adv2 << 4 | (uint32_t)HJ_E_S(e2) << 11) << 17;
+        }
+      }
+#endif
+      (&lds_tabs.ac[0][0])[i] = e1;
     }
     for (int i = threadIdx.x; i < HJ_L2_BLOCKS*128; i += NB) {
       const uint32_t e = T->l2[i];
@@ -1053,6 +1069,58 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
   uint8_t *blk8 = reinterpret_cast<uint8_t *>(blk);
   uint32_t pz = 128;
   int pv = 0;
+#if HJ_WRITE_PAIRS
+  uint32_t pz2 = 128;
+  int pv2 = 0;
+  for (;;) {
+    bool running = !waiting && br.before_stop() && n < max_blocks;
+    if (!out.any(running || waiting)) break;
+#pragma unroll
+    for (int u = 0; u < HJ_WRITE_UNROLL; u++) {
+      if (u) running = !waiting && br.before_stop() && n < max_blocks;
+      if (!running) continue;
+      const uint32_t w = br.window();
+      const bool isdc = k == 0;
+      const uint32_t *tb = isdc ? tb_dc : tb_ac;
+      uint32_t e = tb[w >> (32 - HJ_FAST_BITS)];
+      if ((e & 31u) == 0u) {                                 // a code longer than 9 bits (never half of a pair)
+        e = lds_tabs.l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
+        if (HJ_E_LEN(e) > 16) e |= HJ_W_NOCODE;
+      }
+      const uint32_t tot = e & 31u, s = (e >> 12) & 15u;
+      const uint32_t off = 32u - tot;
+      const int vu = (int)__builtin_amdgcn_ubfe(w, off, s);
+      const int vs = __builtin_amdgcn_sbfe((int)w, off, s);
+      const int v = vu - (vs < 0 ? 0 : (int)((1u << s) - 1u));
+      dcv = isdc ? v : dcv;
+      const int kn = k + (int)((e >> 5) & 127u);
+      // the second symbol of the nine bits: only behind a symbol that left the block open, and only if it starts
+      // before the run's stop (the states are settled: the stop is a symbol boundary)
+      const uint32_t e2 = e >> 17;
+      const bool pair = e2 != 0u && kn < 64 && br.room((int)tot + 1);
+      const uint32_t tot2 = pair ? e2 & 15u : 0u, s2 = pair ? e2 >> 11 : 0u;
+      const uint32_t off2 = off - tot2;
+      const int vu2 = (int)__builtin_amdgcn_ubfe(w, off2, s2);
+      const int vs2 = __builtin_amdgcn_sbfe((int)w, off2, s2);
+      const int v2 = vu2 - (vs2 < 0 ? 0 : (int)((1u << s2) - 1u));
+      const int kn2 = kn + (pair ? (int)((e2 >> 4) & 127u) : 0);
+      *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;      // (the previous trip's values)
+      *reinterpret_cast<hj_i16_alias *>(blk8 + pz2) = (int16_t)pv2;
+      pz = s_dezz[kn - 1];
+      pz2 = s_dezz[pair ? kn2 - 1 : HJ_DEZZ_EXT - 1];        // (no second symbol: the spare half-dword)
+      pv = v;
+      pv2 = v2;
+      errbits |= e;
+      errm = max(errm, max(kn & 127, kn2 & 127));
+      br.skip((int)(tot + tot2));
+      waiting = kn2 >= 64;
+      k = waiting ? 0 : kn2;
+    }
+    *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;     // the stores still owed
+    *reinterpret_cast<hj_i16_alias *>(blk8 + pz2) = (int16_t)pv2;
+    pz = 128;
+    pz2 = 128;
+#else
   for (;;) {
     bool running = !waiting && br.before_stop() && n < max_blocks;
     if (!out.any(running || waiting)) break;
@@ -1086,6 +1154,7 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
     }
     *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;     // the store still owed
     pz = 128;
+#endif
     if (out.flush_due(waiting, running && !waiting)) {
       if (waiting && head) dcq.push(dcv);                    // (the lane that decoded the DC symbol reports it)
       out.flush_blocks(waiting, !head, true, c);

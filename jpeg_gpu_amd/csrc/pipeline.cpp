@@ -40,7 +40,7 @@ namespace {
 // jga_pipeline_create and jga_pipeline_plan_cfg, so that a plan is the plan a run makes.
 struct sched_knobs {
   int lanes, batch, link_slots, dev_slots, groups_per_lane, min_group_eq, offload_at, copy_streams;
-  bool ramp_first, blocking, trace;
+  bool ramp_first, blocking, trace, short_ramp;
 };
 sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   sched_knobs k;
@@ -55,6 +55,7 @@ sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   k.groups_per_lane = 4;
   k.min_group_eq = 4;
   k.ramp_first = true;
+  k.short_ramp = false;
   k.offload_at = 8;
   k.copy_streams = 0;
   if (const char *e = jga_tune("JGA_PIPE_DEVICE_SLOTS")) k.dev_slots = atoi(e) > 0 ? atoi(e) : 1;
@@ -63,6 +64,7 @@ sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   if (const char *e = jga_tune("JGA_PIPE_GROUPS_PER_LANE")) k.groups_per_lane = atoi(e) > 0 ? atoi(e) : 1;
   if (const char *e = jga_tune("JGA_PIPE_MIN_GROUP")) k.min_group_eq = atoi(e) > 0 ? atoi(e) : 1;
   if (const char *e = jga_tune("JGA_PIPE_RAMP_FIRST")) k.ramp_first = atoi(e) != 0;
+  if (const char *e = jga_tune("JGA_PIPE_SHORT_RAMP")) k.short_ramp = atoi(e) != 0;
   if (const char *e = jga_tune("JGA_PIPE_LINK_SLOTS")) k.link_slots = atoi(e) > 0 ? atoi(e) : 0;
   if (const char *e = jga_tune("JGA_PIPE_OFFLOAD_AT")) k.offload_at = atoi(e);
   if (jga_tune("JGA_PIPE_TRACE")) k.trace = true;
@@ -113,6 +115,11 @@ struct input_cache {
   size_t cap = 0, held = 0;
   unsigned long long tick = 0;
   int sight = 1;
+  // input_cache_mb > 0: registrations outlive the run that made them (the caller's contract: the buffer stays
+  // allocated until jga_pipeline_forget_input() or jga_pipeline_destroy()).  Default: a registration lives exactly as
+  // long as the groups that hold it — released by its last user, it is unregistered at once, so that nothing of the
+  // caller's memory is still registered when jga_pipeline_run() returns (free() of registered memory).
+  bool persistent = false;
   static constexpr size_t MIN_BYTES = 64u << 10;     // (below this a copy is cheaper than a registration can ever be)
   static constexpr size_t MAX_TRACKED = 4096;        // addresses whose sights are being counted
   std::atomic<long long> n_registered{0}, n_evicted{0}, us_register{0}, n_in_place{0}, n_copied{0}, host_bytes{0}, n_stale{0};
@@ -176,9 +183,32 @@ struct input_cache {
     hipError_t rc = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
     bool foreign = false;
     if (rc == hipErrorHostMemoryAlreadyRegistered) {
-      // the caller (or another pipeline) registered exactly this range and did not say so: the device can address
-      // it as it is — if it really covers the whole file
       (void)hipGetLastError();
+      // Whose registration is it?  If it is one of OURS under another key — a file since freed whose heap range now
+      // holds this buffer — nothing ties this buffer's life to that entry: it could be evicted, dropped as stale or
+      // forgotten while a lane still reads through it.  Such entries go (idle ones) and the registration
+      // is tried again; if one of them is in use, this buffer is copied.
+      bool ours_in_use = false, dropped = false;
+      {
+        std::lock_guard<std::mutex> lk(m);
+        const unsigned char *lo = static_cast<const unsigned char *>(p), *hi = lo + bytes;
+        for (auto jt = map.begin(); jt != map.end(); ) {
+          const unsigned char *a = static_cast<const unsigned char *>(jt->first), *b = a + jt->second.bytes;
+          const bool overlaps = jt->first != p && jt->second.registered && !jt->second.foreign && a < hi && lo < b;
+          if (!overlaps) { ++jt; continue; }
+          if (jt->second.users > 0 || jt->second.busy) { ours_in_use = true; ++jt; continue; }
+          drop(jt->first, jt->second);
+          jt = map.erase(jt);
+          dropped = true;
+        }
+      }
+      if (dropped && !ours_in_use) rc = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
+      if (rc != hipSuccess) (void)hipGetLastError();
+      if (ours_in_use) rc = hipErrorUnknown;                   // (falls through to the failure path: copied)
+    }
+    if (rc == hipErrorHostMemoryAlreadyRegistered) {
+      // the caller (or another pipeline) registered this range and did not say so: the device can address
+      // it as it is — if it really covers the whole file
       // (EVERY page: a range whose two ends lie in other people's registrations — buffers back to back in one malloc
       // arena share the page at their seam — is not covered by them, and a device read of its middle ends the process)
       bool covered = true;
@@ -215,7 +245,11 @@ struct input_cache {
   void release(const void *p) {
     std::lock_guard<std::mutex> lk(m);
     auto it = map.find(p);
-    if (it != map.end() && it->second.users > 0) it->second.users--;
+    if (it == map.end() || it->second.users <= 0) return;
+    if (--it->second.users == 0 && !persistent && !it->second.busy) {
+      drop(p, it->second);                                 // (run-scoped: the last user takes the registration with it)
+      map.erase(it);
+    }
   }
   int forget(const void *p) {
     std::lock_guard<std::mutex> lk(m);
@@ -321,6 +355,18 @@ struct jga_pipeline {
   // 1024 x 1080p 83-89 -> 106-108 (profiles/r3_link_turns.txt; JGA_PIPE_LINK_SLOTS=0: off).
   int link_slots = 2, link_free = 2;
   bool copy_while_waiting = true;
+  // SHORT runs on a host with cores to spare (round 6): the groups' uploads are queued, in the order their lanes get
+  // through prepare, on two copy streams the lanes share — each group ONE copy call out of its pinned blob, into which
+  // its lane's threads have copied the files (the first two groups to arrive name files that lie in pinned memory
+  // instead: their bytes start crossing at once while the others stage).  The link then runs copy behind copy with
+  // no host thread in between: with turns (a lane waits for its copy to arrive, gives the turn, the next lane wakes
+  // and queues its own) every hand-over cost the link ~0.1 ms of idleness — 98 MB of a 128-file shard crossed in
+  // 2.0-2.4 ms where the link needs 1.8 (profiles/r5_short_runs.md, r6_short_runs.md).
+  hipStream_t fifo_streams[2] = {nullptr, nullptr};
+  bool short_fifo = true, short_fifo_pinned = false;
+  int fifo_nstreams = 1, fifo_threads = 1;       // (one copy stream moves 12 MB copies at the link's rate; a lane stages alone)
+  bool short_ramp = false;
+  std::atomic<unsigned> run_ticket{0};
   std::mutex link_mutex;
   std::condition_variable link_cv;
   // transport 2: the lane threads live as long as the pipeline (a run used to create its eight
@@ -668,9 +714,18 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   // a copy call that names it — the caller says it is pinned, or the input cache holds it registered (or registers it
   // now), or, with no cache, ordinary memory the runtime pins per copy — or copied into the pinned blob by this thread.
   std::vector<unsigned char> in_place((size_t)m, 0);
+  // (pinned files keep the turns of round 5: named where they lie by the first groups, copied into the blob by a group
+  // that waits for the link — 3.50-3.53 ms median per 128-file shard against 3.6-3.9 through the FIFO; ordinary files
+  // take the FIFO: 3.5-3.9 against 4.0 with a registration per file and turns, profiles/r6_short_runs.md)
+  bool all_pinned = true;
+  for (int i = 0; i < m; i++) all_pinned = all_pinned && (jobv[i]->pinned & 1);
+  const bool fifo = short_run && shared && on_device && !pl->offload_cleanup && pl->short_fifo && pl->fifo_streams[0]
+   && (!all_pinned || pl->short_fifo_pinned);
+  const unsigned ticket = fifo ? pl->run_ticket.fetch_add(1) : 0u;
   {
     for (int i = 0; i < m && on_device; i++) {
-      if (jobv[i]->pinned & 1) in_place[(size_t)i] = 1;
+      if (fifo) in_place[(size_t)i] = ticket < 2 && (jobv[i]->pinned & 1);    // (everything else goes through the blob)
+      else if (jobv[i]->pinned & 1) in_place[(size_t)i] = 1;
       else if (pl->inputs.acquire(jobv[i]->jpeg, (size_t)jobv[i]->size)) {
         in_place[(size_t)i] = 1;
         held.v.push_back(jobv[i]->jpeg);
@@ -682,9 +737,10 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
     jga_huff_set_device_unstuff(l.hb, on_device);
     jga_huff_set_inputs_pinned(l.hb, 0);
     jga_huff_set_input_flags(l.hb, in_place.data(), m);
+    if (fifo) jga_huff_set_threads(l.hb, pl->fifo_threads);       // (24 threads copying on a 16-CPU grant move LESS than 8)
     jga_huff_set_blocking_waits(l.hb, pl->blocking);
     jga_huff_set_device_shared(l.hb, shared ? (short_run ? 1 : 2) : 0);   // (2: a long run — throughput, not the last chain, is what counts)
-    jga_huff_set_copy_stream(l.hb, pl->copy_streams.empty() ? nullptr
+    jga_huff_set_copy_stream(l.hb, fifo ? pl->fifo_streams[pl->fifo_nstreams > 1 ? ticket & 1u : 0u] : pl->copy_streams.empty() ? nullptr
      : pl->copy_streams[pl->copy_next.fetch_add(1)%pl->copy_streams.size()]);
   }
   // A lone image whose Huffman tables do not fit the device lookup format takes the host
@@ -692,10 +748,10 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   bool host_entropy = false;
   jpeg_header hdr;
   link_turn link(pl);
-  jga_huff_set_upload_gate(l.hb, pl->link_slots > 0 ? &link_turn::take_hook : nullptr, &link);
-  // (short runs on a host with cores to spare: a group waiting for the link copies its files into its blob
-  // meanwhile — JGA_PIPE_COPY_WAITING=0 in the tuning build: never)
-  if (pl->link_slots > 0 && short_run && on_device && !pl->offload_cleanup && pl->copy_while_waiting) {
+  jga_huff_set_upload_gate(l.hb, pl->link_slots > 0 && !fifo ? &link_turn::take_hook : nullptr, &link);
+  // (short runs with turns — JGA_PIPE_SHORT_FIFO=0 in the tuning build: a group waiting for the link copies its
+  // files into its blob meanwhile — JGA_PIPE_COPY_WAITING=0: never)
+  if (pl->link_slots > 0 && !fifo && short_run && on_device && !pl->offload_cleanup && pl->copy_while_waiting) {
     jga_huff_set_upload_poll(l.hb, &link_turn::poll_hook);
   }
   const int prc = jga_huff_prepare(l.hb, ptrs.data(), sizes.data(), m, &g, l.stream);
@@ -896,7 +952,7 @@ uint64_t geometry_key(const unsigned char *p, int size) {
 // files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
 // entropy stage and block decode of different groups overlap: about groups_per_lane groups
 // per lane, none below min_group_eq frame equivalents.
-struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; };
+struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; bool short_ramp = false; };
 void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups) {
   const int nl = pp.lanes, batch = pp.batch;
   std::unordered_map<uint64_t, long long> pixels;            // geometry -> pixels of all its jobs
@@ -935,6 +991,22 @@ void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<
     if (pp.ramp_first && made < nl && nl > 1 && pixels[key] >= 3ll*nl*cap*px) {
       cap = (cap*(made + 1) + nl - 1)/nl;
       if (cap < 1) cap = 1;
+    }
+    else if (pp.short_ramp && px > 0) {
+      // A SHORT job (one group per lane): what it waits for is the link — every byte has to cross before the last
+      // chain of kernels can start — so the first groups are small (their bytes are staged and crossing while the
+      // bigger ones are still being staged) and rise to an even size: weights min(k + 1, 0.7 G + 0.15) over G groups
+      // (128 files in 8 groups: 4, 8, 12, 16, 20, 23, 23, 22).
+      const long long count = pixels[key]/px, G = (count + cap - 1)/cap;
+      if (G >= 4 && G <= nl) {
+        const double top = 0.7*(double)G + 0.15;
+        double sum = 0, upto = 0;
+        for (long long k = 0; k < G; k++) sum += (double)(k + 1) < top ? (double)(k + 1) : top;
+        for (long long k = 0; k <= made && k < G; k++) upto += (double)(k + 1) < top ? (double)(k + 1) : top;
+        const double before = upto - ((double)(made + 1) < top ? (double)(made + 1) : top);
+        const long long a = (long long)((double)count*before/sum + 0.5), b = made + 1 >= G ? count : (long long)((double)count*upto/sum + 0.5);
+        cap = b - a < 1 ? 1 : b - a;
+      }
     }
     if ((long long)groups[it->second].size() >= cap) { open.erase(it); made++; }
   }
@@ -1049,9 +1121,20 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->link_slots = pl->link_free = K.link_slots;
     if (pl->cfg.input_cache_mb >= 0) {
       pl->inputs.cap = (size_t)(pl->cfg.input_cache_mb > 0 ? pl->cfg.input_cache_mb : 512) << 20;
-      pl->inputs.sight = pl->cfg.input_cache_sight > 0 ? pl->cfg.input_cache_sight : 1;
+      pl->inputs.persistent = pl->cfg.input_cache_mb > 0;
+      pl->inputs.sight = pl->inputs.persistent && pl->cfg.input_cache_sight > 0 ? pl->cfg.input_cache_sight : 1;
     }
     if (const char *e = jga_tune("JGA_PIPE_COPY_WAITING")) pl->copy_while_waiting = atoi(e) != 0;
+    if (const char *e = jga_tune("JGA_PIPE_SHORT_FIFO")) { pl->short_fifo = atoi(e) != 0; pl->short_fifo_pinned = atoi(e) > 1; }
+    if (const char *e = jga_tune("JGA_PIPE_FIFO_STREAMS")) pl->fifo_nstreams = atoi(e) > 1 ? 2 : 1;
+    if (const char *e = jga_tune("JGA_PIPE_FIFO_THREADS")) pl->fifo_threads = atoi(e) > 0 ? atoi(e) : 1;
+    pl->short_ramp = K.short_ramp;
+    for (int i = 0; i < 2 && pl->short_fifo; i++) {
+      if (!hip_ok(hipStreamCreateWithFlags(&pl->fifo_streams[i], hipStreamNonBlocking), "hipStreamCreate")) {
+        jga_pipeline_destroy(pl);
+        return nullptr;
+      }
+    }
     for (int i = 0; i < K.copy_streams; i++) {                 // (measured: profiles/r3_pipe_sweep.txt)
       hipStream_t cs = nullptr;
       if (!hip_ok(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking), "hipStreamCreate")) {
@@ -1093,7 +1176,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
     std::vector<std::vector<jga_job *>> groups;
     {
       std::vector<std::vector<int>> plan;
-      plan_groups({nl, batch, pl->groups_per_lane, pl->min_group_eq, pl->ramp_first != 0}, jobs, n, plan);
+      plan_groups({nl, batch, pl->groups_per_lane, pl->min_group_eq, pl->ramp_first != 0, pl->short_ramp}, jobs, n, plan);
       groups.resize(plan.size());
       for (size_t k = 0; k < plan.size(); k++) {
         groups[k].reserve(plan[k].size());
@@ -1109,6 +1192,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
       std::lock_guard<std::mutex> lk(pl->run_mutex);
       pl->run_groups = &groups; pl->run_next = &next; pl->run_threads = per;
       pl->run_done = 0;
+      pl->run_ticket.store(0);
       pl->run_gen++;
     }
     pl->run_cv.notify_all();
@@ -1136,7 +1220,7 @@ JGA_EXPORT int jga_pipeline_run(jga_pipeline *pl, jga_job *jobs, int n) {
 JGA_EXPORT int jga_pipeline_plan_cfg(const jga_pipeline_config *cfg, const jga_job *jobs, int n, int *group_of) {
   std::vector<std::vector<int>> plan;
   const sched_knobs K = resolve_knobs(*cfg);     // (what jga_pipeline_create makes of the same configuration)
-  plan_groups({K.lanes, K.batch, K.groups_per_lane, K.min_group_eq, K.ramp_first}, jobs, n, plan);
+  plan_groups({K.lanes, K.batch, K.groups_per_lane, K.min_group_eq, K.ramp_first, K.short_ramp}, jobs, n, plan);
   for (size_t k = 0; k < plan.size(); k++) for (int i : plan[k]) group_of[i] = (int)k;
   return (int)plan.size();
 }
@@ -1149,7 +1233,9 @@ JGA_EXPORT int jga_pipeline_plan(int lanes, int batch, const jga_job *jobs, int 
 }
 
 JGA_EXPORT int jga_pipeline_register_input(jga_pipeline *pl, const unsigned char *jpeg, int size) {
-  if (!pl->inputs.enabled()) return jga_fail("pipeline: no input cache (jga_pipeline_config.input_cache_mb < 0)");
+  if (!pl->inputs.enabled() || !pl->inputs.persistent) {
+    return jga_fail("pipeline: no persistent input cache (jga_pipeline_config.input_cache_mb must be > 0)");
+  }
   if (!hip_ok(hipSetDevice(pl->cfg.device), "hipSetDevice")) return EXIT_FAILURE;
   if (!pl->inputs.acquire(jpeg, (size_t)(size > 0 ? size : 0), false)) {
     return jga_fail("pipeline: could not register %d bytes at %p (cache of %d MB, buffers under 64 KB are never registered)",
@@ -1184,6 +1270,7 @@ JGA_EXPORT void jga_pipeline_destroy(jga_pipeline *pl) {
   for (auto &l : pl->lanes) free_lane(l);
   pl->inputs.clear();
   for (auto cs : pl->copy_streams) (void)hipStreamDestroy(cs);
+  for (auto cs : pl->fifo_streams) if (cs) (void)hipStreamDestroy(cs);
   for (auto &w : pl->workers) {
     free_slot(w.slots[0]);
     free_slot(w.slots[1]);

@@ -476,11 +476,19 @@ def test_pipeline_input_cache_registers_pageable_buffers(gpu, orc, synth):
             pl.register_input(big)                                              # larger than the whole cache
     finally:
         pl.close()
-    # the default is a cache of 512 MB
+    # the default: registrations that live as long as the groups that use them — the files are read where they lie,
+    # and NOTHING of the caller's memory is still registered when the run returns (a caller is free to
+    # free() its buffers the moment jga_pipeline_run is back); explicit registration needs the persistent cache
     pl = gpu.Pipeline(device=0, nthreads=4, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2, unstuff=2)
     try:
+        jobs = run(pl, list(range(10)))
+        c = pl.counters()
+        assert c["registered"] == 10 and c["registered_MB"] == 0 and all(j.host_bytes == 0 for j in jobs)
         run(pl, list(range(10)))
-        assert pl.counters()["registered"] == 10
+        c = pl.counters()
+        assert c["registered"] == 20 and c["registered_MB"] == 0 and c["evicted"] == 0
+        with pytest.raises(gpu.JgaError):
+            pl.register_input(arrs[0])
     finally:
         pl.close()
     # no cache: -1 names the callers' memory in the copies (no host pass), -2 copies it
@@ -525,7 +533,8 @@ def test_input_cache_never_serves_a_stale_buffer(gpu, orc, synth):
     addr = libc.mmap(None, n, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, -1, 0)
     assert addr not in (None, C.c_void_p(-1).value)
     out = np.zeros(g.rgb_bytes, np.uint8)
-    pl = gpu.Pipeline(device=0, nthreads=2, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2, unstuff=2)
+    pl = gpu.Pipeline(device=0, nthreads=2, out=abi.JPEG_DECODE_RGB, copy_back=True, transport=2, batch=1, depth=2, unstuff=2,
+                      input_cache_mb=64)                     # (the persistent cache: registrations outlive their runs)
     try:
         def decode_what_lies_there():
             buf = np.ctypeslib.as_array((C.c_ubyte * n).from_address(addr))

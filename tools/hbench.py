@@ -21,6 +21,8 @@ if os.environ.get("CONTENT") == "light":       # bench.py's lighter content: smo
         img = 128 + 60 * np.sin((6 + i) * xx * (cc + 1)) * np.cos(4 * yy) + r.normal(0, 2, (h, w, 3)).astype(np.float32)
         return synth.encode_pixels(np.clip(img, 0, 255).astype(np.uint8), samp, 90, restart_interval=ri)
     distinct = [photo_like(i) for i in range(min(n, 6))]
+elif os.environ.get("CONTENT") == "photo":     # round 6's tracked content class: f^-1.5 spectrum + grain, 0.14-0.17 B/px
+    distinct = [synth.photo_like_jpeg(w, h, samp, 90, ri, seed=1 + i) for i in range(min(n, 4))]
 else:
     distinct = [synth.synthetic_jpeg(w, h, samp, quality=90, restart_interval=ri, seed=1234 + i)
                 for i in range(min(n, 6))]

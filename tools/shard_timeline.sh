@@ -40,6 +40,18 @@ t0 = last[0][0]
 print("events of the last run: %d; span %.3f ms" % (len(last), (max(x[1] for x in last) - t0) / 1e6))
 h2d = [x for x in last if "HOST_TO_DEV" in x[2] and x[1] - x[0] > 20000]
 print("H2D copies > 20 us: %d, first starts %.3f, last ends %.3f ms; sum of durations %.3f ms" % (len(h2d), (h2d[0][0] - t0) / 1e6, (max(x[1] for x in h2d) - t0) / 1e6, sum(x[1] - x[0] for x in h2d) / 1e6))
+# the link: union of the H2D copies' intervals against the run's span, and every copy of 0.2 MB and more
+hv = sorted((s, e) for s, e, n, q in last if "HOST_TO_DEV" in n)
+lb, cs, ce = 0, hv[0][0], hv[0][1]
+for s, e in hv[1:]:
+    if s > ce: lb += ce - cs; cs, ce = s, e
+    else: ce = max(ce, e)
+lb += ce - cs
+span = max(x[1] for x in last) - t0
+print("link busy (union of H2D copies) %.3f ms = %.2f of the span; until the last byte is over (%.3f ms): %.2f" % (
+    lb / 1e6, lb / span, (max(e for s, e in hv) - t0) / 1e6, lb / (max(e for s, e in hv) - t0)))
+print("H2D copies of 50 us and more (start ms, duration us, stream):")
+print("  " + "  ".join("%.2f/%d/%s" % ((s - t0) / 1e6, (e - s) / 1e3, q) for s, e, n, q in last if "HOST_TO_DEV" in n and e - s > 50000))
 per = collections.defaultdict(list)
 for s, e, n, q in last:
     if not n.startswith("copy"): per[n].append((s, e))
