@@ -158,31 +158,53 @@ class quiet_stdout:
 
 
 def dry_launch(args, rank, local_rank, world):
-    """Who am I, which CPUs are mine — the launch path without the GPU work (CPU test)."""
+    """Who am I, which CPUs are mine — the launch path without the GPU work (CPU test): the ranks come up over gloo,
+    pin themselves, run `--steps` stand-in steps (the host entropy stage on a small file) between the same fences the
+    real run uses, and rank 0 prints who they are.  JGA_BENCH_FAIL_RANK = "r" (an exception on rank r in the middle
+    of its steps) or "r,die" (the process is gone without a word) exercise the failure path: every rank leaves
+    non-zero within seconds and rank 0's line names the rank."""
+    import torch
     import torch.distributed as dist
-    from jpeg_gpu_amd import shard
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if world > 1:
-        with quiet_stdout():
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist.barrier()
+    import __graft_entry__
+    __graft_entry__.build()
+    from jpeg_gpu_amd import lib, shard, synth
+    global _COMM
+    comm = _COMM = Comm(torch, dist, rank, world, None, True)
     pin = {} if args.no_pin else shard.pin_rank_to_gpu_node(local_rank, world)
     quota = shard.cpu_quota()
     me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
           "cpus": sorted(os.sched_getaffinity(0)), "pin": pin,
           "cpu_budget": shard.rank_cpu_budget(len(os.sched_getaffinity(0)), world, quota)}
-    everyone = [me]
-    if world > 1:
-        everyone = [None] * world
-        dist.all_gather_object(everyone, me)
-        dist.barrier()
-        dist.destroy_process_group()
+    fail = os.environ.get("JGA_BENCH_FAIL_RANK", "").split(",")
+    data = synth.synthetic_jpeg(160, 96, "420", seed=1 + rank)
+    _, g = lib.geom_of(data)
+    comm.barrier()
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        lib.entropy_decode(data, g)
+        if fail[0] != "" and int(fail[0]) == rank and step == args.steps // 2:
+            if fail[1:] == ["die"]:
+                os._exit(9)
+            raise RuntimeError("injected failure in step %d (JGA_BENCH_FAIL_RANK)" % step)
+    comm.barrier()
+    rate, dt = comm.throughput(args.steps * 160 * 96, time.perf_counter() - t0)
+    everyone = comm.gather(me)
+    comm.close()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": everyone}), flush=True)
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "steps": args.steps, "ranks": everyone,
+                          "pixels_per_s": round(rate, 1)}), flush=True)
     return 0
 
 
 # ---- ranks talk over RCCL where it comes up, gloo where it does not -------------------------------
+
+class RankFailed(Exception):
+    """Some rank of the job failed; .ranks = which (empty: one died without saying), .why = what they said."""
+
+    def __init__(self, ranks, why):
+        Exception.__init__(self, why)
+        self.ranks, self.why = list(ranks), why
+
 
 class Comm:
     """The job's control plane.  The data path needs no collective, so all the ranks exchange is
@@ -196,10 +218,12 @@ class Comm:
         self.group, self.device, self.backend, self.note = None, "cpu", "none", None
         if world <= 1:
             return
+        import datetime as _dt
+        self.timeout = _dt.timedelta(seconds=int(os.environ.get("JGA_BENCH_COMM_TIMEOUT_S", "300")))
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with quiet_stdout():
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=self.timeout)
             dist.barrier()                                           # (connects the pairs now, while stdout is away)
         self.backend = "gloo"
         if share or os.environ.get("JGA_BENCH_NO_RCCL") == "1":
@@ -226,8 +250,29 @@ class Comm:
             self.note = "RCCL group not usable (%s): barrier and reductions over gloo" % (why or "another rank failed")
             log("rank %d: %s" % (rank, self.note))
 
+    # -- is everybody still there?  Before every collective the ranks exchange their state over gloo: a rank that
+    # failed (an exception anywhere in its body: a job of the timed region, one wrong byte, a HIP error) enters the
+    # same exchange from its handler with ok = False, so the others learn WHO failed and why instead of waiting in a
+    # barrier until the backend's timeout; a rank that died outright (abort, kill) closes its sockets and the
+    # exchange raises on the others at once.  Either way every rank leaves non-zero and rank 0's line says which.
+    def status(self, ok=True, err=None):
+        if self.world <= 1:
+            return
+        mine = {"rank": self.rank, "ok": bool(ok), "err": err}
+        everyone = [None] * self.world
+        try:
+            self.dist.all_gather_object(everyone, mine)                  # (gloo)
+        except Exception as e:                                           # a peer is gone: its sockets closed under us
+            raise RankFailed([], "rank %d lost a peer during the status exchange (%s: %s) - a rank died without "
+                             "reporting" % (self.rank, type(e).__name__, str(e)[:160]))
+        bad = [r for r in everyone if r and not r["ok"]]
+        if bad and ok:
+            raise RankFailed([r["rank"] for r in bad],
+                             "; ".join("rank %d: %s" % (r["rank"], r["err"]) for r in bad))
+
     def barrier(self):
         if self.world > 1:
+            self.status()
             if self.group is not None:
                 self.dist.barrier(group=self.group)
             else:
@@ -236,6 +281,7 @@ class Comm:
     def reduce(self, value, op):
         if self.world <= 1:
             return float(value)
+        self.status()
         t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op), group=self.group)
         return float(t.item())
@@ -248,6 +294,7 @@ class Comm:
     def gather(self, obj):
         if self.world <= 1:
             return [obj]
+        self.status()
         out = [None] * self.world
         self.dist.all_gather_object(out, obj)                        # (gloo)
         return out
@@ -580,7 +627,44 @@ def emit(full):
 
 # ---- main -------------------------------------------------------------------------------------
 
+_COMM = None                  # the rank's control plane once it is up (the failure handler below needs it)
+
+
 def main():
+    """The rank's body inside the failure protocol (Comm.status): a rank that fails says so to the others before it
+    leaves; ranks that learn of a failed peer leave non-zero too; rank 0 prints ONE line naming the rank(s)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    def failure_line(ranks, why):
+        if rank == 0:
+            print(json.dumps({"error": _short(why, 600), "failed_ranks": ranks, "n_gpus": world, "metric": METRIC,
+                              "value": None}), flush=True)
+    try:
+        return _rank_main()
+    except RankFailed as e:                                  # somebody else failed
+        log("rank %d: leaving, a rank of the job failed: %s" % (rank, e.why))
+        failure_line(e.ranks, e.why)
+        os._exit(3)                                          # (no orderly shutdown: the group is broken)
+    except SystemExit as e:
+        if e.code in (0, None) or _COMM is None or _COMM.world <= 1:
+            raise
+        why = str(e.code)
+    except BaseException as e:
+        if _COMM is None or _COMM.world <= 1:
+            raise
+        why = "%s: %s" % (type(e).__name__, e)
+        import traceback
+        traceback.print_exc()
+    try:
+        _COMM.status(ok=False, err=_short(why, 300))         # tell the others (they are in, or on their way to, an exchange)
+    except Exception:
+        pass
+    failure_line([rank], "rank %d: %s" % (rank, why))
+    os._exit(1)
+
+
+def _rank_main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -641,7 +725,8 @@ def main():
             pin = dict(pin, cpus=len(take), cpu_list=",".join(map(str, take)))
     torch.cuda.set_device(gpu)
     lib.check(lib.L.jga_set_device(gpu))
-    comm = Comm(torch, dist, rank, world, gpu, share)
+    global _COMM
+    comm = _COMM = Comm(torch, dist, rank, world, gpu, share)
 
     def fence():
         comm.barrier()

@@ -142,7 +142,7 @@ static void choose_wide(jga_huff_batch *b, std::vector<hj_prepared> &prep, int n
     for (int i = 0; i < n; i++) hj_prepare_wide(&prep[(size_t)i]);
     return;
   }
-  if (b->sub_log2 > HJ_SUB_LOG2_MAX || jga_tune("JGA_HUFF_NO_WIDE") || jga_tune("JGA_HUFF_NO_SHARED_WIDE")) return;
+  if (jga_tune("JGA_HUFF_NO_WIDE") || jga_tune("JGA_HUFF_NO_SHARED_WIDE")) return;
   // (not in a long run of a pipeline, device_shared == 2: there the 85 KB of LDS a list workgroup with these tables
   // takes are the other lanes' dense and write workgroups' — 1080p in a steady state 130-135 Gpixel/s with them,
   // 139-141 without; a SHORT run, which waits for its last group's chain, keeps them: the 128-file shard 3.35-3.54 ms
@@ -299,15 +299,13 @@ static void fill_sync_args(const jga_huff_batch *b, hj_args &A) {
 // tuning knobs of the rounds, read once (thread-safe: several pipeline lanes decode at the same time)
 namespace {
 struct round_knobs {
-  int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, sparse_from = -1, lean = 1, list_from = -1, it_list = 8, by_block_subs = 64*1024;
+  int it0 = 0, it1 = 0, group = 6, flush_lanes = 16, lean = 1, list_from = -1, it_list = 8, by_block_subs = -1;
   round_knobs() {
     const char *e = jga_tune("JGA_HUFF_ITERS");     // "first,later,group": in-group iterations, rounds per host check
     if (e) sscanf(e, "%d,%d,%d", &it0, &it1, &group);
     if (e && it0 < 1) it0 = 1;
     if (e && it1 < 1) it1 = 1;
     if (group < 1) group = 1;
-    e = jga_tune("JGA_HUFF_SPARSE_FROM");            // first round run by the sparse kernel (default: by batch size)
-    if (e) sparse_from = atoi(e);
     e = jga_tune("JGA_HUFF_LIST");                   // "first list round[,steps inside a workgroup]"; 0: no list rounds (A/B knob)
     if (e) {
       sscanf(e, "%d,%d", &list_from, &it_list);
@@ -323,8 +321,13 @@ struct round_knobs {
     if (flush_lanes < 1) flush_lanes = 1;
   }
 };
-const round_knobs &the_round_knobs() { static const round_knobs K; return K; }
+round_knobs &the_round_knobs_rw() { static round_knobs K; return K; }
+const round_knobs &the_round_knobs() { return the_round_knobs_rw(); }
 }  // namespace
+// Tuning build only (jga_tune() is NULL elsewhere and nothing changes): read the JGA_HUFF_* knobs of the rounds again —
+// tools/policy_sweep.py forces one plan after the other onto the same batch in one process.  Not thread-safe: no
+// decode may be running.
+extern "C" JGA_EXPORT void jga_huff_reload_tuning(void) { the_round_knobs_rw() = round_knobs(); }
 // In-group iterations per launch: three — the long, thin tail of the propagation is cheaper as
 // further launches than as resident groups — except for a small batch of frames cut into long
 // restart intervals with 64-byte subsequences (hj_choose_sub_log2), whose chains are twice as
@@ -790,8 +793,8 @@ JGA_EXPORT int jga_huff_image_copied(const jga_huff_batch *b, int i) {
 JGA_EXPORT int jga_huff_set_option(jga_huff_batch *b, int option, int value) {
   switch (option) {
     case JGA_HUFF_OPT_SUB_BYTES :
-      b->force_sub_log2 = value == 32 ? 5 : value == 64 ? 6 : value == 128 ? 7 : value == 256 ? 8 : value == 512 ? 9 : 0;
-      return value == 0 || b->force_sub_log2 ? EXIT_SUCCESS : jga_fail("huff: subsequence length %d (32, 64, 128, 256 or 512)", value);
+      b->force_sub_log2 = value == 32 ? 5 : value == 64 ? 6 : value == 128 ? 7 : 0;
+      return value == 0 || b->force_sub_log2 ? EXIT_SUCCESS : jga_fail("huff: subsequence length %d (32, 64 or 128)", value);
     case JGA_HUFF_OPT_ASSIST_AFTER : b->assist_after = value > 0 ? value : 0; return EXIT_SUCCESS;
     case JGA_HUFF_OPT_SPECULATE : b->speculate = value < 0 ? -1 : 0; return EXIT_SUCCESS;
     case JGA_HUFF_OPT_TRACE : b->trace = value != 0; return EXIT_SUCCESS;
@@ -889,6 +892,42 @@ static double thread_cpu_ms() {
   return (double)ts.tv_sec*1e3 + (double)ts.tv_nsec*1e-6;
 }
 
+// ---- the plan of a decode's rounds: ONE table (round 6) ---------------------------------------------------------
+// What a batch is, as far as the choice goes:
+//   crowd   alone and small  (nobody else on the device, at most 200 k subsequences: 8 x 4K, 32 x 1080p)
+//           fills or shares  (a pipeline's lanes side by side, or a batch that fills the device by itself)
+//   size    subsequences in the batch (b->total_sub)
+//   own12   the batch brought 12-bit AC tables per image (at most four images, alone: hj_wide_ac)
+//   dri     restart intervals (chains end at the next marker)
+// and what is chosen for it:
+//   lists     the rounds after the first launch run from work lists (hj_list_build + hj_sync_list) instead of the dense
+//             kernel again
+//   iters     in-group steps of a dense launch
+//   by_block  the write pass one lane per BLOCK (hj_block_starts + hj_write_blocks) instead of hj_write
+//
+//   crowd            size        own12  dri  | lists  iters                       by_block | measured (ms, chosen / other)
+//   alone and small  <= 64 k     any    any  | no     3 (4 own12, 6 long dri)     yes      | 1 x 1080p 0.40 / 0.45-0.49 lists; 0.41 -> 0.32 by block (r5_list_rounds, r5_lone_frame_chain)
+//   alone and small  64-200 k    yes    any  | no     4                           no       | 4 x 4K own tables 0.522 / 0.536 lists
+//   alone and small  64-200 k    no     yes  | no     3 (6 long dri)              no       | 8K DRI frame 0.66 / 0.69 lists
+//   alone and small  64-200 k    no     no   | yes    3                           no       | 16 x 1080p 0.522 / 0.543 dense; 8 x 4K 0.592 / 0.612
+//   fills or shares  any         -      any  | yes    3 (6 long dri)              no       | 48 x 4K 1.82-1.86 / 1.91-1.96; 64 x 1080p 0.87 / 0.95
+// (the tuning build's JGA_HUFF_LIST / JGA_HUFF_ITERS / JGA_HUFF_BY_BLOCK force a column; tools/policy_sweep.py runs every
+// forced alternative over geometries x samplings x batch sizes x qualities x contents: profiles/r6_policy_sweep.md)
+struct round_choice { bool lists, by_block; int iters; };
+static round_choice choose_rounds(const jga_huff_batch *b) {
+  const round_knobs &K = the_round_knobs();
+  const bool alone_small = !b->device_shared && b->total_sub <= 200u*1024u;
+  const bool own12 = b->wide && !b->wide_shared;
+  const bool dri = b->geom.restart_interval > 0;
+  round_choice R;
+  R.iters = auto_iters(b);
+  R.lists = !(alone_small && (b->total_sub <= 64u*1024u || own12 || dri));
+  R.by_block = !b->device_shared && b->total_sub <= 64u*1024u;
+  if (K.list_from >= 0) R.lists = K.list_from < HJ_MAX_ROUNDS;
+  if (K.by_block_subs >= 0) R.by_block = !b->device_shared && b->total_sub <= (uint32_t)K.by_block_subs;
+  return R;
+}
+
 // ---- a decode, in two halves -------------------------------------------------------------------------------
 // decode_begin() queues the start states, the first burst of synchronisation rounds and — speculatively, see
 // below — the whole tail (prefix sums, write pass, DC values, verdict copy) and RETURNS: nothing has been waited
@@ -899,7 +938,7 @@ static double thread_cpu_ms() {
 // write pass and it — and asks decode_end() whether what it queued saw the final planes (`*valid_behind`).
 struct decode_plan {
   hj_args A;
-  int it0, it1, group, sparse_from, assist_after, lean, list_from, it_list;
+  int it0, it1, group, assist_after, lean, list_from, it_list;
   bool speculate, by_block;
 };
 static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, short *d_dc, long long dc_stride, decode_plan &P) {
@@ -929,10 +968,7 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
     A.dc_diff = b->d_dc;
     A.dc_val = d_dc ? (int16_t *)d_dc : b->d_dc + b->dc_cap;
     A.dc_stride = (long long)stride;
-    // A small batch alone on the device writes its planes one lane per BLOCK (hj_block_starts + hj_write_blocks): what a
-    // lone frame waits for in hj_write is one lane's ~206 symbols, 90 us of a 1080p frame's 410.
-    const round_knobs &K0 = the_round_knobs();
-    P.by_block = !b->device_shared && b->sub_log2 <= HJ_SUB_LOG2_MAX && b->total_sub <= (uint32_t)K0.by_block_subs;
+    P.by_block = choose_rounds(b).by_block;
     if (P.by_block) {
       const size_t bneed = stride*(size_t)b->nimages;
       if (bneed > b->blkpos_cap) {
@@ -947,35 +983,13 @@ static int make_plan(jga_huff_batch *b, short *d_coef, long long coef_stride, sh
   A.coef = (int16_t *)d_coef;
   A.coef_stride = coef_stride;
   const round_knobs &K = the_round_knobs();
-  const bool long_subs = b->sub_log2 > HJ_SUB_LOG2_MAX;     // no LDS rows that long: global-memory readers only
-  const int it_auto = auto_iters(b);
-  P.it0 = K.it0 > 0 ? K.it0 : it_auto;
-  P.it1 = K.it1 > 0 ? K.it1 : it_auto;
+  const round_choice R = choose_rounds(b);
+  P.it0 = K.it0 > 0 ? K.it0 : R.iters;
+  P.it1 = K.it1 > 0 ? K.it1 : R.iters;
   P.group = K.group;
   P.lean = K.lean;
   P.assist_after = b->assist_after > 0 ? b->assist_after : 12;
-  // Which kernel runs the later rounds where the list rounds (below) do not: subsequences of 256 / 512 bytes, the tuning
-  // build's JGA_HUFF_LIST=0.  The sparse one (a wave per 256 subsequences, rows read from
-  // global memory) is for batches that fill the device: there a dense launch pays staging for
-  // every group that still has one moving lane.  Up to ~200k subsequences (8 x 4K, 32 x 1080p) the
-  // dense kernel's LDS rows make each step of the chain shorter and nothing else wants the CUs:
-  // one 1080p frame 0.55 -> 0.48 ms, one 4K 0.62 -> 0.52, 8 x 4K 0.71 -> 0.68, but 16 x 4K 0.96 -> 1.05
-  // (profiles/r3_entropy_stage_steps.md).
-  // (with other decodes beside it — a pipeline's lanes — the groups fill the device together: 1024 x 1080p
-  // in groups of 32 ran 22.5 ms with the sparse kernel and 24.2 with the dense one)
-  const bool small_batch = !b->device_shared && b->total_sub <= 200u*1024u;
-  P.sparse_from = long_subs ? 0 : K.sparse_from >= 0 ? K.sparse_from : small_batch ? HJ_MAX_ROUNDS : 1;
-  // Batches that fill the device (or share it): from the second launch on only the subsequences that still move run,
-  // from work lists (hj_sync_list) — one step of the chain per launch, several inside a workgroup once an image's list
-  // fits one; 48 x 4K: 370 us of list rounds where the sparse kernel took 500, on a tenth of its instructions.  A small
-  // batch alone on the device keeps the dense kernel for every round: its in-group steps are ~10 us shorter than a
-  // list step's (no list to read, rows already staged), and nothing else wants the CUs its idle lanes hold.
-  // (alone on the device: lists from 64 k subsequences on unless the batch brought 12-bit tables per image — 16 x 1080p
-  // 0.543 -> 0.522 ms, 8 x 4K 0.612 -> 0.592, but 4 x 4K with its own tables 0.522 -> 0.536: tools/r5_list_boundary.sh)
-  // (... or restart intervals: their chains end at the next marker, six in-group steps cover most of them — the 8K
-  // frame of BASELINE config 5 alone: 0.66 ms dense, 0.69 with lists)
-  const bool dense_only = small_batch && ((b->wide && !b->wide_shared) || b->total_sub <= 64u*1024u || b->geom.restart_interval > 0);
-  P.list_from = long_subs ? HJ_MAX_ROUNDS : K.list_from >= 0 ? K.list_from : dense_only ? HJ_MAX_ROUNDS : 1;
+  P.list_from = R.lists ? 1 : HJ_MAX_ROUNDS;
   P.it_list = K.it_list;
   A.flush_lanes = K.flush_lanes;
   A.sub_log2 = b->sub_log2;
@@ -1044,7 +1058,7 @@ static int queue_rounds(jga_huff_batch *b, const decode_plan &P, int &round, int
       }
       continue;
     }
-    if (hj_launch_round(&P.A, (int)b->max_nsub, round, round ? P.it1 : P.it0, round >= P.sparse_from ? 1 : P.lean ? -1 : 0, st)) {
+    if (hj_launch_round(&P.A, (int)b->max_nsub, round, round ? P.it1 : P.it0, P.lean, st)) {
       return jga_fail("huff: launch failed");
     }
     if (b->list_state == 0) b->list_state = 2;

@@ -41,7 +41,6 @@
 #define HJ_FAST_BITS 9
 #define HJ_SUB_LOG2_MAX 7          /* subsequence length in clean scan bytes: 32, 64 or 128, */
 #define HJ_SUB_LOG2_MIN 5          /* a per-batch run-time value (hj_choose_sub_log2) */
-#define HJ_SUB_LOG2_GMEM_MAX 9     /* 256 / 512: only for the kernels that read the scan from global memory */
 #define HJ_SUB_BYTES_MAX (1 << HJ_SUB_LOG2_MAX)
 #define HJ_MAX_SLOTS 10           /* blocks per MCU (4:1:1 / 4:2:0 = 6) */
 

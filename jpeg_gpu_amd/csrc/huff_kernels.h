@@ -45,12 +45,12 @@ typedef struct hj_clear_args { hj_clear_region region[6]; int nregions; } hj_cle
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* sparse != 0: the one-wave-per-group variant for rounds in which few lanes still move */
 /* fills sub_seg and the start states S (guesses) on the device */
 /* ... and clears ran[] and sets errors[] (to verdicts0[], device memory, or to 0) */
 /* (C: regions cleared by extra workgroups of the same launch, or NULL) */
 int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, const uint32_t *verdicts0, const hj_clear_args *C, void *stream);
-int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse, void *stream);
+/* lean != 0: the rows read through registers (the default; 0: the stateless row reader, an A/B knob) */
+int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int lean, void *stream);
 /* A LIST round: only the subsequences whose start state moved run, packed into dense waves from a work list per image
  * (rebuild != 0: the lists are made afresh from the states first — the first list round of a decode, or after the host
  * changed states; ordinal: how many list rounds of this decode came before).  An image whose list fits one workgroup is

@@ -5,8 +5,10 @@
 //                  A workgroup iterates internally (states handed lane-to-lane
 //                  through LDS) until none of its lanes moves, so most of the
 //                  propagation needs no extra launch.
-//   hj_sync_sparse the same round for the later launches of batches that fill the device: one
-//                  wave per 256 subsequences (smaller batches keep hj_sync_round: huff_api.cpp)
+//   hj_list_build / hj_sync_list   the later rounds of batches that fill or share the device: only the
+//                  subsequences that still move run, from per-image work lists (round 5; the one-wave-per-256
+//                  hj_sync_sparse of rounds 2-4 was removed in round 6: slower wherever lists apply, and the
+//                  batches without lists keep the dense kernel)
 //   hj_scan        per restart segment: exclusive prefix sums of the block counts over the
 //                  segment's lanes; the final launch also zeroes the line of the block every
 //                  lane starts inside (the only lines the write pass stores piecewise)
@@ -382,155 +384,12 @@ __global__ __launch_bounds__(HJ_BLOCK) void hj_sync_round(const hj_args A, int r
   if (__syncthreads_or(on && lds_ran[t]) && t == 0) atomicOr(&A.ran[round], 1u);
 }
 
-// The same round for the LATER launches, when only a minority of the lanes still moves.
-// A launch then costs (groups with a moving lane) x (latency of one run) / (workgroups
-// in flight), whatever the groups hold — so this variant trades lanes for residency: ONE
-// wave per group of 256 subsequences, running at most 64 of them at a time, each reading its
-// scan row from global memory (hj_gmem_src: every row is read once here, nothing to reuse)
-// and looking its byte range up when it runs; run results go straight to global memory.
-// Four groups (waves) share a workgroup's copy of the tables and never meet at a barrier
-// after it is staged: 23 KB of LDS per 4 groups instead of 54 KB per group, 28 groups in
-// flight per CU instead of three.  Same indexing, same hand-over protocol and same results as
-// hj_sync_round.
-#ifndef HJ_SPARSE_GROUPS
-#define HJ_SPARSE_GROUPS 4
-#endif
-static __device__ __forceinline__ void hj_wave_sync() {      // LDS hand-over inside one wavefront
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__global__ __launch_bounds__(64*HJ_SPARSE_GROUPS) void hj_sync_sparse(const hj_args A, int round, int max_iters) {
-  constexpr int NG = HJ_SPARSE_GROUPS;
-#ifndef HJ_SPARSE_WIDE_TABLES
-#define HJ_SPARSE_WIDE_TABLES 1      /* 0: the 10 KB tables as uploaded (16-bit DC entries, a DC / AC case per symbol) */
-#endif
-#if HJ_SPARSE_WIDE_TABLES
-  typedef hj_ltables sparse_tables;
-#else
-  typedef hj_tables sparse_tables;
-#endif
-  __shared__ __attribute__((aligned(16))) sparse_tables lds_tabs;
-  __shared__ uint64_t lds_S_all[NG][HJ_BLOCK + 1];
-  __shared__ uint8_t lds_dirty_all[NG][HJ_BLOCK], lds_ran_all[NG][HJ_BLOCK];
-  __shared__ uint8_t lds_act_all[NG][HJ_BLOCK];
-  __shared__ hj_image s_im;
-  const hj_image im = A.images[blockIdx.y];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t group = blockIdx.x*NG + wave;               // this wave's 256 subsequences
-  uint64_t *lds_S = lds_S_all[wave];
-  uint8_t *lds_dirty = lds_dirty_all[wave], *lds_ran = lds_ran_all[wave];
-  uint8_t *lds_act = lds_act_all[wave];
-  // lane l describes subsequences l, l+64, l+128, l+192 of the group
-  uint32_t g[4], sidx[4];
-  bool on[4], any = false;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const uint32_t t = (uint32_t)q*64u + lane, li = group*HJ_BLOCK + t;
-    on[q] = li < im.nsub;
-    g[q] = 0; sidx[q] = 0;
-    uint64_t st = 0;
-    bool dirty = false;
-    if (on[q]) {
-      g[q] = im.sub0 + li;
-      sidx[q] = g[q] + im.seg0 + A.sub_seg[g[q]];
-      st = A.S[sidx[q]];
-      dirty = st != A.last_in[g[q]];
-    }
-    lds_S[t] = st;
-    lds_dirty[t] = dirty;
-    lds_ran[t] = 0;
-    any = any || dirty;
-  }
-  const uint32_t sidx_last = (uint32_t)__shfl((int)sidx[3], 63);   // entry of the group's last subsequence
-  if (!__syncthreads_or(any)) return;            // nothing moved in any of the four groups
-  hj_stage_image(&s_im, A.images + blockIdx.y);
-#if HJ_SPARSE_WIDE_TABLES
-  hj_stage_tables<64*NG>(&lds_tabs, A.tables + blockIdx.y);
-#else
-  {
-    const uint4 *tsrc = reinterpret_cast<const uint4 *>(A.tables + blockIdx.y);
-    uint4 *tdst = reinterpret_cast<uint4 *>(&lds_tabs);
-    for (int k = (int)threadIdx.x; k < (int)(sizeof(hj_tables)/16); k += 64*NG) tdst[k] = tsrc[k];
-  }
-#endif
-  __syncthreads();
-  // from here on every wave is on its own: no workgroup barriers
-  if (__ballot(any) == 0ull) return;
-  const uint8_t *scan = A.scan + im.scan_off;
-  const uint32_t padded = (im.scan_len + 16 + 15) & ~15u;
-  const hj_slot_words slot_tables = hj_slot_table_words(s_im);
-  for (int it = 0; it < max_iters; it++) {
-    // the lanes that moved, in order
-    uint32_t total = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint32_t t = (uint32_t)q*64u + lane;
-      const bool need = lds_dirty[t] != 0;
-      const unsigned long long m = __ballot(need);
-      if (need) {
-        lds_act[total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)t;
-        lds_dirty[t] = 0;
-      }
-      total += (uint32_t)__popcll(m);
-    }
-    if (total == 0) break;
-    hj_wave_sync();
-    for (uint32_t c0 = 0; c0 < total; c0 += 64) {
-      const uint32_t nact = total - c0 < 64u ? total - c0 : 64u;
-      if (lane < nact) {
-        const uint32_t sub = lds_act[c0 + lane];
-        const uint64_t start = lds_S[sub];
-        // where the subsequence lies (only the lanes that run look this up)
-        const uint32_t li = group*HJ_BLOCK + sub, gg = im.sub0 + li;
-        const hj_segment sg = A.segs[im.seg0 + A.sub_seg[gg]];
-        const uint32_t i = li - sg.sub0;
-        const uint32_t first = sg.start + (i << A.sub_log2);
-        uint32_t stop = first + (1u << A.sub_log2);
-        if (stop > sg.end) stop = sg.end;
-        hj_gmem_src src;
-        {
-          src.scan32 = reinterpret_cast<const uint32_t *>(scan);
-          src.dw0 = first >> 2;
-          src.ndw = padded >> 2;
-        }
-        const hj_run r = hj_sync_decode<hj_gmem_src, false, sparse_tables>(src, s_im, &lds_tabs, start, (uint64_t)stop*8, i + 1 >= sg.nsub, slot_tables);
-        const uint64_t end_state = r.end_state;
-        A.R[gg] = r.nblocks;                     // (a later run of the same subsequence overwrites it)
-        lds_ran[sub] = 1;
-        if (i + 1 < sg.nsub) {
-          if (sub + 1 < HJ_BLOCK) {
-            if (lds_S[sub + 1] != end_state) { lds_S[sub + 1] = end_state; lds_dirty[sub + 1] = 1; }
-          }
-          else A.S[sidx_last + 1] = end_state;   // first subsequence of the next group
-        }
-      }
-      hj_wave_sync();
-    }
-  }
-  // publish (as hj_sync_round)
-  bool ran_any = false;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const uint32_t t = (uint32_t)q*64u + lane;
-    if (!on[q]) continue;
-    const uint64_t st = lds_S[t];
-    if (t > 0 && st != A.S[sidx[q]]) A.S[sidx[q]] = st;
-    if (lds_ran[t]) {
-      A.last_in[g[q]] = lds_dirty[t] ? ~0ull : st;
-      ran_any = true;
-    }
-  }
-  if (__ballot(ran_any) != 0ull && lane == 0) atomicOr(&A.ran[round], 1u);
-}
-
 typedef uint32_t hj_v4u __attribute__((ext_vector_type(4)));
 // ---- list rounds (round 5) ---------------------------------------------------------------------------
 // After the first round's in-group iterations 6-7 % of a photograph's subsequences still move, a quarter of those
 // a step later, and so on down a chain of five or six more steps (4:2:0: the MCU slot has to fall into step as
-// well).  hj_sync_sparse walks that tail with one wave per 256 subsequences: sixteen of its lanes busy in the
-// first step, four in the second, and every wave of the batch resident for three steps' time — 19 000 vector
+// well).  Rounds 2-4 walked that tail with one wave per 256 subsequences (hj_sync_sparse): sixteen of its lanes busy in
+// the first step, four in the second, and every wave of the batch resident for three steps' time — 19 000 vector
 // instructions per wave for what three or four lanes do.  A LIST round runs exactly the subsequences that moved:
 //   hj_list_build   one lane per subsequence: those whose start state differs from the one their latest run
 //                   began in go onto their image's work list (wave-aggregated append);
@@ -945,9 +804,10 @@ static __device__ __forceinline__ uint32_t hj_wentry(uint32_t e) {      // e: a 
 #ifndef HJ_WRITE_UNROLL
 #define HJ_WRITE_UNROLL 4
 #endif
-#ifndef HJ_WRITE_PAIRS
-#define HJ_WRITE_PAIRS 0             /* 1: two AC symbols per look-up where nine bits hold both (round 6 A/B: profiles/r6_entropy_ab.md) */
-#endif
+// (Round 6 A/B, commit f9cf3e7: a second AC symbol per look-up where nine bits hold both — entry pairs made while the
+// tables are staged, two owed stores per trip — 661-666 us against 667-673 on the bench's files, 408-413 against
+// 404-406 on photograph-like content: every trip pays for the second symbol whether it exists or not (1.42 symbols per
+// look-up).  Not kept: profiles/r6_entropy_ab.md.)
 #define HJ_DEZZ_EXT 192              /* k + adv - 1 <= 63 + 127 */
 #define HJ_WRITE_BLOCK 512
 
@@ -969,20 +829,7 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
     const hj_tables *T = A.tables + blockIdx.y;
     for (int i = threadIdx.x; i < 2 << HJ_FAST_BITS; i += NB) {
       (&lds_tabs.dc[0][0])[i] = hj_wentry((&T->dc[0][0])[i]);
-      uint32_t e1 = hj_wentry((&T->ac[0][0])[i] & 0xffffu);
-#if HJ_WRITE_PAIRS
-      // the SECOND AC symbol of the same nine bits, when all of it (code and magnitude) lies inside them:
-      // tot2 | adv2 << 4 | s2 << 11 at bit 17 (0: none).  Taken at run time iff the first one leaves the block open.
-      if (!HJ_IS_ESCAPE(e1) && !(e1 & HJ_W_NOCODE) && HJ_E_ADV(e1) != 127 && HJ_E_TOT(e1) < HJ_FAST_BITS) {
-        const uint32_t t1 = (uint32_t)HJ_E_TOT(e1), tb = (uint32_t)i >> HJ_FAST_BITS, ix = (uint32_t)i & ((1u << HJ_FAST_BITS) - 1u);
-        const uint32_t e2 = T->ac[tb][(ix << t1) & ((1u << HJ_FAST_BITS) - 1u)] & 0xffffu;
-        if (!HJ_IS_ESCAPE(e2) && (uint32_t)HJ_E_TOT(e2) + t1 <= HJ_FAST_BITS) {
-          const uint32_t adv2 = HJ_E_ADV(e2) == 64 ? 127u : (uint32_t)HJ_E_ADV(e2);
-          e1 |= ((uint32_t)HJ_E_TOT(e2) | adv2 << 4 | (uint32_t)HJ_E_S(e2) << 11) << 17;
-        }
-      }
-#endif
-      (&lds_tabs.ac[0][0])[i] = e1;
+      (&lds_tabs.ac[0][0])[i] = hj_wentry((&T->ac[0][0])[i] & 0xffffu);
     }
     for (int i = threadIdx.x; i < HJ_L2_BLOCKS*128; i += NB) {
       const uint32_t e = T->l2[i];
@@ -1069,58 +916,6 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
   uint8_t *blk8 = reinterpret_cast<uint8_t *>(blk);
   uint32_t pz = 128;
   int pv = 0;
-#if HJ_WRITE_PAIRS
-  uint32_t pz2 = 128;
-  int pv2 = 0;
-  for (;;) {
-    bool running = !waiting && br.before_stop() && n < max_blocks;
-    if (!out.any(running || waiting)) break;
-#pragma unroll
-    for (int u = 0; u < HJ_WRITE_UNROLL; u++) {
-      if (u) running = !waiting && br.before_stop() && n < max_blocks;
-      if (!running) continue;
-      const uint32_t w = br.window();
-      const bool isdc = k == 0;
-      const uint32_t *tb = isdc ? tb_dc : tb_ac;
-      uint32_t e = tb[w >> (32 - HJ_FAST_BITS)];
-      if ((e & 31u) == 0u) {                                 // a code longer than 9 bits (never half of a pair)
-        e = lds_tabs.l2[(((e >> 5) - 1u) << 7) | ((w >> 16) & 127u)];
-        if (HJ_E_LEN(e) > 16) e |= HJ_W_NOCODE;
-      }
-      const uint32_t tot = e & 31u, s = (e >> 12) & 15u;
-      const uint32_t off = 32u - tot;
-      const int vu = (int)__builtin_amdgcn_ubfe(w, off, s);
-      const int vs = __builtin_amdgcn_sbfe((int)w, off, s);
-      const int v = vu - (vs < 0 ? 0 : (int)((1u << s) - 1u));
-      dcv = isdc ? v : dcv;
-      const int kn = k + (int)((e >> 5) & 127u);
-      // the second symbol of the nine bits: only behind a symbol that left the block open, and only if it starts
-      // before the run's stop (the states are settled: the stop is a symbol boundary)
-      const uint32_t e2 = e >> 17;
-      const bool pair = e2 != 0u && kn < 64 && br.room((int)tot + 1);
-      const uint32_t tot2 = pair ? e2 & 15u : 0u, s2 = pair ? e2 >> 11 : 0u;
-      const uint32_t off2 = off - tot2;
-      const int vu2 = (int)__builtin_amdgcn_ubfe(w, off2, s2);
-      const int vs2 = __builtin_amdgcn_sbfe((int)w, off2, s2);
-      const int v2 = vu2 - (vs2 < 0 ? 0 : (int)((1u << s2) - 1u));
-      const int kn2 = kn + (pair ? (int)((e2 >> 4) & 127u) : 0);
-      *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;      // (the previous trip's values)
-      *reinterpret_cast<hj_i16_alias *>(blk8 + pz2) = (int16_t)pv2;
-      pz = s_dezz[kn - 1];
-      pz2 = s_dezz[pair ? kn2 - 1 : HJ_DEZZ_EXT - 1];        // (no second symbol: the spare half-dword)
-      pv = v;
-      pv2 = v2;
-      errbits |= e;
-      errm = max(errm, max(kn & 127, kn2 & 127));
-      br.skip((int)(tot + tot2));
-      waiting = kn2 >= 64;
-      k = waiting ? 0 : kn2;
-    }
-    *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;     // the stores still owed
-    *reinterpret_cast<hj_i16_alias *>(blk8 + pz2) = (int16_t)pv2;
-    pz = 128;
-    pz2 = 128;
-#else
   for (;;) {
     bool running = !waiting && br.before_stop() && n < max_blocks;
     if (!out.any(running || waiting)) break;
@@ -1154,7 +949,6 @@ __global__ __launch_bounds__(HJ_WRITE_BLOCK) void hj_write(const hj_args A) {
     }
     *reinterpret_cast<hj_i16_alias *>(blk8 + pz) = (int16_t)pv;     // the store still owed
     pz = 128;
-#endif
     if (out.flush_due(waiting, running && !waiting)) {
       if (waiting && head) dcq.push(dcv);                    // (the lane that decoded the DC symbol reports it)
       out.flush_blocks(waiting, !head, true, c);
@@ -1585,7 +1379,7 @@ extern "C" int hj_launch_init(const hj_args *A, int total_segs, int max_nsub, co
    const_cast<uint32_t *>(A->sub_seg), verdicts0, C ? *C : none, (uint32_t)total_segs);
   return (int)hipGetLastError();
 }
-extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int sparse,
+extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int max_iters, int lean,
  void *stream) {
   // JGA_HUFF_LITE: 0 = the first run of all counts like any other; n > 0 = it is a lite run that
   // starts n - 1 bytes into its subsequence (A/B knob)
@@ -1593,14 +1387,10 @@ extern "C" int hj_launch_round(const hj_args *A, int max_nsub, int round, int ma
   // a lone 1080p frame 0.77 -> 0.70 ms: profiles/r2_lite_first_run_ab.txt)
   static const int lite_first = jga_tune("JGA_HUFF_LITE") ? atoi(jga_tune("JGA_HUFF_LITE")) : 49;
   dim3 grid((max_nsub + HJ_BLOCK - 1)/HJ_BLOCK, A->nimages);
-  if (sparse > 0) {
-    const dim3 sgrid((grid.x + HJ_SPARSE_GROUPS - 1)/HJ_SPARSE_GROUPS, grid.y);
-    hipLaunchKernelGGL(hj_sync_sparse, sgrid, dim3(64*HJ_SPARSE_GROUPS), 0, (hipStream_t)stream, *A, round, max_iters);
-  }
-  else if (sparse < 0 && A->wide && !A->wide_shared) {   // ... and with the 12-bit AC tables (small batches: hj_wide_ac)
+  if (lean && A->wide && !A->wide_shared) {   // ... and with the 12-bit AC tables (small batches: hj_wide_ac)
     hipLaunchKernelGGL((hj_sync_round<hj_lds_reg_src, hj_ltables_wide>), grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
   }
-  else if (sparse < 0) {                         // dense, rows read through registers
+  else if (lean) {                               // rows read through registers
     hipLaunchKernelGGL(hj_sync_round<hj_lds_reg_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);
   }
   else hipLaunchKernelGGL(hj_sync_round<hj_lds_src>, grid, dim3(HJ_BLOCK), 0, (hipStream_t)stream, *A, round, max_iters, lite_first);

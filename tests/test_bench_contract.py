@@ -119,6 +119,43 @@ def test_eight_ranks_dry_launch():
             seen |= set(r["cpus"])
 
 
+def _failing_job(mode, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["JGA_BENCH_FAIL_RANK"] = mode
+    env["JGA_BENCH_COMM_TIMEOUT_S"] = "60"
+    t0 = __import__("time").perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--steps", "8"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, cwd=ROOT, env=env)
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    return r, lines, __import__("time").perf_counter() - t0
+
+
+def test_a_rank_that_raises_mid_run_ends_the_job_and_is_named():
+    """world 2 over gloo, rank 1 raises in the middle of its steps.  It tells the others in the
+    status exchange that precedes every barrier; rank 0 does not wait in the barrier for the backend's timeout: the
+    job ends non-zero within seconds and rank 0's one line says which rank failed and why."""
+    r, lines, dt = _failing_job("1")
+    assert r.returncode != 0 and dt < 120, (r.returncode, dt, r.stderr[-2000:])
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["failed_ranks"] == [1] and "injected failure" in d["error"] and "rank 1" in d["error"]
+    assert d["value"] is None and d["n_gpus"] == 2 and "dry_launch" not in d
+    # ... and rank 0 failing reports itself
+    r, lines, dt = _failing_job("0")
+    assert r.returncode != 0 and dt < 120 and len(lines) == 1 and lines[0]["failed_ranks"] == [0]
+
+
+def test_a_rank_that_dies_without_a_word_ends_the_job_too():
+    """... and when rank 1 is simply gone (os._exit: what an abort after a GPU fault looks like from outside) the job
+    still ends non-zero well inside the timeout — rank 0's exchange fails as the peer's sockets close, or the
+    launcher tears the job down first — and no result line is printed."""
+    r, lines, dt = _failing_job("1,die")
+    assert r.returncode != 0 and dt < 150, (r.returncode, dt, r.stderr[-2000:])
+    assert not [d for d in lines if "dry_launch" in d]
+    for d in lines:                                                # (rank 0 got its line out before the launcher's SIGTERM)
+        assert d["value"] is None and "error" in d
+
+
 def test_inputs_are_synthesised_once_per_box(tmp_path, synth):
     """make_inputs(): rank r makes the files whose index is r modulo the world size into a cache
     keyed by recipe + seed, every rank reads them all in its own rotation; a second call makes

@@ -160,19 +160,19 @@ def test_plugin_entropy_stage_choice(gpu, orc, jpg, entropy):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"JGA_STAGED": "0"}, {"JGA_HUFF_WRITE_GMEM": "0"},
-                                 {"JGA_HUFF_SPARSE_FROM": "99"}, {"JGA_HUFF_ITERS": "1,1,3"},
+                                 {"JGA_HUFF_LIST": "1"}, {"JGA_HUFF_ITERS": "1,1,3"},
                                  {"JGA_HUFF_FLUSH": "1"}, {"JPEG_GPU_HIP_REGISTER": "0"}, {"JPEG_GPU_HIP_REGISTER": "-1"},
                                  {"JGA_HUFF_SUB": "32"}, {"JGA_HUFF_SUB": "64"},
                                  {"JGA_HUFF_LITE": "0"}, {"JGA_HUFF_LITE": "1", "JGA_HUFF_ITERS": "1,1,2"},
                                  {"JGA_HUFF_LITE": "120"}, {"JGA_HUFF_PACKS": "0"},
-                                 {"JGA_HUFF_LEAN": "0"}, {"JGA_HUFF_SPARSE_FROM": "1"}])
+                                 {"JGA_HUFF_LEAN": "0"}, {"JGA_HUFF_BY_BLOCK": "0"}])
 def test_alternate_code_paths_give_the_same_pixels(gpu, orc, jpg, env):
     """Every tuning knob selects a different route to the same result: per-lane loads in the
-    YUV kernel, the write pass with LDS-staged rows, dense rounds only, one in-group iteration
+    YUV kernel, the write pass with LDS-staged rows, list rounds for a lone frame, one in-group iteration
     per launch, unbatched block write-out, staged D2H, 32- and 64-byte subsequences, a counted
     first run, a lite first run that is a launch's only iteration, one that starts from the
     subsequence's first bit / from near its end, tables without multi-symbol packs, the dense
-    rounds' stateless row reader, the sparse kernel for the later rounds of a lone frame."""
+    rounds' stateless row reader, the write pass one lane per subsequence for a lone frame."""
     import oracle
     path, data = jpg(777, 431, "420", quality=88, restart_interval=0)
     _, rgb = orc.decode_rgb(data)
