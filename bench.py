@@ -501,45 +501,39 @@ def _short(s, n=120):
 
 
 def _config_summary(e):
-    """One BASELINE config's entry of the full report -> the handful of figures the line carries."""
+    """One BASELINE config's entry of the full report -> the handful of figures the line carries (rates in whole
+    Mpixel/s; everything else — CPU paths, device-only times, per-leg detail — is in the details file)."""
     if not isinstance(e, dict) or "to_rgb_hbm" not in e:
         return e if not isinstance(e, dict) else _pick(e, "error")
     t, dev, host = e["to_rgb_hbm"], e.get("device", {}), e.get("to_host_pixels", {})
     s = {}
     if "Mpixel_s" in t:
-        s["Mpixel_s"] = t["Mpixel_s"]
+        s["Mpixel_s"] = int(round(t["Mpixel_s"]))
     if "latency_ms" in t:
-        s["latency_ms"] = t["latency_ms"]
+        s["lat_ms"] = t["latency_ms"]
     st = t.get("steady")
     if st:
-        s["steady"] = st["Mpixel_s"]
+        s["steady"] = int(round(st["Mpixel_s"]))
         s["steady_s"] = st["seconds"]
-        s["h2d_GBps"] = st["h2d_GBps"]
         s["of_link_ceiling"] = st["of_link_ceiling"]
     for k, v in t.items():                                   # config 4: the whole batch and one rank's shard
         if isinstance(v, dict) and "pageable_files" in v:
             pg, pn = v["pageable_files"], v["pinned_files"]
-            s[k] = {"ms": [pg["ms"], pn["ms"]], "ms_best": [pg["ms_best"], pn["ms_best"]]}      # [pageable, pinned files]
+            s[k] = {"ms": [pg["ms"], pn["ms"]], "best": [pg["ms_best"], pn["ms_best"]]}      # [pageable, pinned files]
     if "ms_per_frame" in host:
-        s["host_ms_per_frame"] = host["ms_per_frame"]
+        s["host_ms"] = host["ms_per_frame"]
     elif isinstance(host.get("plugin"), dict):
-        s["host_ms_per_frame"] = host["plugin"].get("ms_per_frame")
+        s["host_ms"] = host["plugin"].get("ms_per_frame")
     if "kernel_hbm_frac" in dev:
         s["kernel_hbm_frac"] = dev["kernel_hbm_frac"]
-    for k in ("one_frame", "shard_128", "whole_batch"):
-        if k in dev:
-            s["device_ms_" + k] = dev[k]["ms"]
+    if "shard_128" in dev:
+        s["dev_shard_ms"] = dev["shard_128"]["ms"]
     for k in ("huffman_ms", "idct_rgb_ms"):
         if k in dev:
             s[k] = dev[k]
     if "bound_by" in e:
         s["bound_by"] = e["bound_by"]
         s["B_per_px"] = e.get("bytes_per_pixel")
-        s["device_ceiling"] = e.get("device_ceiling_Mpixel_s")
-    cpu = e.get("cpu") or {}
-    c = [cpu.get(k, {}).get("value") for k in ("reference_xjpeg_yuv", "libjpeg_turbo_rgb")]
-    if any(v is not None for v in c):
-        s["cpu_ref_turbo"] = c
     s["ok"] = bool(e.get("bit_exact_vs_oracle"))
     return s
 
@@ -578,12 +572,13 @@ def compact_line(full, details_path=None):
                          "verified": sum(r.get("images_verified", 0) for r in rk)}
     e2e = full.get("e2e") or {}
     if e2e:
-        o["e2e"] = {k: v["value"] for k, v in e2e.items() if isinstance(v, dict) and "value" in v
-                    and k in ("north_star_host_huffman_to_rgb_hbm", "north_star_host_huffman_to_rgb_host",
-                              "pack_transport_to_rgb_hbm", "gpu_entropy_to_rgb_host", "gpu_entropy_to_rgb_pinned_host")}
+        short = {"north_star_host_huffman_to_rgb_hbm": "host_huffman_to_hbm", "north_star_host_huffman_to_rgb_host": "host_huffman_to_host",
+                 "pack_transport_to_rgb_hbm": "pack_to_hbm", "gpu_entropy_to_rgb_host": "gpu_entropy_to_host",
+                 "gpu_entropy_to_rgb_pinned_host": "gpu_entropy_to_pinned_host"}
+        o["e2e"] = {short[k]: int(round(v["value"])) for k, v in e2e.items() if isinstance(v, dict) and "value" in v and k in short}
     ge = full.get("gpu_entropy")
     if ge:
-        o["gpu_entropy"] = _pick(ge, "value", "huffman_ms", "idct_rgb_ms", "sync_rounds", "bit_exact_vs_oracle")
+        o["gpu_entropy"] = _pick(ge, "huffman_ms", "idct_rgb_ms", "sync_rounds", "bit_exact_vs_oracle")
     ps = full.get("pack_stage")
     if ps:
         o["pack_stage"] = _pick(ps, "ms_per_launch", "achieved_GBps", "equals_oracle_quant_stage")

@@ -54,6 +54,7 @@ struct jga_huff_batch {
   int last_assisted;           // subsequences the host walked in the last decode
   int image_errors;            // images of the last decode whose data was damaged
   int assist_hint;             // the previous decode needed the host walk
+  unsigned long long assist_left;   // list entries left at the previous look (decode_end: is the decode still getting anywhere?)
   int spec_rounds;             // rounds queued before the speculative tail (0: not yet decided)
   hipEvent_t ev_wait;          // hipEventBlockingSync: host waits that sleep instead of spinning
   int blocking_waits;
@@ -340,7 +341,15 @@ static int auto_iters(const jga_huff_batch *b) {
   // chain, a lone 1080p frame 0.355 -> 0.350 ms, 4K 0.386 -> 0.378, 4K 4:4:4 0.280 -> 0.269; five helps the 1080p frame
   // more and costs the 4K one: profiles/r5_lone_frame_chain.md)
   if (b->wide && !b->wide_shared && !long_intervals) return 4;
-  return long_intervals ? 6 : 3;
+  if (long_intervals) return 6;
+  // (round 6, tools/policy_sweep.py: frames of three blocks per MCU or fewer — 4:4:4, grey — fall into step inside
+  // one subsequence: beyond a small batch the third in-group step only holds the groups' barriers — 32 x 4K 4:4:4
+  // 1.86 -> 1.66 ms, 128 x 1080p 4:4:4 1.87 -> 1.75, 32 x 4K grey 1.12 -> 1.03; four blocks per MCU (4:2:2) from 24 MB
+  // on: 32 x 4K 1.32 -> 1.21, 128 x 1080p 1.35 -> 1.24; a lone 8K 4:2:2 frame of 16 MB is better off with three)
+  const uint64_t bytes = (uint64_t)b->total_sub << b->sub_log2;
+  const int nslots = b->nimages > 0 ? ((const hj_image *)(b->h_blob + b->off_images))[0].nslots : 6;
+  if ((nslots <= 3 && bytes > (8ull << 20)) || (nslots == 4 && bytes > (24ull << 20))) return 2;
+  return 3;
 }
 // prepare() with the unstuffing left to the device: the host parses the marker segments
 // (phase A, as below) and the device does the rest (unstuff_kernels.hip).  The RAW entropy-coded
@@ -907,10 +916,12 @@ static double thread_cpu_ms() {
 //
 //   crowd            size        own12  dri  | lists  iters                       by_block | measured (ms, chosen / other)
 //   alone and small  <= 64 k     any    any  | no     3 (4 own12, 6 long dri)     yes      | 1 x 1080p 0.40 / 0.45-0.49 lists; 0.41 -> 0.32 by block (r5_list_rounds, r5_lone_frame_chain)
-//   alone and small  64-200 k    yes    any  | no     4                           no       | 4 x 4K own tables 0.522 / 0.536 lists
-//   alone and small  64-200 k    no     yes  | no     3 (6 long dri)              no       | 8K DRI frame 0.66 / 0.69 lists
-//   alone and small  64-200 k    no     no   | yes    3                           no       | 16 x 1080p 0.522 / 0.543 dense; 8 x 4K 0.592 / 0.612
-//   fills or shares  any         -      any  | yes    3 (6 long dri)              no       | 48 x 4K 1.82-1.86 / 1.91-1.96; 64 x 1080p 0.87 / 0.95
+//   alone and small  64-128 k    any    any  | no     3 (4 own12, 6 long dri)     no       | 8 x 2.7K 0.547 / 0.677 lists, 8 x 4K photo 0.582 / 0.729 (r6_policy_sweep; r5's 16 x 1080p: 0.543 / 0.522)
+//   alone and small  128-200 k   yes    any  | no     4                           no       | 4 x 4K own tables 0.522 / 0.536 lists
+//   alone and small  128-200 k   no     yes  | no     3 (6 long dri)              no       | 8K DRI frame 0.66 / 0.69 lists
+//   alone and small  128-200 k   no     no   | yes    3                           no       | 8 x 4K 0.592 / 0.612 dense; 32 x 1080p 0.584 / 0.612
+//   fills or shares  any         -      any  | yes    3 (6 long dri; 2: see below) no       | 48 x 4K 1.82-1.86 / 1.91-1.96; 64 x 1080p 0.87 / 0.95
+//   iters = 2 for batches over 8 MB of frames with <= 3 blocks per MCU, over 24 MB with 4 (auto_iters)
 // (the tuning build's JGA_HUFF_LIST / JGA_HUFF_ITERS / JGA_HUFF_BY_BLOCK force a column; tools/policy_sweep.py runs every
 // forced alternative over geometries x samplings x batch sizes x qualities x contents: profiles/r6_policy_sweep.md)
 struct round_choice { bool lists, by_block; int iters; };
@@ -921,7 +932,7 @@ static round_choice choose_rounds(const jga_huff_batch *b) {
   const bool dri = b->geom.restart_interval > 0;
   round_choice R;
   R.iters = auto_iters(b);
-  R.lists = !(alone_small && (b->total_sub <= 64u*1024u || own12 || dri));
+  R.lists = !(alone_small && (b->total_sub <= 128u*1024u || own12 || dri));
   R.by_block = !b->device_shared && b->total_sub <= 64u*1024u;
   if (K.list_from >= 0) R.lists = K.list_from < HJ_MAX_ROUNDS;
   if (K.by_block_subs >= 0) R.by_block = !b->device_shared && b->total_sub <= (uint32_t)K.by_block_subs;
@@ -1089,6 +1100,7 @@ static int decode_begin(jga_huff_batch *b, short *d_coef, long long coef_stride,
     return jga_fail("huff: launch failed");
   }
   b->last_assisted = 0;
+  b->assist_left = 0;
   b->list_state = 1;                                         // (hj_init_states zeroed the lists' counters)
   // A photograph settles in 4-6 rounds, so the tail is queued SPECULATIVELY behind the first
   // group of rounds: one host round trip per decode instead of two (a lone 1080p frame: ~60 us of
@@ -1141,7 +1153,23 @@ static int decode_end(jga_huff_batch *b, int *valid_behind) {
     if (round >= HJ_MAX_ROUNDS) return jga_fail("huff: synchronisation did not converge");
     // (a batch object whose previous decode needed the walk — the same camera, the same
     // letterbox — gets it at the first check instead of waiting out twelve rounds)
-    if (round >= (b->assist_hint ? 1 : P.assist_after) && assist_chains(b, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (round >= (b->assist_hint ? 1 : P.assist_after)) {
+      // Streams that NEVER fall into step (flat areas, letterbox bars) need the host's walk; streams that are merely
+      // slow — a q97 8K frame: 310 k subsequences, chains of thirty steps and more — do not: 6.5 ms with the walk after
+      // twelve rounds, 0.9 without (round 6, tools/policy_sweep.py).  With list rounds the lists' lengths say which it
+      // is: while what is left shrinks by a third from look to look, the rounds go on (up to 96).
+      bool stuck = true;
+      if (!b->assist_hint && round > P.list_from && round < 96) {
+        std::vector<uint32_t> left((size_t)b->nimages);
+        HOK(hipMemcpy2D(left.data(), sizeof(uint32_t), b->d_lcount + (size_t)(round & 3)*(size_t)b->nimages*HJ_LIST_CSTRIDE,
+         sizeof(uint32_t)*HJ_LIST_CSTRIDE, sizeof(uint32_t), (size_t)b->nimages, hipMemcpyDeviceToHost));
+        unsigned long long sum = 0;
+        for (uint32_t x : left) sum += x;
+        stuck = b->assist_left != 0 && sum*3 > b->assist_left*2;
+        b->assist_left = sum ? sum : 1;
+      }
+      if (stuck && assist_chains(b, st) != EXIT_SUCCESS) return EXIT_FAILURE;
+    }
     with_tail = false;
     first = false;
     if (queue_rounds(b, P, round, P.group, st) != EXIT_SUCCESS) return EXIT_FAILURE;

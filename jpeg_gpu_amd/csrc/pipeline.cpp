@@ -180,7 +180,10 @@ struct input_cache {
       held += bytes;
     }
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t rc = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
+    // (tuning build, tests: JGA_PIPE_REGISTER_FAIL=1 — every registration fails the way it does when the process may
+    // not lock more memory: the buffer is copied instead, same pixels)
+    hipError_t rc = jga_tune("JGA_PIPE_REGISTER_FAIL") ? hipErrorOutOfMemory
+     : hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
     bool foreign = false;
     if (rc == hipErrorHostMemoryAlreadyRegistered) {
       (void)hipGetLastError();

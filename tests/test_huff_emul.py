@@ -190,6 +190,8 @@ def test_subsequence_length_by_batch(emul):
     assert E.huff_emul_choose_sub(3 * MB, 6, 0) == 128          # one 4K 4:2:0 frame
     assert E.huff_emul_choose_sub(6 * MB, 3, 0) == 64           # one 4K 4:4:4 frame
     assert E.huff_emul_choose_sub(9 * MB, 3, 0) == 128          # ... two of them
+    assert E.huff_emul_choose_sub(4 * MB, 4, 0) == 64           # one 4K 4:2:2 frame (round 6's sweep)
+    assert E.huff_emul_choose_sub(16 * MB, 4, 0) == 128
     assert E.huff_emul_choose_sub(12 * MB, 6, 480) == 64        # BASELINE config 5: 8K, an interval per MCU row
     assert E.huff_emul_choose_sub(3 * MB, 6, 8) == 64
     assert E.huff_emul_choose_sub(148 * MB, 6, 480) == 128      # a batch that fills the device

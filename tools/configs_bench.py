@@ -213,15 +213,21 @@ def _pipeline_steady(lib, abi, np, orc, jpegs, nthreads, group, lanes, seconds=0
     ok = pl.run_jobs(cal) == 0
     rate = len(cal) / (time.perf_counter() - t0)                     # images / s, short-run regime: an underestimate
     n = int(rate * seconds * 1.6) // ring * ring + ring
-    jobs = mk(n)
-    # (the same job list once untimed: a LONG run sizes every lane's buffers for full groups — pinned blobs of
-    # ~200 MB per lane, a few tenths of a second of page pinning the first time — where the short calibration runs
-    # above only sized them for theirs)
-    ok = pl.run_jobs(jobs) == 0 and ok
-    lib.check(lib.L.jga_stream_sync(None))
-    t0 = time.perf_counter()
-    ok = pl.run_jobs(jobs) == 0 and ok
-    dt = time.perf_counter() - t0
+    for attempt in range(3):
+        jobs = mk(n)
+        # (the same job list once untimed: a LONG run sizes every lane's buffers for full groups — pinned blobs of
+        # ~200 MB per lane, a few tenths of a second of page pinning the first time — where the short calibration runs
+        # above only sized them for theirs)
+        ok = pl.run_jobs(jobs) == 0 and ok
+        lib.check(lib.L.jga_stream_sync(None))
+        t0 = time.perf_counter()
+        ok = pl.run_jobs(jobs) == 0 and ok
+        dt = time.perf_counter() - t0
+        if dt >= min(seconds, 0.5) * 0.95 or not ok:
+            break
+        # (light content: the long run is much faster than the short calibration said — photograph-like 1080p files
+        # ran 0.40 s where 0.6 was asked for: again, with as many jobs as THIS rate needs)
+        n = int(n / dt * seconds * 1.15) // ring * ring + ring
     pl.close()
     ok = ok and all(j.status == 0 for j in jobs)
     with ThreadPoolExecutor(max_workers=max(1, min(16, nthreads))) as ex:
