@@ -1,6 +1,6 @@
 // copy_kernel.hip — what THIS device's memory system gives a kernel that does nothing but move the
 // fused block-decode kernel's byte volume: the measured ceiling bench.py prints beside the kernels'
-// rates (SURVEY.md 8d; DESIGN.md 3, 7).  16 bytes per lane per trip, grid-stride, whole 1 KB runs per
+// rates (SURVEY.md 8d; DESIGN.md 2, 6).  16 bytes per lane per trip, grid-stride, whole 1 KB runs per
 // wave, non-temporal stores like the kernels' own.  hipMemcpyDtoDAsync of the same volume is printed
 // next to it: the runtime's copy reads 4.5-5.5 TB/s from box to box, below the kernels it is
 // supposed to bound on some of them.

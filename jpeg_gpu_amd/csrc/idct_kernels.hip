@@ -340,7 +340,7 @@ DEV void take_dc(const jga_kparams &P, int img, long long slot, uint4 (&rows)[8]
 // Coalesced fetch of a wave's 64 consecutive blocks (8 KB) through LDS: each
 // instruction moves 1 KB contiguous (8 blocks); the LDS image of region k is
 // [row ^ ((k>>1)&1)][block&7] in 16-byte slots so that the per-lane
-// ds_read_b128 of "my block, row r" is bank-conflict free.
+// ds_read_b128 of "my block, row r" is bank-conflict free (profiles/design_diary_r3_r5.md §3).
 DEV void load_block_staged(const int16_t *__restrict__ wave_src, int lane,
  uint4 *__restrict__ lds /* 512 slots of this wave */, uint4 (&rows)[8]) {
   const uint4 *p = reinterpret_cast<const uint4 *>(wave_src);

@@ -51,7 +51,7 @@ def aggregate_throughput(local_units, local_seconds, dist=None, device=None):
 # A node has two sockets; a GPU's PCIe root hangs off one of them, and the pipeline's host
 # threads (marker parse + unstuffing, or the host Huffman threads of the north-star
 # transport) read the JPEG bytes and write pinned memory the GPU then pulls: they should run
-# on the GPU's socket (86-106 vs 108-117 Gpixel/s), and N ranks must share
+# on the GPU's socket (profiles/design_diary_r3_r5.md §5.1: 86-106 vs 108-117 Gpixel/s), and N ranks must share
 # the cores, not each start one thread per core of the box.
 
 def parse_cpulist(text):

@@ -118,7 +118,7 @@ def rgb_gap_counts(orc=None):
 
 
 def test_shader_literal_sequence_vs_a5_over_every_input(orc):
-    """The count DESIGN.md §4 quotes.  The shader's literal sequence — with or without fused
+    """The count profiles/design_diary_r3_r5.md §4 quotes.  The shader's literal sequence — with or without fused
     multiply-adds — gives A.5's bytes on ALL 3 x 16 777 216 outputs; only an implementation that
     multiplies by fl(1/255) instead of dividing moves 21 G bytes (of 50 331 648) by one."""
     gap = rgb_gap_counts(orc)
