@@ -434,7 +434,10 @@ typedef struct jga_pipeline_config {
 typedef struct jga_job {
   const unsigned char *jpeg;   /* in : file bytes (caller keeps alive) */
   int size;
-  unsigned char *host_out;     /* in : destination if copy_back (may be NULL) */
+  unsigned char *host_out;     /* in : destination if copy_back (may be NULL).  A job that FAILS (status 1) leaves it
+                                * unspecified: copies are queued before the decode's verdict is known — a damaged file's
+                                * buffer may hold partial pixels, then zeros (the same holds for img->pixels / plane data
+                                * when HIPJPEG's decode_image returns EXIT_FAILURE) */
   unsigned char *dev_out;      /* in : device destination, or NULL = internal */
   int status;                  /* out: 0 ok, 1 failed */
   int width, height, nplanes;  /* out */

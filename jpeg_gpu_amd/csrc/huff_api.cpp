@@ -538,6 +538,7 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
   const auto t_1 = std::chrono::steady_clock::now();
   // copy calls: files the copy engine reads where they lie, runs of files a host core put into the blob, and the
   // descriptors
+  bool descriptors_sent = false;
   for (int i = 0; i < n; ) {
     if (how[(size_t)i] == NAMED) {
       HOK(hipMemcpyAsync(b->d_blob + b->off_raw + uimg[(size_t)i].raw_off, jpegs[i] + prep[i].desc->scan_off,
@@ -548,11 +549,20 @@ static int prepare_raw(jga_huff_batch *b, const unsigned char *const *jpegs, con
     int j = i;
     while (j + 1 < n && how[(size_t)j + 1] != NAMED) j++;
     const size_t from = uimg[(size_t)i].raw_off, to = (size_t)uimg[(size_t)j].raw_off + uimg[(size_t)j].avail;
-    HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, to - from, hipMemcpyHostToDevice, up));
+    if (j + 1 == n) {
+      // the run reaches the last file: the descriptors lie right behind the raw bytes in both blobs — ONE copy call
+      // for both (round 6: a second call per group held the link for ~40 us: the small copy itself and two hand-overs
+      // in the copy queue, eight times per 128-file shard)
+      HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, b->upload_size - (b->off_raw + from), hipMemcpyHostToDevice, up));
+      descriptors_sent = true;
+    }
+    else HOK(hipMemcpyAsync(b->d_blob + b->off_raw + from, b->h_blob + b->off_raw + from, to - from, hipMemcpyHostToDevice, up));
     i = j + 1;
   }
-  HOK(hipMemcpyAsync(b->d_blob + b->off_images, b->h_blob + b->off_images, b->upload_size - b->off_images,
-   hipMemcpyHostToDevice, up));
+  if (!descriptors_sent) {
+    HOK(hipMemcpyAsync(b->d_blob + b->off_images, b->h_blob + b->off_images, b->upload_size - b->off_images,
+     hipMemcpyHostToDevice, up));
+  }
   HOK(hipEventRecord(b->ev_up, up));
   hj_unstuff_args U;
   memset(&U, 0, sizeof(U));

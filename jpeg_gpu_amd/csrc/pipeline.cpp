@@ -368,6 +368,7 @@ struct jga_pipeline {
   hipStream_t fifo_streams[2] = {nullptr, nullptr};
   bool short_fifo = true, short_fifo_pinned = false;
   int fifo_nstreams = 1, fifo_threads = 1;       // (one copy stream moves 12 MB copies at the link's rate; a lane stages alone)
+  int fifo_named = 0;                            // the run's first groups that name pinned files instead (tuning: JGA_PIPE_FIFO_NAMED)
   bool short_ramp = false;
   std::atomic<unsigned> run_ticket{0};
   std::mutex link_mutex;
@@ -727,7 +728,7 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   const unsigned ticket = fifo ? pl->run_ticket.fetch_add(1) : 0u;
   {
     for (int i = 0; i < m && on_device; i++) {
-      if (fifo) in_place[(size_t)i] = ticket < 2 && (jobv[i]->pinned & 1);    // (everything else goes through the blob)
+      if (fifo) in_place[(size_t)i] = (int)ticket < pl->fifo_named && (jobv[i]->pinned & 1);    // (everything else goes through the blob)
       else if (jobv[i]->pinned & 1) in_place[(size_t)i] = 1;
       else if (pl->inputs.acquire(jobv[i]->jpeg, (size_t)jobv[i]->size)) {
         in_place[(size_t)i] = 1;
@@ -1131,6 +1132,7 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     if (const char *e = jga_tune("JGA_PIPE_SHORT_FIFO")) { pl->short_fifo = atoi(e) != 0; pl->short_fifo_pinned = atoi(e) > 1; }
     if (const char *e = jga_tune("JGA_PIPE_FIFO_STREAMS")) pl->fifo_nstreams = atoi(e) > 1 ? 2 : 1;
     if (const char *e = jga_tune("JGA_PIPE_FIFO_THREADS")) pl->fifo_threads = atoi(e) > 0 ? atoi(e) : 1;
+    if (const char *e = jga_tune("JGA_PIPE_FIFO_NAMED")) pl->fifo_named = atoi(e);
     pl->short_ramp = K.short_ramp;
     for (int i = 0; i < 2 && pl->short_fifo; i++) {
       if (!hip_ok(hipStreamCreateWithFlags(&pl->fifo_streams[i], hipStreamNonBlocking), "hipStreamCreate")) {
