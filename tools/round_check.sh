@@ -11,6 +11,7 @@ if [ -z "$SKIP_TESTS" ]; then
   tail -4 $OUT/pytest.log
 fi
 ( time timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err ) 2> $OUT/bench.time; echo "bench rc=$?"; tail -3 $OUT/bench.time
+cp bench_details.json $OUT/bench_details.json; wc -c $OUT/bench.json
 tail -3 $OUT/bench.err
 # the roofline leg alone, as bench.py runs it: 0.5 s of untimed launches of the fused RGB kernel on 48 resident 4K
 # frames, then 50 launches between two HIP events (the LAST 50 launches of the trace)
@@ -35,7 +36,7 @@ for name in ("hj_init","hj_sync_round","hj_sync_sparse","hj_list_build","hj_sync
 PY
 grep "Mpix/s\|equal" $OUT/hbench.txt | tail -4 >> $OUT/huffman_kernels.txt
 rm -rf $OUT/hprof
-bash tools/archive/r3_pmc.sh $TAG/hpmc > $OUT/huffman_pmc.txt 2>&1; rm -rf $OUT/hpmc; grep -A3 "^hj_write\|^hj_sync_round" $OUT/huffman_pmc.txt | head -12
+bash tools/pmc_entropy.sh $TAG/hpmc > $OUT/huffman_pmc.txt 2>&1; rm -rf $OUT/hpmc; grep -A3 "^hj_write\|^hj_sync_round" $OUT/huffman_pmc.txt | head -12
 # one frame through the plugin per registration mode, and the harness
 python - <<PY > $OUT/plugin_latency.txt 2>&1
 import sys, ctypes as C

@@ -6,7 +6,8 @@ import csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 name = sys.argv[2] if len(sys.argv) > 2 else tag
 src = os.path.join("gpurun_out", tag)
-bench = json.load(open(os.path.join(src, "bench.json")))
+line = json.load(open(os.path.join(src, "bench.json")))          # the one stdout line (round 6: a <= 4 KB summary)
+bench = json.load(open(os.path.join(src, "bench_details.json"))) if os.path.exists(os.path.join(src, "bench_details.json")) else line
 rf = bench["roofline"]
 out = ["# rocprofv3 summary, %s" % name, ""]
 roof = glob.glob(os.path.join(src, "roof", "**", "roof_kernel_trace.csv"), recursive=True)
@@ -80,7 +81,12 @@ out += ["", "## bench line of the same build (un-profiled run)", "```", json.dum
         "other_kernels: " + json.dumps({k: (v["ms"], v["GBps"]) for k, v in bench.get("other_kernels", {}).items()}),
         "gpu_entropy: " + json.dumps({k: bench["gpu_entropy"][k] for k in ("value", "huffman_ms", "idct_rgb_ms", "sync_rounds")} if "gpu_entropy" in bench else {})]
 open(os.path.join("profiles", "%s_rocprof_summary.md" % name), "w").write("\n".join(out) + "\n")
-json.dump(bench, open(os.path.join("profiles", "%s_bench.json" % name), "w"), indent=1)
+# (round 6) <name>_bench.json = the ONE stdout line as printed, <name>_bench_details.json = the full report beside it
+if bench is not line:
+    open(os.path.join("profiles", "%s_bench.json" % name), "w").write(json.dumps(line, separators=(",", ":")) + "\n")
+    json.dump(bench, open(os.path.join("profiles", "%s_bench_details.json" % name), "w"), indent=1)
+else:
+    json.dump(bench, open(os.path.join("profiles", "%s_bench.json" % name), "w"), indent=1)
 print("\n".join(out))
 
 # round 3 extras
