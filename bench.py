@@ -111,8 +111,10 @@ def parse_args(argv=None):
     ap.add_argument("--as-rank-of", type=int, default=0, help=argparse.SUPPRESS)   # the scale-proxy child
     ap.add_argument("--proxy-slot", type=int, default=0, help=argparse.SUPPRESS)   # ... which share of the cores it takes
     ap.add_argument("--proxy-dir", default="", help=argparse.SUPPRESS)             # ... and where the N children meet
-    ap.add_argument("--no-concurrent-proxy", action="store_true",
-                    help="skip scale_proxy.concurrent (N children alive at once on the one GPU, each on its own CPUs)")
+    ap.add_argument("--concurrent-proxy", dest="no_concurrent_proxy", action="store_false", default=True,
+                    help="also run scale_proxy.concurrent (N children alive at once on the one GPU, each on its own CPUs; "
+                         "off by default since round 6: eight processes time-slice one device, so it says little about "
+                         "eight GPUs - VERDICT r5 - and costs the run 18 s)")
     ap.add_argument("--input-cache-MB", type=int, default=1024,
                     help="jga_pipeline_config.input_cache_mb of the headline pipelines: > 0 a persistent cache of that "
                          "many MB (pageable files are registered at first sight inside the timed region and DMA'd "

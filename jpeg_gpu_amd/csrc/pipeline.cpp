@@ -723,8 +723,10 @@ int lane_group(jga_pipeline *pl, hlane &l, jga_job *const *jobv, int m, int thre
   // take the FIFO: 3.5-3.9 against 4.0 with a registration per file and turns, profiles/r6_short_runs.md)
   bool all_pinned = true;
   for (int i = 0; i < m; i++) all_pinned = all_pinned && (jobv[i]->pinned & 1);
+  // (a caller that asked for the persistent cache keeps round 5's route: its buffers are registered once and read
+  // where they lie from then on)
   const bool fifo = short_run && shared && on_device && !pl->offload_cleanup && pl->short_fifo && pl->fifo_streams[0]
-   && (!all_pinned || pl->short_fifo_pinned);
+   && (!all_pinned || pl->short_fifo_pinned) && !pl->inputs.persistent;
   const unsigned ticket = fifo ? pl->run_ticket.fetch_add(1) : 0u;
   {
     for (int i = 0; i < m && on_device; i++) {
