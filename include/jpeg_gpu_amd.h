@@ -339,6 +339,11 @@ int   jga_host_register(void *p, size_t bytes);
 int   jga_host_unregister(void *p);
 int   jga_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
 int   jga_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+/* The same two copies through a pinned bounce buffer of the library's, synchronously (NULL stream): for host buffers that
+ * are short-lived ordinary memory — a copy that NAMES such memory leaves the runtime's pinning of it cached (read-only
+ * for a source), and the range may come back from the allocator as somebody's pixel buffer (csrc/device_api.cpp). */
+int   jga_upload_staged(void *d_dst, const void *h_src, size_t bytes);
+int   jga_download_staged(void *h_dst, const void *d_src, size_t bytes);
 int   jga_device_memset(void *dst, int value, size_t bytes, void *stream);
 int   jga_stream_sync(void *stream);
 int   jga_set_device(int dev);

@@ -3,6 +3,7 @@
 // reference's GL driver for the three passes (src/jpeg_gpu.c:902-1119 setup,
 // 1312-1399 per-frame upload + draws): one descriptor + one launch per batch.
 #include <hip/hip_runtime_api.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -407,6 +408,37 @@ JGA_EXPORT int jga_memcpy_h2d(void *dst, const void *src, size_t bytes, void *st
 JGA_EXPORT int jga_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return EXIT_SUCCESS;
+}
+// The same two copies for callers whose host buffers are SHORT-LIVED ordinary memory (the Python tooling: numpy arrays
+// made for one upload, results downloaded into fresh arrays): through a pinned bounce buffer, synchronously.  A copy that
+// NAMES ordinary memory makes the runtime pin what it touches and keep that pinning cached — read-only for a source;
+// when the allocator later hands the same range out as somebody's pixel buffer, a device write into it is a "Memory
+// access fault by GPU ... Write access to a read-only page" that aborts the process (round 5: bench.py's configs leg;
+// round 6: the same leg again, in a test run — the tooling's own uploads of coefficient planes were the pins).
+static std::mutex g_bounce_mutex;
+static unsigned char *g_bounce = nullptr;
+static const size_t BOUNCE_BYTES = (size_t)8 << 20;
+static int bounce_copy(void *dev, void *host, size_t bytes, bool h2d) {
+  std::lock_guard<std::mutex> lk(g_bounce_mutex);
+  if (!g_bounce) HIP_TRY(hipHostMalloc((void **)&g_bounce, BOUNCE_BYTES, hipHostMallocDefault));
+  for (size_t o = 0; o < bytes; o += BOUNCE_BYTES) {
+    const size_t n = bytes - o < BOUNCE_BYTES ? bytes - o : BOUNCE_BYTES;
+    if (h2d) {
+      memcpy(g_bounce, (const unsigned char *)host + o, n);
+      HIP_TRY(hipMemcpy((unsigned char *)dev + o, g_bounce, n, hipMemcpyHostToDevice));
+    }
+    else {
+      HIP_TRY(hipMemcpy(g_bounce, (const unsigned char *)dev + o, n, hipMemcpyDeviceToHost));
+      memcpy((unsigned char *)host + o, g_bounce, n);
+    }
+  }
+  return EXIT_SUCCESS;
+}
+JGA_EXPORT int jga_upload_staged(void *dst, const void *src, size_t bytes) {
+  return bounce_copy(dst, const_cast<void *>(src), bytes, true);
+}
+JGA_EXPORT int jga_download_staged(void *dst, const void *src, size_t bytes) {
+  return bounce_copy(const_cast<void *>(src), dst, bytes, false);
 }
 JGA_EXPORT int jga_device_memset(void *dst, int value, size_t bytes, void *stream) {
   HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));

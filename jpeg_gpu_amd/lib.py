@@ -18,7 +18,7 @@ EXPORTED = [
     "jga_device_count", "jga_idct_rgb_batch", "jga_idct_yuv_batch", "jga_idct_rgb_batch_dc", "jga_idct_yuv_batch_dc", "jga_huff_decode_split", "jga_kernel_name",
     "jga_index_count", "jga_unpack_batch", "jga_yuv_rgb_batch",
     "jga_device_malloc", "jga_device_free", "jga_host_malloc_pinned",
-    "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_device_memset",
+    "jga_host_free_pinned", "jga_memcpy_h2d", "jga_memcpy_d2h", "jga_upload_staged", "jga_download_staged", "jga_device_memset",
     "jga_stream_sync", "jga_set_device", "jga_device_pci_bus_id", "jga_stream_create", "jga_stream_destroy",
     "jga_time_idct_batch", "jga_pipeline_create", "jga_pipeline_run", "jga_pipeline_plan",
     "jga_pipeline_destroy", "jga_huff_create", "jga_huff_destroy", "jga_huff_prepare",
@@ -93,6 +93,8 @@ L.jga_host_free_pinned.argtypes = [_vp]
 L.jga_host_free_pinned.restype = None
 L.jga_memcpy_h2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
 L.jga_memcpy_d2h.argtypes = [_vp, _vp, C.c_size_t, _vp]
+L.jga_upload_staged.argtypes = [_vp, _vp, C.c_size_t]
+L.jga_download_staged.argtypes = [_vp, _vp, C.c_size_t]
 L.jga_device_memset.argtypes = [_vp, _i, C.c_size_t, _vp]
 L.jga_stream_sync.argtypes = [_vp]
 L.jga_set_device.argtypes = [_i]
@@ -257,6 +259,9 @@ def entropy_decode_pack(data, g=None):
 
 # ---- device stage ---------------------------------------------------------------
 
+_NAMED_COPIES = os.environ.get("JGA_TOOLING_NAMED_COPIES") == "1"
+
+
 class DeviceBuffer:
     """hipMalloc'd bytes owned through the C-ABI helpers."""
 
@@ -269,14 +274,24 @@ class DeviceBuffer:
     def upload(self, arr, offset=0, stream=None):
         arr = np.ascontiguousarray(arr)
         assert offset + arr.nbytes <= self.nbytes
-        check(L.jga_memcpy_h2d(self.ptr + offset, arr.ctypes.data, arr.nbytes, stream))
+        # (through the library's pinned bounce buffer: a copy that NAMED this short-lived array would leave the runtime's
+        # read-only pinning of its pages cached for whoever gets them next — csrc/device_api.cpp)
         check(L.jga_stream_sync(stream))
+        if _NAMED_COPIES:                                    # (A/B of the fault's cause only: tools/sessions/r6_s11.sh)
+            check(L.jga_memcpy_h2d(self.ptr + offset, arr.ctypes.data, arr.nbytes, stream))
+            check(L.jga_stream_sync(stream))
+            return
+        check(L.jga_upload_staged(self.ptr + offset, arr.ctypes.data, arr.nbytes))
 
     def download(self, nbytes=None, offset=0, dtype=np.uint8, stream=None):
         nbytes = self.nbytes - offset if nbytes is None else int(nbytes)
         out = np.empty(nbytes, np.uint8)
-        check(L.jga_memcpy_d2h(out.ctypes.data, self.ptr + offset, nbytes, stream))
         check(L.jga_stream_sync(stream))
+        if _NAMED_COPIES:
+            check(L.jga_memcpy_d2h(out.ctypes.data, self.ptr + offset, nbytes, stream))
+            check(L.jga_stream_sync(stream))
+            return out.view(dtype)
+        check(L.jga_download_staged(out.ctypes.data, self.ptr + offset, nbytes))
         return out.view(dtype)
 
     def fill(self, value, stream=None):

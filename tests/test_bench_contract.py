@@ -272,6 +272,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     assert any(k.startswith("all_") for k in e4["to_rgb_hbm"]) and "rank3_shard_of_8" in e4["to_rgb_hbm"]
     for v in e4["to_rgb_hbm"].values():
         assert v["pageable_files"]["Mpixel_s"] > 0 and v["pinned_files"]["Mpixel_s"] > 0
+    # ... and the photograph-like content class: verified, with what bounds it
+    for name in ("photo_like_4k_420", "photo_like_1080p_420"):
+        e = cf[name]
+        assert e["bit_exact_vs_oracle"] is True and 0.08 < e["bytes_per_pixel"] < 0.25, name
+        assert e["bound_by"] in ("link", "entropy stage", "block decode") and set(e["per_image_ms"]) == {"link", "entropy_stage", "block_decode"}
+        assert e["device"]["huffman_ms"] > 0 and e["device"]["idct_rgb_ms"] > 0 and e["to_rgb_hbm"]["steady"]["Mpixel_s"] > 0
+        assert line["configs"][name]["bound_by"] == e["bound_by"]
     hl = cf["headline_4k_420"]
     assert hl["to_rgb_hbm"]["Mpixel_s"] == d["value"] and hl["device"]["kernel_hbm_frac"] == d["roofline"]["frac"]
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1

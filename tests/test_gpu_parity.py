@@ -908,6 +908,44 @@ def test_gpu_huffman_full_size_and_end_to_end(gpu, orc, synth):
             b.free()
 
 
+def test_dense_frames_settle_on_the_device_without_the_hosts_walk(gpu, orc, synth):
+    """Round 6's policy sweep: a q97 8K frame (1.2 bytes per pixel: 310 k subsequences, chains of thirty steps and
+    more) did not settle within twelve rounds of which each list round is ONE step of the chain, and the host's walk
+    — meant for streams that never fall into step — took over: 6.5 ms where six in-group steps needed 0.9.  The walk
+    is now taken only when the work lists stop shrinking: the frame settles on the device (no subsequence walked by
+    the host), in more than twelve rounds, to the host stage's planes; and a stream that really never settles still
+    gets the walk."""
+    data = synth.synthetic_jpeg(7680, 4320, "420", quality=97, seed=11)
+    assert len(data) > 20 << 20
+    hb = gpu.HuffBatch(1, len(data) + 4096)
+    g = hb.prepare([data])
+    stride = (g.coef_shorts * 2 + 255) // 256 * 128
+    d_coef = gpu.DeviceBuffer(stride * 2)
+    rounds = hb.decode(d_coef.ptr, stride)
+    real = gpu.real_coef_mask(g)
+    assert np.array_equal(d_coef.download(dtype=np.int16)[:g.coef_shorts][real], gpu.entropy_decode(data, g)[real])
+    assert hb.assisted() == 0 and 12 < rounds < 96, (hb.assisted(), rounds)
+    hb.close()
+    d_coef.free()
+    # (the never-settling kind: a DC value alternating between two levels over a flat 4K frame)
+    _, g4 = gpu.geom_of(synth.synthetic_jpeg(3840, 2160, "420", quality=90, seed=1))
+    levels = np.zeros(g4.coef_shorts, np.int16)
+    levels.reshape(-1, 64)[:, 0] = 5
+    levels.reshape(-1, 64)[::2, 0] = -5                                         # (tools/periodic_streams.py: "dc alternating")
+    flat = synth.encode_levels(levels, 3840, 2160, "420")
+    hb = gpu.HuffBatch(1, len(flat) + 4096)
+    gpu.L.jga_huff_set_device_shared(hb.ptr, 2)                                 # (list rounds: the progress test applies)
+    g = hb.prepare([flat])
+    stride4 = (g.coef_shorts * 2 + 255) // 256 * 128
+    d_coef = gpu.DeviceBuffer(stride4 * 2)
+    hb.decode(d_coef.ptr, stride4)
+    real4 = gpu.real_coef_mask(g)
+    assert np.array_equal(d_coef.download(dtype=np.int16)[:g.coef_shorts][real4], gpu.entropy_decode(flat, g)[real4])
+    assert hb.assisted() > 0
+    hb.close()
+    d_coef.free()
+
+
 def test_gpu_huffman_rejects_truncated_scan(gpu, synth):
     data = synth.synthetic_jpeg(320, 200, "420", seed=3)
     with pytest.raises(gpu.JgaError):
