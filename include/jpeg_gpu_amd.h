@@ -591,7 +591,7 @@ long long jga_huff_host_bytes(const jga_huff_batch *b);
 /* Tunables of a batch object that used to be JGA_HUFF_* environment variables (still read by builds made
  * with -DJGA_TUNING).  value 0 = the default.  Returns EXIT_FAILURE for an unknown option or value. */
 enum {
-  JGA_HUFF_OPT_SUB_BYTES = 1,      /* subsequence length: 32, 64, 128, 256, 512; 0 = by batch */
+  JGA_HUFF_OPT_SUB_BYTES = 1,      /* subsequence length: 32, 64 or 128; 0 = by batch (256 / 512 were removed in round 6) */
   JGA_HUFF_OPT_ASSIST_AFTER = 2,   /* rounds before the host walks unsettled stretches (default 12) */
   JGA_HUFF_OPT_SPECULATE = 3,      /* 0 / 1 = the tail is queued behind the first rounds, -1 = never */
   /* 4: retired (round 4's JGA_HUFF_OPT_PIECES): rejected, so that a stale caller does not switch something else on */

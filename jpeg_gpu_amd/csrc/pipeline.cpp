@@ -72,18 +72,23 @@ sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   return k;
 }
 
-// Callers' pageable JPEG buffers kept registered with the device (jga_pipeline_config.input_cache_mb):
-// address -> registration, least recently used out first.  A lane ACQUIRES the buffers of its
-// group before it queues work that reads them and RELEASES them when its stream has drained; only
-// buffers nobody holds are evicted or forgotten.  hipHostRegister runs outside the lock (lanes register
-// different buffers side by side) — a buffer in the middle of being registered by one lane reads as "not
-// registered" to the others, who copy it as before.
+// Callers' pageable JPEG buffers registered with the device (jga_pipeline_config.input_cache_mb): address ->
+// registration.  A lane ACQUIRES the buffers of its group before it queues work that reads them and RELEASES them when
+// its stream has drained.  Two lifetimes (round 6):
+//   run-scoped (the default, input_cache_mb = 0): the last user's release() undoes the registration at once — nothing of
+//     the caller's memory is registered when jga_pipeline_run() returns, so the caller may free() it at will;
+//   persistent (input_cache_mb > 0): entries stay, least recently used out first when the cache is full; only buffers
+//     nobody holds are evicted or forgotten; the caller promises jga_pipeline_forget_input() before it frees one.
+// hipHostRegister runs outside the lock (lanes register different buffers side by side) — a buffer in the middle of
+// being registered by one lane reads as "not registered" to the others, who copy it as before.
 // A registration is made for a FILE, not for an address: the entry keeps a fingerprint of the buffer's contents
 // (size, first and last 64 bytes, sixteen 8-byte words spread over the rest) which the host re-reads at every sight.
 // The caller's buffer is plain malloc memory (reference src/jpeg_info.c:31-62: malloc, fread, free in
 // jpeg_info_clear): freed and handed out again at the same address for another file, it may be backed by other
 // pages than the ones the device has mapped — such a buffer fails the check, loses its registration and is
-// registered afresh (or copied, if somebody still holds the old one).
+// registered afresh (or copied, if somebody still holds the old one).  A buffer that meets "already registered" is
+// checked against the cache's OWN entries first (a stale entry under another key that covers it is dropped, or — if
+// it is in use — the buffer is copied): only ranges no own entry covers count as the caller's registration.
 struct input_cache {
   struct fingerprint {
     size_t bytes = 0;
