@@ -40,7 +40,8 @@ namespace {
 // jga_pipeline_create and jga_pipeline_plan_cfg, so that a plan is the plan a run makes.
 struct sched_knobs {
   int lanes, batch, link_slots, dev_slots, groups_per_lane, min_group_eq, offload_at, copy_streams;
-  bool ramp_first, blocking, trace, short_ramp;
+  bool ramp_first, blocking, trace;
+  int short_ramp;                                // 0 equal groups, 1 rising, 2 falling (tuning build only)
 };
 sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   sched_knobs k;
@@ -55,7 +56,7 @@ sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   k.groups_per_lane = 4;
   k.min_group_eq = 4;
   k.ramp_first = true;
-  k.short_ramp = false;
+  k.short_ramp = 0;
   k.offload_at = 8;
   k.copy_streams = 0;
   if (const char *e = jga_tune("JGA_PIPE_DEVICE_SLOTS")) k.dev_slots = atoi(e) > 0 ? atoi(e) : 1;
@@ -64,7 +65,7 @@ sched_knobs resolve_knobs(const jga_pipeline_config &c) {
   if (const char *e = jga_tune("JGA_PIPE_GROUPS_PER_LANE")) k.groups_per_lane = atoi(e) > 0 ? atoi(e) : 1;
   if (const char *e = jga_tune("JGA_PIPE_MIN_GROUP")) k.min_group_eq = atoi(e) > 0 ? atoi(e) : 1;
   if (const char *e = jga_tune("JGA_PIPE_RAMP_FIRST")) k.ramp_first = atoi(e) != 0;
-  if (const char *e = jga_tune("JGA_PIPE_SHORT_RAMP")) k.short_ramp = atoi(e) != 0;
+  if (const char *e = jga_tune("JGA_PIPE_SHORT_RAMP")) k.short_ramp = atoi(e);
   if (const char *e = jga_tune("JGA_PIPE_LINK_SLOTS")) k.link_slots = atoi(e) > 0 ? atoi(e) : 0;
   if (const char *e = jga_tune("JGA_PIPE_OFFLOAD_AT")) k.offload_at = atoi(e);
   if (jga_tune("JGA_PIPE_TRACE")) k.trace = true;
@@ -374,7 +375,7 @@ struct jga_pipeline {
   bool short_fifo = true, short_fifo_pinned = false;
   int fifo_nstreams = 1, fifo_threads = 1;       // (one copy stream moves 12 MB copies at the link's rate; a lane stages alone)
   int fifo_named = 0;                            // the run's first groups that name pinned files instead (tuning: JGA_PIPE_FIFO_NAMED)
-  bool short_ramp = false;
+  int short_ramp = 0;
   std::atomic<unsigned> run_ticket{0};
   std::mutex link_mutex;
   std::condition_variable link_cv;
@@ -963,7 +964,7 @@ uint64_t geometry_key(const unsigned char *p, int size) {
 // files are 256 frame equivalents: ONE group of 32 per lane) is cut finer, so that uploads,
 // entropy stage and block decode of different groups overlap: about groups_per_lane groups
 // per lane, none below min_group_eq frame equivalents.
-struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; bool short_ramp = false; };
+struct plan_params { int lanes, batch, groups_per_lane, min_group_eq; bool ramp_first; int short_ramp = 0; };
 void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<std::vector<int>> &groups) {
   const int nl = pp.lanes, batch = pp.batch;
   std::unordered_map<uint64_t, long long> pixels;            // geometry -> pixels of all its jobs
@@ -1011,10 +1012,13 @@ void plan_groups(const plan_params &pp, const jga_job *jobs, int n, std::vector<
       const long long count = pixels[key]/px, G = (count + cap - 1)/cap;
       if (G >= 4 && G <= nl) {
         const double top = 0.7*(double)G + 0.15;
+        // (2: the same weights from the other end — big groups first, so that the group that arrives LAST is small and
+        // its chain of kernels, what the run ends with, short)
+        auto weight = [&](long long k) { const long long j = pp.short_ramp == 2 ? G - 1 - k : k; return (double)(j + 1) < top ? (double)(j + 1) : top; };
         double sum = 0, upto = 0;
-        for (long long k = 0; k < G; k++) sum += (double)(k + 1) < top ? (double)(k + 1) : top;
-        for (long long k = 0; k <= made && k < G; k++) upto += (double)(k + 1) < top ? (double)(k + 1) : top;
-        const double before = upto - ((double)(made + 1) < top ? (double)(made + 1) : top);
+        for (long long k = 0; k < G; k++) sum += weight(k);
+        for (long long k = 0; k <= made && k < G; k++) upto += weight(k);
+        const double before = upto - weight(made < G ? made : G - 1);
         const long long a = (long long)((double)count*before/sum + 0.5), b = made + 1 >= G ? count : (long long)((double)count*upto/sum + 0.5);
         cap = b - a < 1 ? 1 : b - a;
       }
