@@ -28,7 +28,9 @@
 //     each: eight blocks per store instruction.
 // A third fewer instructions per block than the wave-per-block form (the lanes of short blocks
 // still sit out the trips of the longest one): [MI355X] 0.449 -> 0.349 ms per 48 x 4K = 0.61 of the
-// HBM peak (tools/ubench.py).
+// HBM peak (tools/ubench.py).  Round 6: a trip runs as three sweeps — positions, look-ups, stores — instead of a
+// branch + look-up + wait + store per word: 0.355 -> 0.342 ms = 0.62 (probes and what else was tried:
+// profiles/r6_short_runs.md 5).
 // Integer/byte work, HBM-bound: per block it reads 2 B x words + 4 B and writes 128 B.
 //
 // Out-of-range input is made safe, not meaningful: word reads stop at the end of the
@@ -42,9 +44,14 @@
 #ifndef PK_HOMOGENEOUS
 #define PK_HOMOGENEOUS 0             /* 1: a wave takes one MCU slot of 64 consecutive MCUs; 0: 64 blocks in scan order */
 #endif
-#define PK_BLK_STRIDE 33             /* dwords per lane's block buffer: 32 + its destination */
+#ifndef PK_BLK_STRIDE
+#define PK_BLK_STRIDE 33             /* dwords per lane's block buffer: 32 + its destination (36: 16-byte aligned buffers, an A/B) */
+#endif
 #ifndef PK_CHUNK
 #define PK_CHUNK 16                  /* words per trip: 8 or 16 */
+#endif
+#ifndef PK_PROBE
+#define PK_PROBE 0                   /* 1-3: timing probes with wrong output (tools/build_variant.sh), never in the product */
 #endif
 #ifndef PK_PREFETCH
 #define PK_PREFETCH 0                /* 1: the next trip's words are loaded before this trip's are placed */
@@ -67,13 +74,22 @@ static __device__ __forceinline__ int pk_sext12(uint32_t w) {
 
 __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_params P) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_blk[PK_BLOCK*PK_BLK_STRIDE];
-  __shared__ uint8_t s_dezz2[64];                          // BYTE offset of zig-zag position p in a block buffer
+  __shared__ uint8_t s_dezz2[68];                          // BYTE offset of zig-zag position p in a block buffer; [64]: the spare dword
   const uint32_t lane = threadIdx.x & 63;
   const int img = blockIdx.y;
   if (threadIdx.x < 64) s_dezz2[threadIdx.x] = (uint8_t)(2u*PK_DEZZ[threadIdx.x]);
+  if (threadIdx.x == 64) s_dezz2[64] = 128;                 // (words of a finished block land in dword 32, which receives the block's destination afterwards)
   uint32_t *blk = lds_blk + threadIdx.x*PK_BLK_STRIDE;
+#if PK_BLK_STRIDE % 4 == 0
+  {
+    const pk_v4u zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 8; q++) reinterpret_cast<pk_v4u *>(blk)[q] = zero4;   // (ds_write_b128)
+  }
+#else
 #pragma unroll
   for (int q = 0; q < 32; q++) blk[q] = 0;                  // own buffer only
+#endif
   __syncthreads();                                           // s_dezz2
 
   const uint32_t nslots = (uint32_t)P.nslots, nhmb = (uint32_t)P.nhmb;
@@ -124,13 +140,14 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
       k = (uint32_t)index[index0 + by*hblocks + bx];
     }
   }
-  blk[32] = dst;
-
   // Walk the block's words: word 0 is the DC level (position 0), every later one moves the
   // position by run + 1 — a zero word (end of block) by 64, which ends the walk like a run past
   // coefficient 63 does.
   uint8_t *blk8 = reinterpret_cast<uint8_t *>(blk);
   bool active = k < limit;                                   // (a start outside the stream: the block stays zero)
+#if PK_PROBE == 1
+  uint32_t probe_acc = 0;
+#endif
   bool dcword = true;
   int pos = 0;
   // PK_CHUNK words per trip (with PK_PREFETCH the next trip's are loaded before these are placed)
@@ -162,14 +179,45 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
 #if PK_PREFETCH
     const chunk nxt = fetch(k + (uint32_t)PK_CHUNK, active);
 #endif
+#if PK_PROBE
 #pragma unroll
     for (int j = 0; j < PK_CHUNK; j++) {
       const uint32_t w = (j & 1) ? cur.q[j >> 1] >> 16 : cur.q[j >> 1] & 0xffffu;
       const int inc = (j == 0 && dcword) ? 0 : w == 0u ? 64 : (int)(w >> 12) + 1;
       pos += inc;
       active = active && pos < 64;
+#if PK_PROBE == 1            /* timing probes only (round 6, profiles/r6_short_runs.md 5): no scatter at all: the loop's loads and arithmetic alone */
+      probe_acc += active ? (uint32_t)pk_sext12(w) + (uint32_t)pos : 0u;
+#elif PK_PROBE == 2          /* the scatter without its bank conflicts: every lane stores to ONE fixed halfword of its own buffer */
+      if (active) *reinterpret_cast<pk_i16_alias *>(blk8 + 2*(j & 1)) = (int16_t)pk_sext12(w);
+#elif PK_PROBE == 3          /* ... and without the de-zigzag look-up: the position itself as the offset (conflicts stay) */
+      if (active) *reinterpret_cast<pk_i16_alias *>(blk8 + 2*pos) = (int16_t)pk_sext12(w);
+#else                        /* 4: round 5's loop — per word a branch, a look-up, a wait, a store */
       if (active) *reinterpret_cast<pk_i16_alias *>(blk8 + s_dezz2[pos]) = (int16_t)pk_sext12(w);
+#endif
     }
+#else
+    // Three sweeps over the trip's words (round 6): the positions (a serial prefix in registers), ALL the de-zigzag
+    // look-ups (independent LDS reads: one latency per trip, where the branchy form — per word a test, a look-up, a
+    // wait, a store — paid sixteen in a row: 0.355 -> 0.32x ms per 48 x 4K, profiles/r6_short_runs.md 5), the stores.
+    // No branch: the words behind a block's end go to the spare dword.
+    uint32_t at[PK_CHUNK];
+#pragma unroll
+    for (int j = 0; j < PK_CHUNK; j++) {
+      const uint32_t w = (j & 1) ? cur.q[j >> 1] >> 16 : cur.q[j >> 1] & 0xffffu;
+      const int inc = (j == 0 && dcword) ? 0 : w == 0u ? 64 : (int)(w >> 12) + 1;
+      pos += inc;
+      active = active && pos < 64;
+      at[j] = active ? (uint32_t)pos : 64u;
+    }
+#pragma unroll
+    for (int j = 0; j < PK_CHUNK; j++) at[j] = s_dezz2[at[j]];
+#pragma unroll
+    for (int j = 0; j < PK_CHUNK; j++) {
+      const uint32_t w = (j & 1) ? cur.q[j >> 1] >> 16 : cur.q[j >> 1] & 0xffffu;
+      *reinterpret_cast<pk_i16_alias *>(blk8 + at[j]) = (int16_t)pk_sext12(w);
+    }
+#endif
     dcword = false;
     k += (uint32_t)PK_CHUNK;
 #if PK_PREFETCH
@@ -178,6 +226,10 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
     cur = fetch(k, active);
 #endif
   }
+#if PK_PROBE == 1
+  blk[0] = probe_acc;
+#endif
+  blk[32] = dst;                                             // (the spare dword's last use: where the block goes)
   // (a wave's LDS accesses execute in order: the writes above are visible to the reads below)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -192,7 +244,11 @@ __global__ __launch_bounds__(PK_BLOCK) void jga_unpack_kernel(const jga_pack_par
     const uint32_t *src = wave_blk + ((uint32_t)pass*8u + (lane >> 3))*PK_BLK_STRIDE;
     const uint32_t off = src[32];
     pk_v4u v;
+#if PK_BLK_STRIDE % 4 == 0
+    v = reinterpret_cast<const pk_v4u *>(src)[part];        // (ds_read_b128)
+#else
     v.x = src[4*part]; v.y = src[4*part + 1]; v.z = src[4*part + 2]; v.w = src[4*part + 3];
+#endif
     if (off != ~0u) {
       typedef __attribute__((address_space(1))) pk_v4u global_v4u;     // global_store, not flat
       __builtin_nontemporal_store(v, (global_v4u *)(uintptr_t)(planes + (size_t)off*128u) + part);
