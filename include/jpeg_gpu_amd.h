@@ -418,7 +418,8 @@ typedef struct jga_pipeline_config {
    *     callers' JPEG buffers with the device (hipHostRegister: 14 us for a 0.77 MB file where copying it costs a
    *     core 17) and the copy engine reads their scans where they lie, exactly like a `pinned` job's.
    *     input_cache_mb = 0 (default): a registration lives as long as the groups that use the buffer and is undone
-   *       by the last of them — NOTHING of the caller's memory is registered once jga_pipeline_run() has returned,
+   *       by the last of them (at most 4 GB held at a time; what does not fit is copied) — NOTHING of the caller's
+   *       memory is registered once jga_pipeline_run() has returned,
    *       so the caller may free() or reuse its buffers as it pleases.  (Short runs on a host with cores to spare
    *       copy small files into the group's pinned blob instead: one copy call per group, see csrc/pipeline.cpp.)
    *     input_cache_mb > 0: a PERSISTENT cache of that many MB, keyed by address, least recently used out first:

@@ -1135,7 +1135,9 @@ JGA_EXPORT jga_pipeline *jga_pipeline_create(const jga_pipeline_config *cfg) {
     pl->ramp_first = K.ramp_first;
     pl->link_slots = pl->link_free = K.link_slots;
     if (pl->cfg.input_cache_mb >= 0) {
-      pl->inputs.cap = (size_t)(pl->cfg.input_cache_mb > 0 ? pl->cfg.input_cache_mb : 512) << 20;
+      // (run-scoped registrations: the bound is on what the run's groups hold at one time — eight lanes' groups of
+      // 32 x 4K files are 0.8 GB; what does not fit is copied)
+      pl->inputs.cap = (size_t)(pl->cfg.input_cache_mb > 0 ? pl->cfg.input_cache_mb : 4096) << 20;
       pl->inputs.persistent = pl->cfg.input_cache_mb > 0;
       pl->inputs.sight = pl->inputs.persistent && pl->cfg.input_cache_sight > 0 ? pl->cfg.input_cache_sight : 1;
     }
