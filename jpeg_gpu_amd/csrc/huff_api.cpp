@@ -334,21 +334,36 @@ extern "C" JGA_EXPORT void jga_huff_reload_tuning(void) { the_round_knobs_rw() =
 // restart intervals with 64-byte subsequences (hj_choose_sub_log2), whose chains are twice as
 // many steps of half the length: six (one 1080p frame with an interval per MCU row 0.41 -> 0.39
 // ms, the 8K frame of BASELINE config 5 0.64 -> 0.60; intervals of a few subsequences: worse).
-static int auto_iters(const jga_huff_batch *b) {
-  const bool long_intervals = b->geom.restart_interval > 0 && b->sub_log2 == HJ_SUB_LOG2_MAX - 1
-   && b->total_seg > 0 && b->total_sub/b->total_seg >= 64u;
+// What the plan of a decode's rounds looks at (choose_rounds below; jga_huff_policy exposes the table to tests).
+struct batch_facts {
+  uint32_t total_sub, total_seg;
+  int sub_log2, nslots, restart_interval;
+  bool shared, own12;                    // other decodes share the device; the batch brought 12-bit tables per image
+};
+static batch_facts facts_of(const jga_huff_batch *b) {
+  batch_facts F;
+  F.total_sub = b->total_sub; F.total_seg = b->total_seg;
+  F.sub_log2 = b->sub_log2;
+  F.nslots = b->nimages > 0 ? ((const hj_image *)(b->h_blob + b->off_images))[0].nslots : 6;
+  F.restart_interval = b->geom.restart_interval;
+  F.shared = b->device_shared != 0;
+  F.own12 = b->wide && !b->wide_shared;
+  return F;
+}
+static int auto_iters(const batch_facts &F) {
+  const bool long_intervals = F.restart_interval > 0 && F.sub_log2 == HJ_SUB_LOG2_MAX - 1
+   && F.total_seg > 0 && F.total_sub/F.total_seg >= 64u;
   // (a small batch with its own 12-bit tables, every round by the dense kernel: four — fewer launches for the same
   // chain, a lone 1080p frame 0.355 -> 0.350 ms, 4K 0.386 -> 0.378, 4K 4:4:4 0.280 -> 0.269; five helps the 1080p frame
   // more and costs the 4K one: profiles/r5_lone_frame_chain.md)
-  if (b->wide && !b->wide_shared && !long_intervals) return 4;
+  if (F.own12 && !long_intervals) return 4;
   if (long_intervals) return 6;
   // (round 6, tools/policy_sweep.py: frames of three blocks per MCU or fewer — 4:4:4, grey — fall into step inside
   // one subsequence: beyond a small batch the third in-group step only holds the groups' barriers — 32 x 4K 4:4:4
   // 1.86 -> 1.66 ms, 128 x 1080p 4:4:4 1.87 -> 1.75, 32 x 4K grey 1.12 -> 1.03; four blocks per MCU (4:2:2) from 24 MB
   // on: 32 x 4K 1.32 -> 1.21, 128 x 1080p 1.35 -> 1.24; a lone 8K 4:2:2 frame of 16 MB is better off with three)
-  const uint64_t bytes = (uint64_t)b->total_sub << b->sub_log2;
-  const int nslots = b->nimages > 0 ? ((const hj_image *)(b->h_blob + b->off_images))[0].nslots : 6;
-  if ((nslots <= 3 && bytes > (8ull << 20)) || (nslots == 4 && bytes > (24ull << 20))) return 2;
+  const uint64_t bytes = (uint64_t)F.total_sub << F.sub_log2;
+  if ((F.nslots <= 3 && bytes > (8ull << 20)) || (F.nslots == 4 && bytes > (24ull << 20))) return 2;
   return 3;
 }
 // prepare() with the unstuffing left to the device: the host parses the marker segments
@@ -935,18 +950,33 @@ static double thread_cpu_ms() {
 // (the tuning build's JGA_HUFF_LIST / JGA_HUFF_ITERS / JGA_HUFF_BY_BLOCK force a column; tools/policy_sweep.py runs every
 // forced alternative over geometries x samplings x batch sizes x qualities x contents: profiles/r6_policy_sweep.md)
 struct round_choice { bool lists, by_block; int iters; };
+static round_choice policy_rounds(const batch_facts &F) {
+  const bool alone_small = !F.shared && F.total_sub <= 200u*1024u;
+  const bool dri = F.restart_interval > 0;
+  round_choice R;
+  R.iters = auto_iters(F);
+  R.lists = !(alone_small && (F.total_sub <= 128u*1024u || F.own12 || dri));
+  R.by_block = !F.shared && F.total_sub <= 64u*1024u;
+  return R;
+}
 static round_choice choose_rounds(const jga_huff_batch *b) {
   const round_knobs &K = the_round_knobs();
-  const bool alone_small = !b->device_shared && b->total_sub <= 200u*1024u;
-  const bool own12 = b->wide && !b->wide_shared;
-  const bool dri = b->geom.restart_interval > 0;
-  round_choice R;
-  R.iters = auto_iters(b);
-  R.lists = !(alone_small && (b->total_sub <= 128u*1024u || own12 || dri));
-  R.by_block = !b->device_shared && b->total_sub <= 64u*1024u;
-  if (K.list_from >= 0) R.lists = K.list_from < HJ_MAX_ROUNDS;
+  round_choice R = policy_rounds(facts_of(b));
+  if (K.list_from >= 0) R.lists = K.list_from < HJ_MAX_ROUNDS;                                  // (tuning build: a forced column)
   if (K.by_block_subs >= 0) R.by_block = !b->device_shared && b->total_sub <= (uint32_t)K.by_block_subs;
   return R;
+}
+// The table above as a function of the facts alone (host logic, no device): what a batch of `total_sub` subsequences of
+// 1 << sub_log2 bytes in `total_seg` restart segments, `nslots` blocks per MCU, would get.  For tests/test_huff_emul.py.
+extern "C" JGA_EXPORT void jga_huff_policy(unsigned total_sub, unsigned total_seg, int sub_log2, int nslots, int restart_interval,
+ int shared, int own12, int *lists, int *iters, int *by_block) {
+  batch_facts F;
+  F.total_sub = total_sub; F.total_seg = total_seg; F.sub_log2 = sub_log2; F.nslots = nslots;
+  F.restart_interval = restart_interval; F.shared = shared != 0; F.own12 = own12 != 0;
+  const round_choice R = policy_rounds(F);
+  if (lists) *lists = R.lists;
+  if (iters) *iters = R.iters;
+  if (by_block) *by_block = R.by_block;
 }
 
 // ---- a decode, in two halves -------------------------------------------------------------------------------

@@ -78,3 +78,36 @@ def test_plan_of_a_configuration_is_the_plan_of_its_lanes_and_batch(lib, synth):
     assert sizes(depth=8, batch=2) == [8] * 16                    # ... and none over a full group
     with pytest.raises(TypeError):
         lib.Pipeline.config(transport=2, min_group=8)             # (gone)
+
+
+def test_the_plan_of_a_decodes_rounds_is_one_table(lib):
+    """csrc/huff_api.cpp: choose_rounds — the rows of its table (jga_huff_policy: host logic, no device).  A batch
+    alone on the device and small keeps the dense kernel up to 128 k subsequences (and whenever it brought its own
+    12-bit tables, or has restart intervals) and writes by block up to 64 k; everything that fills or shares the device
+    runs its later rounds from work lists; in-group steps: 3, 4 with own 12-bit tables, 6 for long restart intervals
+    at 64-byte subsequences, 2 for batches over 8 MB of frames with <= 3 blocks per MCU (24 MB with 4)."""
+    L = lib.L
+    L.jga_huff_policy.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.jga_huff_policy.restype = None
+
+    def plan_of(total_sub, total_seg=1, sub_log2=7, nslots=6, ri=0, shared=0, own12=0):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        L.jga_huff_policy(total_sub, total_seg, sub_log2, nslots, ri, shared, own12, C.byref(a), C.byref(b), C.byref(c))
+        return {"lists": bool(a.value), "iters": b.value, "by_block": bool(c.value)}
+    k = 1024
+    assert plan_of(6 * k) == {"lists": False, "iters": 3, "by_block": True}               # one 1080p 4:2:0 frame
+    assert plan_of(24 * k, own12=1) == {"lists": False, "iters": 4, "by_block": True}      # one 4K frame, own 12-bit tables
+    assert plan_of(96 * k) == {"lists": False, "iters": 3, "by_block": False}              # 8 x 2.7K: dense (round 6)
+    assert plan_of(96 * k, shared=1) == {"lists": True, "iters": 3, "by_block": False}     # ... a pipeline's group: lists
+    assert plan_of(192 * k) == {"lists": True, "iters": 3, "by_block": False}              # 8 x 4K alone
+    assert plan_of(192 * k, own12=1)["lists"] is False and plan_of(192 * k, total_seg=2160, ri=240)["lists"] is False
+    assert plan_of(1146 * k) == {"lists": True, "iters": 3, "by_block": False}             # 48 x 4K: the headline's batch
+    # long restart intervals cut into 64-byte subsequences: six in-group steps (BASELINE config 5's 8K frame)
+    assert plan_of(192 * k, total_seg=270, sub_log2=6, ri=480)["iters"] == 6
+    assert plan_of(192 * k, total_seg=270 * 40, sub_log2=6, ri=12)["iters"] == 3           # ... short ones: three
+    # few blocks per MCU, beyond a small batch: two steps
+    assert plan_of(400 * k, nslots=3)["iters"] == 2 and plan_of(60 * k, nslots=3)["iters"] == 3      # 4:4:4: 50 MB / 7.5 MB
+    assert plan_of(400 * k, nslots=1)["iters"] == 2
+    assert plan_of(400 * k, nslots=4)["iters"] == 2 and plan_of(128 * k, nslots=4)["iters"] == 3     # 4:2:2: 50 MB / 16 MB
+    assert plan_of(400 * k, nslots=6)["iters"] == 3
